@@ -1,0 +1,158 @@
+/*
+ * qllm_mi355x.h -- C ABI of libqllm_mi355x.so: the MI355X (gfx950 / CDNA4) replacement for the native
+ * extensions behind QLLM's quantized-linear forward (fused int4 dequant + matmul).
+ *
+ * Boundary it replaces (all citations relative to /root/reference):
+ *   qllm.ort_ops.gemv        csrc/ort_cuda/ort_ops.cc:94-140   (op_gemv -> dq_gemv.cu gemv<half> / Gemv_g)
+ *   qllm.ort_ops.dequant     csrc/ort_cuda/ort_ops.cc:58-92    (dequant_any_bit -> DequantizeAndUnpackWeight*)
+ *   qllm.awq_inference_engine.gemm_forward_cuda
+ *                            csrc/awq_cuda/quantization/gemm_cuda.h:3-4, gemm_cuda_gen.cu:1102-1161
+ *   QuantLinearTorchFunction.forward (+bias) of the three q_layers
+ *                            qllm/modeling/q_layers/quant_linear_gptq.py:71-85,136-143
+ *                            qllm/modeling/q_layers/quant_linear_hqq.py:31-38,76-80
+ *                            qllm/modeling/q_layers/quant_linear_awq.py:142-148
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer on the current HIP device unless noted;
+ *     inputs are borrowed, contiguous, row-major; the library never allocates or frees device memory and never
+ *     synchronises the host with the device -- every entry point is hipGraph-capturable.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  The reference's default-stream
+ *     launches (dq_gemv.cu:166,563; gemm_cuda_gen.cu:1083) are NOT reproduced.
+ *   - every function returns a qllm_status_t (0 = ok).  Nothing aborts (contrast dq_gemv.cu:156-159,172-176);
+ *     the message for the calling thread's last failure is qllm_last_error().
+ *   - weight layouts are exactly the reference's state-dict buffers:
+ *       GPTQ     qweight i32 [K*bits/32, N] (column n = little-endian bit stream along K)
+ *                qzeros  i32 [ceil(K/g), N*bits/32] (row G = bit stream along N), or NULL => symmetric 2^(bits-1)
+ *                scales  f16 [ceil(K/g), N];  g_idx i32 [K] or NULL (NULL = k / group_size)
+ *       AWQ_GEMM qweight i32 [K, N/8], nibble i of word (k,j) = q[k, 8j+{0,2,4,6,1,3,5,7}[i]]; qzeros i32 [K/g, N/8]
+ *                same interleave; scales f16 [K/g, N]; 4-bit only; no g_idx
+ *       HQQ      qweight as GPTQ; qzeros f16 [ceil(K/g), N] (un-packed, non-integer); no g_idx
+ *   - numerics: W[k,n] = fp16( fp16(s*q) - fp16(z*s) ) exactly as DequantizeLinearBlockWise
+ *     (quant_linear_gptq.py:38-48) -- one IEEE rounding per op, bit-identical to the CPU path -- then
+ *     y = x.W accumulated in fp32 and rounded once to the activation dtype; bias added in fp32 before rounding.
+ */
+#ifndef QLLM_MI355X_H_
+#define QLLM_MI355X_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QLLM_ABI_VERSION 1
+
+typedef enum qllm_status {
+  QLLM_OK = 0,
+  QLLM_ERR_INVALID = 1,     /* bad shape / null pointer / misalignment (the reference's TORCH_CHECK / invalid_argument) */
+  QLLM_ERR_UNSUPPORTED = 2, /* valid request this build has no fused kernel for (caller may use dequant + GEMM) */
+  QLLM_ERR_WORKSPACE = 3,   /* workspace NULL or smaller than qllm_workspace_bytes() */
+  QLLM_ERR_LAUNCH = 4,      /* HIP launch failure (message carries hipGetErrorString) */
+  QLLM_ERR_DEVICE = 5       /* no gfx950 device / wrong architecture */
+} qllm_status_t;
+
+typedef enum qllm_layout {
+  QLLM_LAYOUT_GPTQ = 0,     /* QuantLinearGPTQ   quant_linear_gptq.py:92-117 */
+  QLLM_LAYOUT_AWQ_GEMM = 1, /* WQLinear_GEMM     quant_linear_awq.py:38-68   */
+  QLLM_LAYOUT_HQQ = 2       /* QuantLinearHQQ    quant_linear_hqq.py:47-68   */
+} qllm_layout_t;
+
+typedef enum qllm_dtype {
+  QLLM_F16 = 0,
+  QLLM_BF16 = 1
+} qllm_dtype_t;
+
+/* One quantized linear layer's buffers: the reference module's state dict, by pointer. */
+typedef struct qllm_weight {
+  const void *qweight;  /* i32, layout-dependent shape (see above) */
+  const void *scales;   /* f16 [ceil(K/g), N] */
+  const void *qzeros;   /* i32 packed (GPTQ/AWQ), f16 [ceil(K/g), N] (HQQ), or NULL (GPTQ symmetric) */
+  const int32_t *g_idx; /* i32 [K] act-order group map, or NULL for k / group_size (GPTQ only) */
+  const void *bias;     /* f16 [N] or NULL */
+  int32_t K;            /* in_features  */
+  int32_t N;            /* out_features */
+  int32_t group_size;   /* > 0 (callers map the reference's -1 to K) */
+  int32_t bits;         /* 2..8 (AWQ_GEMM: 4) */
+  int32_t layout;       /* qllm_layout_t */
+  int32_t add_zero_bias;/* COMPATIBLE_WITH_AUTOGPTQ: stored zero + this, masked (GPTQ packed zeros only) */
+} qllm_weight_t;
+
+typedef struct qllm_device_info {
+  char arch[32];              /* e.g. "gfx950" (feature suffixes stripped) */
+  int32_t compute_units;      /* 256 on MI355X */
+  int32_t wavefront_size;     /* 64 */
+  int32_t lds_bytes_per_cu;   /* 163840 */
+  int32_t clock_khz;
+  int64_t hbm_bytes;
+} qllm_device_info_t;
+
+/* ---- library ------------------------------------------------------------------------------------------- */
+int qllm_abi_version(void);
+/* Thread-local, never NULL; "" when the calling thread's last call succeeded. */
+const char *qllm_last_error(void);
+/* Fills `out` for HIP device `device`; QLLM_ERR_DEVICE if there is none or it is not gfx950. */
+int qllm_device_info(int device, qllm_device_info_t *out);
+
+/* ---- workspace ----------------------------------------------------------------------------------------- */
+/* Bytes of scratch qllm_linear_forward()/qllm_linear_forward_grouped() need for `w` at M rows (split-K slabs +
+ * arrival counters).  The region must be zero-filled once (qllm_workspace_init) before first use; the kernels
+ * leave it clean.  One workspace may be shared by calls that are ordered on one stream. */
+size_t qllm_workspace_bytes(const qllm_weight_t *w, int32_t M);
+int qllm_workspace_init(void *workspace, size_t bytes, void *stream);
+
+/* ---- the hot path -------------------------------------------------------------------------------------- */
+/* y[M,N] = x[M,K] . dequant(w) (+ bias).  x, y in `act_dtype`; scales/bias stay f16 (bf16 activations are
+ * converted on load, replacing the reference's bf16->f16 shims, ort_ops.cc:119-138, quant_linear_awq.py:29-36).
+ * Dispatch: M <= 64 -> weight-streaming MFMA matvec (HBM-bound); larger M -> LDS-tiled MFMA GEMM.
+ * Replaces QuantLinearTorchFunction.forward + bias for all three layouts. */
+int qllm_linear_forward(const qllm_weight_t *w, const void *x, void *y, int32_t M, int32_t act_dtype,
+                        void *workspace, size_t workspace_bytes, void *stream);
+
+/* n_weights layers that share the SAME input x (q/k/v, gate/up) in ONE launch: y[i] = x . dequant(w[i]).
+ * `w` and `y` are HOST arrays of length n_weights (<= 8); all w[i] must agree on K, bits, layout family and
+ * group_size.  M <= 64 only (decode); QLLM_ERR_UNSUPPORTED otherwise. */
+int qllm_linear_forward_grouped(const qllm_weight_t *w, void *const *y, int32_t n_weights, const void *x,
+                                int32_t M, int32_t act_dtype, void *workspace, size_t workspace_bytes,
+                                void *stream);
+
+/* W[K,N] (out_transposed = 0) or W[N,K] (out_transposed = 1) in `out_dtype`, bit-identical to
+ * DequantizeLinearBlockWise / DequantAndUnpack / unpack().  All bits 2..8, all layouts, optional g_idx.
+ * Replaces ort_ops.dequant (ort_ops.cc:58-92). */
+int qllm_dequant(const qllm_weight_t *w, void *out, int32_t out_dtype, int32_t out_transposed, void *stream);
+
+/* ---- reference-named entry points (flat signatures mirroring the pybind functions) ---------------------- */
+/* ort_ops.gemv(x, qweight, scales, qzeros, g_idx, groupsize, bits, in_features, add_zero_bias) -> y[M,N]
+ * (ort_ops.cc:94-98).  The reference restricts this to M <= 8 and 4 bits at the call site
+ * (quant_linear_gptq.py:76-80); here any M dispatches like qllm_linear_forward. */
+int qllm_ort_gemv(const void *x, const void *qweight, const void *scales, const void *qzeros,
+                  const int32_t *g_idx, int32_t groupsize, int32_t bits, int32_t in_features,
+                  int32_t add_zero_bias, void *y, int32_t M, int32_t N, int32_t act_dtype, void *workspace,
+                  size_t workspace_bytes, void *stream);
+
+/* ort_ops.dequant(qweight, scales, qzeros, g_idx, groupsize, bits, in_features, add_zero_bias) -> W[K,N] f16
+ * (ort_ops.cc:58-63). */
+int qllm_ort_dequant(const void *qweight, const void *scales, const void *qzeros, const int32_t *g_idx,
+                     int32_t groupsize, int32_t bits, int32_t in_features, int32_t add_zero_bias, void *out_kn,
+                     int32_t N, void *stream);
+
+/* awq_inference_engine.gemm_forward_cuda(x[M,K], qweight[K,N/8], scales[K/g,N], qzeros[K/g,N/8], split_k_iters)
+ * -> y[M,N] (gemm_cuda.h:3-4).  `split_k_iters` is accepted for signature parity and ignored: the reduction
+ * over K is carried in fp32, never as the reference's fp16 partial sums (gemm_cuda_gen.cu:1115,1160). */
+int qllm_awq_gemm_forward(const void *x, const void *qweight, const void *scales, const void *qzeros,
+                          int32_t split_k_iters, void *y, int32_t M, int32_t K, int32_t N, int32_t group_size,
+                          int32_t act_dtype, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- layout conversion on device (repack) ----------------------------------- */
+/* Integer grid q[K,N] (i32, natural order) <-> packed qweight of `layout`/`bits`.
+ * Replaces general_pack_on_row / general_unpack_on_row (+ AWQ reorder) (compress_weight.py:46-92,
+ * quant_linear_awq.py:95-140). */
+int qllm_unpack_qweight(const void *qweight, int32_t layout, int32_t bits, int32_t K, int32_t N, int32_t *q_kn,
+                        void *stream);
+int qllm_pack_qweight(const int32_t *q_kn, int32_t layout, int32_t bits, int32_t K, int32_t N, void *qweight,
+                      void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QLLM_MI355X_H_ */

@@ -1,0 +1,302 @@
+// C-ABI entry points of libqllm_mi355x.so: argument validation (the reference's TORCH_CHECK / invalid_argument
+// sites: /root/reference/csrc/ort_cuda/ort_ops.cc:64-73,99-107; csrc/awq_cuda/quantization/gemm_cuda_gen.cu:1128-1135),
+// kernel selection, workspace carving.  No allocation, no host sync, no global mutable state beyond thread-local
+// error text and a few env-derived tuning constants read once.
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "kernels.hpp"
+
+namespace qllm {
+
+// ---- error plumbing ----------------------------------------------------------------------------------------
+static thread_local char g_err[512] = {0};
+
+int set_error(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+void clear_error() { g_err[0] = 0; }
+
+// ---- tuning knobs (read once; for experiments, not part of the ABI) --------------------------------------------
+static int env_int(const char *name, int dflt) {
+  const char *v = getenv(name);
+  return (v && *v) ? atoi(v) : dflt;
+}
+static int skinny_target_waves() {
+  static int v = env_int("QLLM_SKINNY_WAVES", 2048);
+  return v;
+}
+static int skinny_awq_w(int M) {
+  static int v = env_int("QLLM_SKINNY_AWQ_W", 1);
+  return (M <= 16 && v == 2) ? 2 : 1;
+}
+static int skinny_max_m() {
+  static int v = env_int("QLLM_SKINNY_MAX_M", 64);
+  return v > 64 ? 64 : v;
+}
+
+constexpr size_t kCounterBytes = 16384;  // 4096 column-tile arrival counters at the head of the workspace
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---- validation ----------------------------------------------------------------------------------------------
+static int zero_kind_of(const qllm_weight_t &w) {
+  if (w.layout == QLLM_LAYOUT_HQQ) return ZK_F16;
+  if (w.qzeros == nullptr) return ZK_SYM;
+  return ZK_PACKED;
+}
+
+static int validate_weight(const qllm_weight_t *w) {
+  if (!w) return set_error(QLLM_ERR_INVALID, "weight descriptor is NULL");
+  if (!w->qweight || !w->scales) return set_error(QLLM_ERR_INVALID, "qweight/scales must not be NULL");
+  if (w->layout < QLLM_LAYOUT_GPTQ || w->layout > QLLM_LAYOUT_HQQ) return set_error(QLLM_ERR_INVALID, "unknown layout %d", w->layout);
+  if (w->bits < 2 || w->bits > 8) return set_error(QLLM_ERR_INVALID, "bits must be >= 2 and <= 8 (got %d)", w->bits);
+  if (w->K <= 0 || w->N <= 0) return set_error(QLLM_ERR_INVALID, "in_features/out_features must be >= 1 (K=%d N=%d)", w->K, w->N);
+  if (w->group_size < 8) return set_error(QLLM_ERR_INVALID, "groupsize must be >= 8 (got %d)", w->group_size);
+  if (w->layout == QLLM_LAYOUT_AWQ_GEMM) {
+    if (w->bits != 4) return set_error(QLLM_ERR_INVALID, "AWQ GEMM layout is 4-bit only (got %d)", w->bits);
+    if (w->N % 8 != 0) return set_error(QLLM_ERR_INVALID, "OC is not multiple of pack_num = 8 (N=%d)", w->N);
+    if (w->K % w->group_size != 0) return set_error(QLLM_ERR_INVALID, "IC is not multiple of group size (K=%d g=%d)", w->K, w->group_size);
+    if (!w->qzeros) return set_error(QLLM_ERR_INVALID, "AWQ GEMM layout needs qzeros");
+    if (w->g_idx) return set_error(QLLM_ERR_INVALID, "AWQ GEMM layout has no act-order (g_idx must be NULL)");
+  } else {
+    if ((w->K * w->bits) % 32 != 0) return set_error(QLLM_ERR_INVALID, "in_features*bits must be a multiple of 32 (K=%d bits=%d)", w->K, w->bits);
+    if (w->layout == QLLM_LAYOUT_HQQ && !w->qzeros) return set_error(QLLM_ERR_INVALID, "HQQ layout needs fp16 qzeros");
+    if (w->layout == QLLM_LAYOUT_HQQ && w->g_idx) return set_error(QLLM_ERR_INVALID, "HQQ layout has no act-order (g_idx must be NULL)");
+    if (w->layout == QLLM_LAYOUT_GPTQ && w->qzeros && (w->N * w->bits) % 32 != 0)
+      return set_error(QLLM_ERR_INVALID, "out_features*bits must be a multiple of 32 for packed zeros (N=%d bits=%d)", w->N, w->bits);
+  }
+  if (w->add_zero_bias < 0 || w->add_zero_bias > 1) return set_error(QLLM_ERR_INVALID, "add_zero_bias must be 0 or 1");
+  return QLLM_OK;
+}
+
+static bool fused_common_ok(const qllm_weight_t &w) {
+  return w.bits == 4 && w.N % 8 == 0 && w.group_size % 8 == 0 && ((uintptr_t)w.qweight % 16 == 0) &&
+         ((uintptr_t)w.scales % 16 == 0) && (!w.qzeros || (uintptr_t)w.qzeros % 8 == 0);
+}
+static bool skinny_ok(const qllm_weight_t &w, int M) {
+  return M <= skinny_max_m() && fused_common_ok(w) && w.K % 32 == 0 && w.g_idx == nullptr;
+}
+static bool gemm_ok(const qllm_weight_t &w) {
+  if (!fused_common_ok(w) || w.K % 64 != 0) return false;
+  if (w.layout == QLLM_LAYOUT_AWQ_GEMM) return w.group_size % 4 == 0;
+  if (w.g_idx) {
+    const int groups = (w.K + w.group_size - 1) / w.group_size;
+    return (size_t)groups * 128 * 4 + 65536 <= 160 * 1024;
+  }
+  return true;
+}
+
+static int run_skinny(const qllm_weight_t *w, void *const *y, int n, const void *x, int M, int act_dtype, void *workspace,
+                      size_t workspace_bytes, hipStream_t stream) {
+  const int layout = w[0].layout;
+  const int awq_w = skinny_awq_w(M);
+  const int tn = skinny_tile_cols(layout, awq_w);
+  int tiles_total = 0;
+  for (int i = 0; i < n; ++i) tiles_total += (w[i].N + tn - 1) / tn;
+  if (tiles_total > (int)(kCounterBytes / sizeof(int))) return set_error(QLLM_ERR_UNSUPPORTED, "too many column tiles (%d)", tiles_total);
+  int S, spw;
+  skinny_plan(w[0].K, M, tiles_total, skinny_target_waves(), &S, &spw);
+
+  SkinnyParams p;
+  memset(&p, 0, sizeof(p));
+  p.x = x;
+  p.n_prob = n;
+  p.M = M;
+  p.K = w[0].K;
+  p.T = w[0].K / 32;
+  p.group_size = w[0].group_size;
+  p.add_zero_bias = w[0].add_zero_bias;
+  p.act_bf16 = (act_dtype == QLLM_BF16);
+  size_t slab_off = kCounterBytes;
+  int tile_off = 0, block = 0;
+  for (int i = 0; i < n; ++i) {
+    SkinnyProblem &q = p.prob[i];
+    q.qweight = (const uint32_t *)w[i].qweight;
+    q.scales = (const half_t *)w[i].scales;
+    q.qzeros = w[i].qzeros;
+    q.bias = (const half_t *)w[i].bias;
+    q.y = y[i];
+    q.N = w[i].N;
+    q.n_tiles = (w[i].N + tn - 1) / tn;
+    q.S = S;
+    q.spw = spw;
+    q.block_begin = block;
+    q.zero_kind = zero_kind_of(w[i]);
+    q.counters = (int *)workspace + tile_off;
+    q.slabs = (float *)((char *)workspace + slab_off);
+    tile_off += q.n_tiles;
+    block += q.n_tiles * S;
+    if (S > 1) slab_off += align_up((size_t)S * M * w[i].N * sizeof(float), 256);
+  }
+  if (S > 1) {
+    if (!workspace) return set_error(QLLM_ERR_WORKSPACE, "split-K needs a workspace (call qllm_workspace_bytes)");
+    if (workspace_bytes < slab_off) return set_error(QLLM_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", slab_off, workspace_bytes);
+    if ((uintptr_t)workspace % 256 != 0) return set_error(QLLM_ERR_INVALID, "workspace must be 256-byte aligned");
+  }
+  return launch_skinny(p, layout, awq_w, block, stream);
+}
+
+static int check_io(const void *x, const void *y, int M, int act_dtype) {
+  if (!x || !y) return set_error(QLLM_ERR_INVALID, "x / y must not be NULL");
+  if (M <= 0) return set_error(QLLM_ERR_INVALID, "M must be >= 1 (got %d)", M);
+  if (act_dtype != QLLM_F16 && act_dtype != QLLM_BF16) return set_error(QLLM_ERR_INVALID, "act_dtype must be f16 or bf16");
+  if ((uintptr_t)x % 16 != 0) return set_error(QLLM_ERR_INVALID, "x must be 16-byte aligned");
+  return QLLM_OK;
+}
+
+}  // namespace qllm
+
+using namespace qllm;
+
+extern "C" {
+
+int qllm_abi_version(void) { return QLLM_ABI_VERSION; }
+
+const char *qllm_last_error(void) { return g_err; }
+
+int qllm_device_info(int device, qllm_device_info_t *out) {
+  clear_error();
+  if (!out) return set_error(QLLM_ERR_INVALID, "out is NULL");
+  memset(out, 0, sizeof(*out));
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) {
+    (void)hipGetLastError();
+    return set_error(QLLM_ERR_DEVICE, "no HIP device %d (count=%d)", device, count);
+  }
+  hipDeviceProp_t prop;
+  QLLM_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+  size_t n = 0;
+  while (prop.gcnArchName[n] && prop.gcnArchName[n] != ':' && n + 1 < sizeof(out->arch)) {
+    out->arch[n] = prop.gcnArchName[n];
+    ++n;
+  }
+  out->compute_units = prop.multiProcessorCount;
+  out->wavefront_size = prop.warpSize;
+  out->lds_bytes_per_cu = (int32_t)prop.maxSharedMemoryPerMultiProcessor;
+  out->clock_khz = prop.clockRate;
+  out->hbm_bytes = (int64_t)prop.totalGlobalMem;
+  if (strncmp(out->arch, "gfx950", 6) != 0) return set_error(QLLM_ERR_DEVICE, "device %d is %s, this library is gfx950-only", device, out->arch);
+  return QLLM_OK;
+}
+
+size_t qllm_workspace_bytes(const qllm_weight_t *w, int32_t M) {
+  if (!w || M <= 0 || M > 64) return kCounterBytes;
+  return kCounterBytes + align_up((size_t)skinny_max_split(M) * M * w->N * sizeof(float), 256);
+}
+
+int qllm_workspace_init(void *workspace, size_t bytes, void *stream) {
+  clear_error();
+  if (!workspace || bytes < kCounterBytes) return set_error(QLLM_ERR_WORKSPACE, "workspace must be at least %zu bytes", kCounterBytes);
+  QLLM_HIP_CHECK(hipMemsetAsync(workspace, 0, kCounterBytes, (hipStream_t)stream));
+  return QLLM_OK;
+}
+
+int qllm_linear_forward_grouped(const qllm_weight_t *w, void *const *y, int32_t n_weights, const void *x, int32_t M,
+                                int32_t act_dtype, void *workspace, size_t workspace_bytes, void *stream) {
+  clear_error();
+  if (!w || !y) return set_error(QLLM_ERR_INVALID, "w / y arrays must not be NULL");
+  if (n_weights < 1 || n_weights > kMaxProblems) return set_error(QLLM_ERR_INVALID, "n_weights must be 1..%d (got %d)", kMaxProblems, n_weights);
+  for (int i = 0; i < n_weights; ++i) {
+    int rc = validate_weight(&w[i]);
+    if (rc) return rc;
+    rc = check_io(x, y[i], M, act_dtype);
+    if (rc) return rc;
+    const bool rows0 = w[0].layout != QLLM_LAYOUT_AWQ_GEMM, rowsi = w[i].layout != QLLM_LAYOUT_AWQ_GEMM;
+    if (w[i].K != w[0].K || w[i].group_size != w[0].group_size || w[i].bits != w[0].bits || rows0 != rowsi ||
+        w[i].add_zero_bias != w[0].add_zero_bias)
+      return set_error(QLLM_ERR_INVALID, "grouped weights must agree on K, group_size, bits, layout family and add_zero_bias");
+    if (!skinny_ok(w[i], M)) return set_error(QLLM_ERR_UNSUPPORTED, "grouped forward needs the decode kernel (4-bit, M<=%d, K%%32==0, no act-order)", skinny_max_m());
+  }
+  return run_skinny(w, y, n_weights, x, M, act_dtype, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int qllm_linear_forward(const qllm_weight_t *w, const void *x, void *y, int32_t M, int32_t act_dtype, void *workspace,
+                        size_t workspace_bytes, void *stream) {
+  clear_error();
+  int rc = validate_weight(w);
+  if (rc) return rc;
+  rc = check_io(x, y, M, act_dtype);
+  if (rc) return rc;
+  if (skinny_ok(*w, M)) {
+    void *ys[1] = {y};
+    return run_skinny(w, ys, 1, x, M, act_dtype, workspace, workspace_bytes, (hipStream_t)stream);
+  }
+  if (gemm_ok(*w)) {
+    GemmParams p;
+    p.x = x;
+    p.qweight = (const uint32_t *)w->qweight;
+    p.scales = (const half_t *)w->scales;
+    p.qzeros = w->qzeros;
+    p.g_idx = w->g_idx;
+    p.bias = (const half_t *)w->bias;
+    p.y = y;
+    p.M = M;
+    p.K = w->K;
+    p.N = w->N;
+    p.group_size = w->group_size;
+    p.gs_shift = ((w->group_size & (w->group_size - 1)) == 0) ? __builtin_ctz((unsigned)w->group_size) : -1;
+    p.add_zero_bias = w->add_zero_bias;
+    p.zero_kind = zero_kind_of(*w);
+    p.act_bf16 = (act_dtype == QLLM_BF16);
+    p.n_groups = (w->K + w->group_size - 1) / w->group_size;
+    return launch_gemm(p, w->layout, (hipStream_t)stream);
+  }
+  return set_error(QLLM_ERR_UNSUPPORTED, "no fused kernel for bits=%d K=%d N=%d g=%d layout=%d act_order=%d; use qllm_dequant + GEMM",
+                   w->bits, w->K, w->N, w->group_size, w->layout, w->g_idx != nullptr);
+}
+
+int qllm_dequant(const qllm_weight_t *w, void *out, int32_t out_dtype, int32_t out_transposed, void *stream) {
+  clear_error();
+  int rc = validate_weight(w);
+  if (rc) return rc;
+  if (!out) return set_error(QLLM_ERR_INVALID, "out must not be NULL");
+  if (out_dtype != QLLM_F16 && out_dtype != QLLM_BF16) return set_error(QLLM_ERR_INVALID, "out_dtype must be f16 or bf16");
+  return launch_dequant(*w, zero_kind_of(*w), out, out_dtype, out_transposed ? 1 : 0, (hipStream_t)stream);
+}
+
+int qllm_ort_gemv(const void *x, const void *qweight, const void *scales, const void *qzeros, const int32_t *g_idx,
+                  int32_t groupsize, int32_t bits, int32_t in_features, int32_t add_zero_bias, void *y, int32_t M, int32_t N,
+                  int32_t act_dtype, void *workspace, size_t workspace_bytes, void *stream) {
+  qllm_weight_t w = {qweight, scales, qzeros, g_idx, nullptr, in_features, N, groupsize, bits, QLLM_LAYOUT_GPTQ, add_zero_bias};
+  return qllm_linear_forward(&w, x, y, M, act_dtype, workspace, workspace_bytes, stream);
+}
+
+int qllm_ort_dequant(const void *qweight, const void *scales, const void *qzeros, const int32_t *g_idx, int32_t groupsize,
+                     int32_t bits, int32_t in_features, int32_t add_zero_bias, void *out_kn, int32_t N, void *stream) {
+  qllm_weight_t w = {qweight, scales, qzeros, g_idx, nullptr, in_features, N, groupsize, bits, QLLM_LAYOUT_GPTQ, add_zero_bias};
+  return qllm_dequant(&w, out_kn, QLLM_F16, 0, stream);
+}
+
+int qllm_awq_gemm_forward(const void *x, const void *qweight, const void *scales, const void *qzeros, int32_t split_k_iters,
+                          void *y, int32_t M, int32_t K, int32_t N, int32_t group_size, int32_t act_dtype, void *workspace,
+                          size_t workspace_bytes, void *stream) {
+  (void)split_k_iters;
+  qllm_weight_t w = {qweight, scales, qzeros, nullptr, nullptr, K, N, group_size, 4, QLLM_LAYOUT_AWQ_GEMM, 0};
+  return qllm_linear_forward(&w, x, y, M, act_dtype, workspace, workspace_bytes, stream);
+}
+
+int qllm_unpack_qweight(const void *qweight, int32_t layout, int32_t bits, int32_t K, int32_t N, int32_t *q_kn, void *stream) {
+  clear_error();
+  if (!qweight || !q_kn) return set_error(QLLM_ERR_INVALID, "qweight / q_kn must not be NULL");
+  if (bits < 2 || bits > 8 || K <= 0 || N <= 0) return set_error(QLLM_ERR_INVALID, "bad bits/K/N (%d/%d/%d)", bits, K, N);
+  if (layout == QLLM_LAYOUT_AWQ_GEMM && (bits != 4 || N % 8)) return set_error(QLLM_ERR_INVALID, "AWQ GEMM layout is 4-bit, N%%8==0");
+  if (layout != QLLM_LAYOUT_AWQ_GEMM && (K * bits) % 32) return set_error(QLLM_ERR_INVALID, "K*bits must be a multiple of 32");
+  return launch_unpack_qweight(qweight, layout, bits, K, N, q_kn, (hipStream_t)stream);
+}
+
+int qllm_pack_qweight(const int32_t *q_kn, int32_t layout, int32_t bits, int32_t K, int32_t N, void *qweight, void *stream) {
+  clear_error();
+  if (!qweight || !q_kn) return set_error(QLLM_ERR_INVALID, "qweight / q_kn must not be NULL");
+  if (bits < 2 || bits > 8 || K <= 0 || N <= 0) return set_error(QLLM_ERR_INVALID, "bad bits/K/N (%d/%d/%d)", bits, K, N);
+  if (layout == QLLM_LAYOUT_AWQ_GEMM && (bits != 4 || N % 8)) return set_error(QLLM_ERR_INVALID, "AWQ GEMM layout is 4-bit, N%%8==0");
+  if (layout != QLLM_LAYOUT_AWQ_GEMM && (K * bits) % 32) return set_error(QLLM_ERR_INVALID, "K*bits must be a multiple of 32");
+  return launch_pack_qweight(q_kn, layout, bits, K, N, qweight, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,59 @@
+// Parameter blocks and host launchers shared by the translation units of libqllm_mi355x.
+#pragma once
+#include "common.hpp"
+
+namespace qllm {
+
+// ---- dequant.hip ---------------------------------------------------------------------------------------------
+int launch_dequant(const qllm_weight_t &w, int zero_kind, void *out, int out_dtype, int out_transposed, hipStream_t stream);
+int launch_unpack_qweight(const void *qweight, int layout, int bits, int K, int N, int32_t *q_kn, hipStream_t stream);
+int launch_pack_qweight(const int32_t *q_kn, int layout, int bits, int K, int N, void *qweight, hipStream_t stream);
+
+// ---- skinny.hip ----------------------------------------------------------------------------------------------
+constexpr int kMaxProblems = 8;
+
+struct SkinnyProblem {
+  const uint32_t *qweight;
+  const half_t *scales;
+  const void *qzeros;
+  const half_t *bias;
+  void *y;
+  float *slabs;   // [S][M][N] fp32 (only if S > 1)
+  int *counters;  // [n_tiles]
+  int N;
+  int n_tiles;
+  int S;            // blocks along K
+  int spw;          // k-steps (32 k) per wave
+  int block_begin;  // first blockIdx.x of this problem
+  int zero_kind;
+};
+
+struct SkinnyParams {
+  SkinnyProblem prob[kMaxProblems];
+  const void *x;
+  int n_prob;
+  int M, K, T;  // T = K / 32
+  int group_size;
+  int add_zero_bias;
+  int act_bf16;
+};
+
+int skinny_tile_cols(int layout, int awq_w);
+int skinny_max_split(int M);
+void skinny_plan(int K, int M, int tiles_total, int target_waves, int *S_out, int *spw_out);
+int launch_skinny(const SkinnyParams &p, int layout, int awq_w, int grid, hipStream_t stream);
+
+// ---- gemm.hip ------------------------------------------------------------------------------------------------
+struct GemmParams {
+  const void *x;
+  const uint32_t *qweight;
+  const half_t *scales;
+  const void *qzeros;
+  const int32_t *g_idx;
+  const half_t *bias;
+  void *y;
+  int M, K, N, group_size, gs_shift, add_zero_bias, zero_kind, act_bf16, n_groups;
+};
+int launch_gemm(const GemmParams &p, int layout, hipStream_t stream);
+
+}  // namespace qllm

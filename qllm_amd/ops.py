@@ -1,0 +1,162 @@
+"""torch-facing wrappers over the C ABI: pass data_ptr()s + the current HIP stream, allocate outputs and the
+split-K workspace with torch's caching allocator (the library itself never allocates).
+
+PyTorch is plumbing here (device memory, streams); all compute is in libqllm_mi355x.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import (DT_BF16, DT_F16, LAYOUT_AWQ_GEMM, LAYOUT_GPTQ, LAYOUT_HQQ, QllmUnsupported, QllmWeight)
+
+LAYOUTS = {"GPTQ": LAYOUT_GPTQ, "GEMM": LAYOUT_AWQ_GEMM, "AWQ": LAYOUT_AWQ_GEMM, "HQQ": LAYOUT_HQQ}
+
+_workspaces: dict = {}
+
+
+def _check_input(t: torch.Tensor, name: str):
+    # the reference's CHECK_INPUT (csrc/ort_cuda/ort_ops.cc:6-10): device tensor, contiguous
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a HIP/CUDA tensor (qllm_amd has no CPU forward path)")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+
+
+def _stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _act_dtype(t: torch.Tensor) -> int:
+    if t.dtype == torch.float16:
+        return DT_F16
+    if t.dtype == torch.bfloat16:
+        return DT_BF16
+    raise RuntimeError(f"activations must be float16 or bfloat16, got {t.dtype}")
+
+
+def workspace(device: torch.device, nbytes: int) -> torch.Tensor:
+    """Per-(device, stream) scratch for split-K slabs + arrival counters; zero-filled once (kernels leave it clean)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), _stream_ptr())
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        size = max(int(nbytes), 1 << 20)
+        ws = torch.zeros(size, dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def make_weight(layout: str, qweight, scales, qzeros, g_idx, bias, in_features: int, out_features: int,
+                group_size: int, bits: int, add_zero_bias: int = 0):
+    """Build the C descriptor.  Returns (QllmWeight, keepalive tuple of tensors whose pointers it holds)."""
+    lay = LAYOUTS[layout.upper()]
+    for name, t in (("qweight", qweight), ("scales", scales)):
+        _check_input(t, name)
+    if scales.dtype != torch.float16:
+        raise RuntimeError("scales must be float16 at the C boundary (cast bf16 scales once, like ort_ops.cc:79-90)")
+    if qweight.dtype != torch.int32:
+        raise RuntimeError("qweight must be int32")
+    if qzeros is not None:
+        _check_input(qzeros, "qzeros")
+        want = torch.float16 if lay == LAYOUT_HQQ else torch.int32
+        if qzeros.dtype != want:
+            raise RuntimeError(f"qzeros must be {want} for layout {layout}")
+    if g_idx is not None:
+        _check_input(g_idx, "g_idx")
+        if g_idx.dtype != torch.int32:
+            raise RuntimeError("g_idx must be int32")
+    if bias is not None:
+        _check_input(bias, "bias")
+        if bias.dtype != torch.float16:
+            raise RuntimeError("bias must be float16 at the C boundary")
+    w = QllmWeight(
+        qweight.data_ptr(), scales.data_ptr(), qzeros.data_ptr() if qzeros is not None else None,
+        g_idx.data_ptr() if g_idx is not None else None, bias.data_ptr() if bias is not None else None,
+        int(in_features), int(out_features), int(group_size), int(bits), lay, int(add_zero_bias))
+    return w, (qweight, scales, qzeros, g_idx, bias)
+
+
+def linear_forward(w: QllmWeight, x2d: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y[M,N] = x2d[M,K] . dequant(w) (+bias) through the fused HIP kernels.  Raises QllmUnsupported when the
+    library has no fused kernel for the configuration (caller may then use dequant() + matmul)."""
+    _check_input(x2d, "x")
+    lib = _lib.load()
+    m = x2d.shape[0]
+    if x2d.dim() != 2 or x2d.shape[1] != w.K:
+        raise RuntimeError(f"x must be [M, {w.K}], got {tuple(x2d.shape)}")
+    if out is None:
+        out = torch.empty((m, w.N), dtype=x2d.dtype, device=x2d.device)
+    if m == 0:
+        return out
+    nbytes = lib.qllm_workspace_bytes(C.byref(w), m)
+    ws = workspace(x2d.device, nbytes)
+    with torch.cuda.device(x2d.device):
+        rc = lib.qllm_linear_forward(C.byref(w), x2d.data_ptr(), out.data_ptr(), m, _act_dtype(x2d), ws.data_ptr(),
+                                     ws.numel(), _stream_ptr())
+    _lib.check(rc)
+    return out
+
+
+def linear_forward_grouped(ws_desc: Sequence[QllmWeight], x2d: torch.Tensor,
+                           outs: Optional[Sequence[torch.Tensor]] = None):
+    """Several layers sharing x (q/k/v, gate/up) in ONE launch (decode sizes only)."""
+    _check_input(x2d, "x")
+    lib = _lib.load()
+    n = len(ws_desc)
+    m = x2d.shape[0]
+    if outs is None:
+        outs = [torch.empty((m, w.N), dtype=x2d.dtype, device=x2d.device) for w in ws_desc]
+    arr = (QllmWeight * n)(*ws_desc)
+    ys = (C.c_void_p * n)(*[o.data_ptr() for o in outs])
+    nbytes = sum(lib.qllm_workspace_bytes(C.byref(w), m) for w in ws_desc)
+    wsp = workspace(x2d.device, nbytes)
+    with torch.cuda.device(x2d.device):
+        rc = lib.qllm_linear_forward_grouped(arr, ys, n, x2d.data_ptr(), m, _act_dtype(x2d), wsp.data_ptr(),
+                                             wsp.numel(), _stream_ptr())
+    _lib.check(rc)
+    return list(outs)
+
+
+def dequant(w: QllmWeight, device: torch.device, dtype=torch.float16, transposed: bool = False) -> torch.Tensor:
+    """W[K,N] (or [N,K]) bit-identical to the reference's DequantizeLinearBlockWise / unpack()."""
+    lib = _lib.load()
+    shape = (w.N, w.K) if transposed else (w.K, w.N)
+    out = torch.empty(shape, dtype=dtype, device=device)
+    dt = DT_F16 if dtype == torch.float16 else DT_BF16
+    if dtype not in (torch.float16, torch.bfloat16):
+        raise RuntimeError("dequant output must be float16 or bfloat16")
+    with torch.cuda.device(device):
+        rc = lib.qllm_dequant(C.byref(w), out.data_ptr(), dt, 1 if transposed else 0, _stream_ptr())
+    _lib.check(rc)
+    return out
+
+
+def unpack_qweight(qweight: torch.Tensor, layout: str, bits: int, in_features: int, out_features: int) -> torch.Tensor:
+    _check_input(qweight, "qweight")
+    q = torch.empty((in_features, out_features), dtype=torch.int32, device=qweight.device)
+    with torch.cuda.device(qweight.device):
+        rc = _lib.load().qllm_unpack_qweight(qweight.data_ptr(), LAYOUTS[layout.upper()], bits, in_features,
+                                             out_features, q.data_ptr(), _stream_ptr())
+    _lib.check(rc)
+    return q
+
+
+def pack_qweight(q_kn: torch.Tensor, layout: str, bits: int) -> torch.Tensor:
+    _check_input(q_kn, "q_kn")
+    if q_kn.dtype != torch.int32:
+        raise RuntimeError("q_kn must be int32")
+    k, n = q_kn.shape
+    lay = LAYOUTS[layout.upper()]
+    shape = (k, n // 8) if lay == LAYOUT_AWQ_GEMM else (k * bits // 32, n)
+    out = torch.empty(shape, dtype=torch.int32, device=q_kn.device)
+    with torch.cuda.device(q_kn.device):
+        rc = _lib.load().qllm_pack_qweight(q_kn.data_ptr(), lay, bits, k, n, out.data_ptr(), _stream_ptr())
+    _lib.check(rc)
+    return out
+
+
+__all__ = ["make_weight", "linear_forward", "linear_forward_grouped", "dequant", "unpack_qweight", "pack_qweight",
+           "workspace", "QllmUnsupported", "LAYOUTS"]

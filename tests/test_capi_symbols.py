@@ -1,0 +1,67 @@
+"""The C-ABI library builds, loads on a GPU-less host and exports every symbol include/qllm_mi355x.h declares.
+No compute is launched here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from qllm_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "qllm_mi355x.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(qllm_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not _lib.is_built():
+        import __graft_entry__
+        __graft_entry__.build()
+    return _lib.load()
+
+
+def test_header_and_binding_agree():
+    assert declared_symbols() == sorted(_lib.EXPORTS)
+
+
+def test_every_declared_symbol_is_exported(lib):
+    for name in declared_symbols():
+        assert hasattr(lib, name), name
+        assert ctypes.cast(getattr(lib, name), ctypes.c_void_p).value
+
+
+def test_version_and_error_plumbing(lib):
+    assert lib.qllm_abi_version() == _lib.ABI_VERSION
+    # argument validation runs before any device work, so it is testable without a GPU
+    w = _lib.QllmWeight(None, None, None, None, None, 256, 128, 128, 4, 0, 0)
+    rc = lib.qllm_linear_forward(ctypes.byref(w), None, None, 1, 0, None, 0, None)
+    assert rc == _lib.QLLM_ERR_INVALID and "NULL" in _lib.last_error()
+    w = _lib.QllmWeight(16, 16, None, None, None, 256, 128, 128, 9, 0, 0)
+    assert lib.qllm_dequant(ctypes.byref(w), 16, 0, 0, None) == _lib.QLLM_ERR_INVALID
+    assert "bits" in _lib.last_error()
+    w = _lib.QllmWeight(16, 16, 16, None, None, 256, 100, 128, 4, _lib.LAYOUT_AWQ_GEMM, 0)
+    assert lib.qllm_dequant(ctypes.byref(w), 16, 0, 0, None) == _lib.QLLM_ERR_INVALID
+    assert "pack_num" in _lib.last_error()
+    with pytest.raises(_lib.QllmError):
+        _lib.check(_lib.QLLM_ERR_INVALID)
+
+
+def test_workspace_bytes_is_pure(lib):
+    w = _lib.QllmWeight(16, 16, 16, None, None, 4096, 4096, 128, 4, 0, 0)
+    b1 = lib.qllm_workspace_bytes(ctypes.byref(w), 1)
+    b16 = lib.qllm_workspace_bytes(ctypes.byref(w), 16)
+    assert b1 >= 16384 and b16 > b1
+    assert lib.qllm_workspace_bytes(ctypes.byref(w), 2048) == 16384  # GEMM path needs counters only
+
+
+def test_device_probe_fails_cleanly_without_gpu(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    info = _lib.QllmDeviceInfo()
+    assert lib.qllm_device_info(0, ctypes.byref(info)) == _lib.QLLM_ERR_DEVICE

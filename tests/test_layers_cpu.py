@@ -1,0 +1,156 @@
+"""Host logic of the q_layers (pack / unpack / dispatch / contract) against the reference-minted goldens. CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from qllm_amd.modeling.q_layers import QuantLinearGPTQ, QuantLinearHQQ, WQLinear_GEMM
+from qllm_amd.modeling.q_layers import compress_weight as cw
+from qllm_amd.utils import modelutils
+
+LAYER = {"GPTQ": QuantLinearGPTQ, "GEMM": WQLinear_GEMM, "HQQ": QuantLinearHQQ}
+
+
+def build_layer_by_pack(g):
+    """Construct the layer the way the reference's pack_model does: target_layer(...).pack(linear, scales, zeros, g_idx)."""
+    gi = torch.from_numpy(g["g_idx"]).long()
+    scales = torch.from_numpy(g["scales"])
+    zeros = torch.from_numpy(g["zeros"])
+    q = torch.from_numpy(g["q"])
+    w_kn = scales.double()[gi] * (q.double() - zeros.double()[gi])
+    lin = torch.nn.Linear(g["K"], g["N"], bias=g["bias"] is not None, dtype=torch.float64)
+    lin.weight.data = w_kn.T.contiguous()
+    os.environ["COMPATIBLE_WITH_AUTOGPTQ"] = str(g["compat"])
+    try:
+        layer = LAYER[g["layout"]](g["bits"], g["groupsize"], g["K"], g["N"], g["bias"] is not None, dtype=torch.float16)
+        z_arg = zeros if g["layout"] == "HQQ" else zeros.float()
+        layer.pack(lin, scales.float().T.contiguous(), z_arg.T.contiguous(), torch.from_numpy(g["g_idx"]).clone())
+    finally:
+        os.environ["COMPATIBLE_WITH_AUTOGPTQ"] = "0"
+    return layer
+
+
+def test_pack_matches_reference_bit_exact(golden):
+    g = golden
+    layer = build_layer_by_pack(g)
+    assert layer.qweight.dtype == torch.int32 and tuple(layer.qweight.shape) == g["qweight"].shape
+    assert np.array_equal(layer.qweight.numpy(), g["qweight"])
+    assert tuple(layer.qzeros.shape) == g["qzeros"].shape
+    assert np.array_equal(layer.qzeros.numpy(), g["qzeros"])
+    assert np.array_equal(layer.scales.numpy().view(np.uint16), g["scales"].view(np.uint16))
+    assert np.array_equal(layer.g_idx.numpy(), g["g_idx"])
+
+
+def test_unpack_matches_reference_bit_exact(golden):
+    g = golden
+    if "W_unpack" not in g:
+        pytest.skip("large fixture keeps W_fwd only")
+    layer = LAYER[g["layout"]](g["bits"], g["groupsize"], g["K"], g["N"], g["bias"] is not None, dtype=torch.float16)
+    layer.qweight = torch.from_numpy(g["qweight"])
+    layer.qzeros = torch.from_numpy(g["qzeros"])
+    layer.scales = torch.from_numpy(g["scales"])
+    layer.g_idx = torch.from_numpy(g["g_idx"])
+    w, s, z = layer.unpack()
+    assert tuple(w.shape) == (g["N"], g["K"])
+    assert np.array_equal(w.numpy().view(np.uint16), g["W_unpack"].view(np.uint16))
+    assert np.array_equal(s.numpy().view(np.uint16), g["scales"].view(np.uint16))
+    if g["layout"] != "HQQ" and not g["compat"]:
+        assert np.array_equal(z.numpy(), g["zeros"])
+
+
+def test_state_dict_contract():
+    for cls, kw in ((QuantLinearGPTQ, {}), (QuantLinearHQQ, {}), (WQLinear_GEMM, {})):
+        layer = cls(4, 128, 256, 128, True, dtype=torch.float16)
+        sd = layer.state_dict()
+        assert {"qweight", "qzeros", "scales", "bias"} <= set(sd)
+        assert ("g_idx" in sd) == (cls is QuantLinearGPTQ)  # registered buffer only for GPTQ
+        assert sd["scales"].shape == (2, 128) and sd["scales"].dtype == torch.float16
+        if cls is WQLinear_GEMM:
+            assert sd["qweight"].shape == (256, 16) and sd["qzeros"].shape == (2, 16)
+            assert layer.w_bit == 4 and layer.group_size == 128
+        elif cls is QuantLinearHQQ:
+            assert sd["qweight"].shape == (32, 128) and sd["qzeros"].shape == (2, 128)
+            assert sd["qzeros"].dtype == torch.float16
+        else:
+            assert sd["qweight"].shape == (32, 128) and sd["qzeros"].shape == (2, 16)
+        for attr in ("bits", "groupsize", "infeatures", "outfeatures", "pack_mode", "orig_fp_weight", "g_idx"):
+            assert hasattr(layer, attr)
+    assert QuantLinearGPTQ(3, 64, 256, 128, False).qweight.shape == (24, 128)
+    assert QuantLinearGPTQ(4, -1, 256, 128, False).groupsize == 256
+    with pytest.raises(NotImplementedError):
+        WQLinear_GEMM(3, 128, 256, 128, False)
+    with pytest.raises(NotImplementedError):
+        QuantLinearGPTQ(9, 128, 256, 128, False)
+
+
+def test_forward_refuses_cpu_tensors():
+    """The product has no CPU compute path: forward on CPU tensors must fail loudly, never fall back."""
+    layer = QuantLinearGPTQ(4, 128, 256, 128, False, dtype=torch.float16)
+    with pytest.raises(RuntimeError, match="no CPU"):
+        layer(torch.zeros(1, 256, dtype=torch.float16))
+    with pytest.raises(RuntimeError, match="no CPU"):
+        WQLinear_GEMM(4, 128, 256, 128, False, dtype=torch.float16)(torch.zeros(1, 256, dtype=torch.float16))
+
+
+def test_autogptq_fixup_matches_reference():
+    g = load_golden("gptq_w4_g128_autogptq")
+    layer = QuantLinearGPTQ(4, 128, g["K"], g["N"], False, dtype=torch.float16)
+    layer.qzeros = torch.from_numpy(g["qzeros"].copy())
+    layer.handle_qzeros_for_autogptq()
+    assert np.array_equal(layer.qzeros.numpy(), g["qzeros_fixed"])
+
+
+def test_awq_refuses_act_order():
+    layer = WQLinear_GEMM(4, 128, 256, 128, False, dtype=torch.float16)
+    layer.g_idx = layer.g_idx[torch.randperm(256, generator=torch.Generator().manual_seed(0))]
+    layer.g_idx[0] = 1
+    # reference: act_order True slips through its own assert; trivial-or-act-order is all it checks. Mirror that:
+    layer.reorder_int_tensor(torch.zeros((2, 128), dtype=torch.int32))
+    layer.g_idx = torch.cat([layer.g_idx[128:], layer.g_idx[:128]])
+    layer.g_idx[:32] = 0  # first g//bits entries zero but not trivial -> assertion
+    with pytest.raises(AssertionError):
+        layer.reorder_int_tensor(torch.zeros((2, 128), dtype=torch.int32))
+
+
+@pytest.mark.parametrize("bits", [2, 3, 4, 5, 6, 7, 8])
+def test_bitstream_roundtrip_and_inplace_api(bits):
+    gen = torch.Generator().manual_seed(bits)
+    q = torch.randint(0, 2 ** bits, (64, 24), generator=gen, dtype=torch.int32)
+    packed = torch.zeros((64 * bits // 32, 24), dtype=torch.int32)
+    cw.general_pack_on_row(packed, q, bits)
+    back = torch.zeros_like(q)
+    cw.general_unpack_on_row(packed, back, bits)
+    assert torch.equal(back, q)
+    z = torch.randint(0, 2 ** bits, (3, 64), generator=gen, dtype=torch.int32)
+    pz = torch.zeros((3, 64 * bits // 32), dtype=torch.int32)
+    cw.general_pack_on_row(pz, z, bits)
+    bz = torch.zeros_like(z)
+    cw.general_unpack_on_row(pz, bz, bits)
+    assert torch.equal(bz, z)
+
+
+def test_select_and_swap():
+    assert modelutils.select_quant_linear("GPTQ", 4, "gptq") is QuantLinearGPTQ
+    assert modelutils.select_quant_linear("GEMM", 4, "awq") is WQLinear_GEMM
+    assert modelutils.select_quant_linear("AUTO", 3, "hqq") is QuantLinearHQQ
+    assert modelutils.select_quant_linear("AUTO", 3, "gptq") is QuantLinearGPTQ  # no engine on CPU -> GPTQ, as reference
+    with pytest.raises(NotImplementedError):
+        modelutils.select_quant_linear("MARLIN", 4, "gptq")
+
+    class Blk(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.q = torch.nn.Linear(256, 128, bias=False)
+            self.mlp = torch.nn.ModuleList([torch.nn.Linear(256, 512, bias=True)])
+            self.head = torch.nn.Linear(128, 10)
+
+    m = Blk().half()
+    info = {"q": {"wbits": 4, "groupsize": 128}, "mlp.0": {"wbits": 3, "groupsize": 64}, "quant_method": "hqq"}
+    modelutils.make_mixbits_quant_linear(m, ["q", "mlp.0"], info, target_layer=QuantLinearHQQ)
+    assert isinstance(m.q, QuantLinearHQQ) and m.q.bits == 4 and m.q.groupsize == 128 and m.q.bias is None
+    assert isinstance(m.mlp[0], QuantLinearHQQ) and m.mlp[0].bits == 3 and m.mlp[0].groupsize == 64
+    assert m.mlp[0].bias is not None and m.mlp[0].qweight.shape == (256 // 32 * 3, 512)
+    assert isinstance(m.head, torch.nn.Linear)
+    assert set(modelutils.find_layers(m, [QuantLinearHQQ])) == {"q", "mlp.0"}
