@@ -146,9 +146,16 @@ def test_properties_at_full_size():
     """Size-independent properties on Llama-2-7B shapes: exact scaling, zero weights, column independence."""
     d = synth("GEMM", 4, 128, 4096, 11008, seed=9)
     layer = to_layer(d, DEV)
-    x = torch.from_numpy(randx(4, 4096)).to(DEV)
+    xn = randx(4, 4096)
+    xn[np.abs(xn) < 1e-2] = 1e-2                      # keep every activation a normal fp16 number (see note below)
+    x = torch.from_numpy(xn).to(DEV)
     y = layer(x)
-    assert torch.equal(layer(x * 2), y * 2)          # power-of-two scaling commutes with every rounding
+    # power-of-two scaling commutes with every rounding as long as the OUTPUT is a normal fp16 number (a subnormal
+    # output rounds at a fixed 2^-24 quantum: measured 1 such element in 44k here), so compare those bit-for-bit.
+    y2 = layer(x * 2)
+    normal = y.abs() >= 6.2e-5
+    assert torch.equal(y2[normal], (y * 2)[normal])
+    assert (y2.float() - 2 * y.float()).abs().max() <= 2 ** -23
     assert torch.equal(layer(-x), -y)
     assert torch.count_nonzero(layer(torch.zeros_like(x))) == 0
     # q == z everywhere -> W == 0 -> y == bias exactly
