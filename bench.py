@@ -76,9 +76,9 @@ class Stack:
         for b in self.blocks:
             if grouped:
                 from qllm_amd import ops
-                q, k, v = ops.linear_forward_grouped([b[n]._descriptor(None, 0) for n in ("q", "k", "v")], h)
+                q, k, v = ops.linear_forward_grouped([b[n].decode_descriptor() for n in ("q", "k", "v")], h)
                 o = b["o"](q)
-                gate, up = ops.linear_forward_grouped([b[n]._descriptor(None, 0) for n in ("gate", "up")], o)
+                gate, up = ops.linear_forward_grouped([b[n].decode_descriptor() for n in ("gate", "up")], o)
             else:
                 q = b["q"](h)
                 k = b["k"](h)  # noqa: F841  (results feed attention in the real model)

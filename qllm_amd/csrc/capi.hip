@@ -82,6 +82,57 @@ static bool fused_common_ok(const qllm_weight_t &w) {
 static bool skinny_ok(const qllm_weight_t &w, int M) {
   return M <= skinny_max_m() && fused_common_ok(w) && w.K % 32 == 0 && w.g_idx == nullptr;
 }
+static int strip_min_strips() {
+  static int v = env_int("QLLM_STRIP_MIN", 192);
+  return v;
+}
+// full-K strip kernel: row-stream layouts, M <= 16, enough 16-column strips to cover the 256 CUs
+static bool strip_ok(const qllm_weight_t *w, int n, int M) {
+  if (M > 16 || strip_min_strips() <= 0) return false;
+  if (!strip_group_ok(w[0].group_size)) return false;
+  int strips = 0;
+  for (int i = 0; i < n; ++i) {
+    if (w[i].layout == QLLM_LAYOUT_AWQ_GEMM || w[i].N % 16 != 0) return false;
+    strips += w[i].N / 16;
+  }
+  if (strips < strip_min_strips()) return false;
+  const int nw = strip_nw(w[0].K, strips);
+  const int spw = strip_spw(w[0].K, w[0].group_size, nw);
+  return strip_x_ok(M, spw, nw) && strip_lds_bytes(M, spw, nw) <= 150 * 1024;
+}
+
+static int run_strip(const qllm_weight_t *w, void *const *y, int n, const void *x, int M, int act_dtype, hipStream_t stream) {
+  StripParams p;
+  memset(&p, 0, sizeof(p));
+  p.x = x;
+  p.n_prob = n;
+  p.M = M;
+  p.K = w[0].K;
+  p.T = w[0].K / 32;
+  int strips_total = 0;
+  for (int i = 0; i < n; ++i) strips_total += w[i].N / 16;
+  p.nw = strip_nw(w[0].K, strips_total);
+  p.spw = strip_spw(w[0].K, w[0].group_size, p.nw);
+  p.group_size = w[0].group_size;
+  p.add_zero_bias = w[0].add_zero_bias;
+  p.act_bf16 = (act_dtype == QLLM_BF16);
+  int block = 0;
+  for (int i = 0; i < n; ++i) {
+    StripProblem &q = p.prob[i];
+    q.qweight = (const uint32_t *)w[i].qweight;
+    q.scales = (const half_t *)w[i].scales;
+    q.qzeros = w[i].qzeros;
+    q.bias = (const half_t *)w[i].bias;
+    q.y = y[i];
+    q.N = w[i].N;
+    q.n_strips = w[i].N / 16;
+    q.block_begin = block;
+    q.zero_kind = zero_kind_of(w[i]);
+    block += q.n_strips;
+  }
+  return launch_strip(p, block, stream);
+}
+
 static bool gemm_ok(const qllm_weight_t &w) {
   if (!fused_common_ok(w) || w.K % 64 != 0) return false;
   if (w.layout == QLLM_LAYOUT_AWQ_GEMM) return w.group_size % 4 == 0;
@@ -213,6 +264,7 @@ int qllm_linear_forward_grouped(const qllm_weight_t *w, void *const *y, int32_t 
       return set_error(QLLM_ERR_INVALID, "grouped weights must agree on K, group_size, bits, layout family and add_zero_bias");
     if (!skinny_ok(w[i], M)) return set_error(QLLM_ERR_UNSUPPORTED, "grouped forward needs the decode kernel (4-bit, M<=%d, K%%32==0, no act-order)", skinny_max_m());
   }
+  if (strip_ok(w, n_weights, M)) return run_strip(w, y, n_weights, x, M, act_dtype, (hipStream_t)stream);
   return run_skinny(w, y, n_weights, x, M, act_dtype, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
@@ -225,6 +277,7 @@ int qllm_linear_forward(const qllm_weight_t *w, const void *x, void *y, int32_t 
   if (rc) return rc;
   if (skinny_ok(*w, M)) {
     void *ys[1] = {y};
+    if (strip_ok(w, 1, M)) return run_strip(w, ys, 1, x, M, act_dtype, (hipStream_t)stream);
     return run_skinny(w, ys, 1, x, M, act_dtype, workspace, workspace_bytes, (hipStream_t)stream);
   }
   if (gemm_ok(*w)) {

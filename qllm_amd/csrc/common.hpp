@@ -37,7 +37,14 @@ __device__ __forceinline__ uint32_t as_u32(half2_t v) { return __builtin_bit_cas
 __device__ __forceinline__ half2_t as_h2(uint32_t v) { return __builtin_bit_cast(half2_t, v); }
 __device__ __forceinline__ half2_t splat2(half_t v) { return half2_t{v, v}; }
 
-// (a & mask) | orv  -> one v_and_or_b32
+// (a & mask) | orv  -> one v_and_or_b32.  gfx950 VOP3 takes a single constant-bus operand, so with two literals
+// hipcc splits it into v_and + v_or; holding the mask in a VGPR the compiler cannot constant-fold lets it select the
+// fused op itself (no per-op inline asm, hence no hazard s_nops).
+__device__ __forceinline__ uint32_t nib_mask_vgpr() {
+  uint32_t m;
+  asm volatile("v_mov_b32 %0, 0x000f000f" : "=v"(m));
+  return m;
+}
 __device__ __forceinline__ uint32_t and_or(uint32_t a, uint32_t mask, uint32_t orv) { return (a & mask) | orv; }
 
 // fp16 "1024 + q" magic: low nibble of each 16-bit half -> exact fp16 (1024+q).
@@ -72,11 +79,11 @@ __device__ __forceinline__ half2_t deq_pair(uint32_t magic_pair, const ColConst 
 // Dequantise one GPTQ-style word (8 consecutive-k 4-bit values of one column) into a B fragment whose
 // register r holds k-slots (r, r+4):  {(k0,k4),(k1,k5),(k2,k6),(k3,k7)}.  The matching A fragment must be
 // permuted with a_perm_04152637().
-__device__ __forceinline__ half8_t deq_word_k04(uint32_t w, const ColConst &c) {
-  half2_t b0 = deq_pair(and_or(w, kNibLo, kMagic), c);
-  half2_t b1 = deq_pair(and_or(w >> 4, kNibLo, kMagic), c);
-  half2_t b2 = deq_pair(and_or(w >> 8, kNibLo, kMagic), c);
-  half2_t b3 = deq_pair(and_or(w >> 12, kNibLo, kMagic), c);
+__device__ __forceinline__ half8_t deq_word_k04(uint32_t w, const ColConst &c, uint32_t mask = kNibLo) {
+  half2_t b0 = deq_pair(and_or(w, mask, kMagic), c);
+  half2_t b1 = deq_pair(and_or(w >> 4, mask, kMagic), c);
+  half2_t b2 = deq_pair(and_or(w >> 8, mask, kMagic), c);
+  half2_t b3 = deq_pair(and_or(w >> 12, mask, kMagic), c);
   return half8_t{b0.x, b0.y, b1.x, b1.y, b2.x, b2.y, b3.x, b3.y};
 }
 

@@ -43,6 +43,37 @@ int skinny_max_split(int M);
 void skinny_plan(int K, int M, int tiles_total, int target_waves, int *S_out, int *spw_out);
 int launch_skinny(const SkinnyParams &p, int layout, int awq_w, int grid, hipStream_t stream);
 
+// ---- strip.hip -----------------------------------------------------------------------------------------------
+struct StripProblem {
+  const uint32_t *qweight;
+  const half_t *scales;
+  const void *qzeros;
+  const half_t *bias;
+  void *y;
+  int N;
+  int n_strips;     // N / 16
+  int block_begin;  // first blockIdx.x of this problem
+  int zero_kind;
+};
+
+struct StripParams {
+  StripProblem prob[kMaxProblems];
+  const void *x;
+  int n_prob;
+  int M, K, T;  // T = K / 32
+  int nw;       // waves per block (8 or 16)
+  int spw;      // k-steps per wave (nw waves per block cover all of K)
+  int group_size;
+  int add_zero_bias;
+  int act_bf16;
+};
+bool strip_group_ok(int group_size);
+int strip_nw(int K, int strips_total);
+int strip_spw(int K, int group_size, int nw);
+size_t strip_lds_bytes(int M, int spw, int nw);
+bool strip_x_ok(int M, int spw, int nw);
+int launch_strip(const StripParams &p, int grid, hipStream_t stream);
+
 // ---- gemm.hip ------------------------------------------------------------------------------------------------
 struct GemmParams {
   const void *x;

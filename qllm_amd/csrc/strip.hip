@@ -1,0 +1,223 @@
+// Full-K "strip" decode kernel: y[M<=16, N] = x . dequant(W4), GPTQ/HQQ row-stream layout, NO cross-block reduction.
+//
+// Why a second decode kernel: at batch 1 a Llama-2-7B linear is 8.7-23 MB, i.e. 1-3 us of HBM time, the same order
+// as ONE DRAM round trip under load.  The split-K kernel (skinny.hip) pays three more dependent round trips after
+// its loads (slab write-through, arrival ticket, slab read-back).  Here every block owns a 16-column strip for ALL
+// of K, so the dependency chain is: loads -> dequant+MFMA -> LDS reduce -> store.
+//
+//   * block = 16 waves (1024 threads) = one 16-column strip; wave w owns a contiguous K chunk of spw k-steps.
+//   * a wave-load is 64 lanes x 4 B = 4 word-rows x 64 B (lane (g,i): word-row r+g, column n0+i): exactly the
+//     B fragment of v_mfma_f32_16x16x32_f16 for 32 consecutive k.  ALL of a wave's loads -- its activation chunk
+//     (LDS-DMA straight into wave-private LDS, no registers), <= 24 weight dwords per lane, the scale/zero of every
+//     group it touches -- are issued back to back before the first wait: straight-line code, no branches in the loop.
+//   * the two 64-byte halves of every 128-byte line belong to strips 2j and 2j+1; the block->strip map places them
+//     on the same XCD (blocks b and b+8), so the line is fetched into one L2 only (measured: 10.5 -> 7.4 us on the
+//     22.5 MB shape; tools/lab/memlab.hip).
+//   * dequant is the bit-exact 3-op form (common.hpp); the activation fragment is permuted to the (k0,k4,k1,k5,..)
+//     slot order when it is read from LDS.
+//   * up to 8 layers sharing x run as one launch (q/k/v, gate/up).
+//
+// Replaces gemv<half> (/root/reference/csrc/ort_cuda/dq_gemv.cu:41-150).
+#include "kernels.hpp"
+
+namespace qllm {
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_cvoid_t;
+
+// MAXS: weight dwords per lane per round; SPG: k-steps per quantisation group (group_size / 32);
+// XL: 16-byte activation chunks staged per lane.  Everything below is straight-line: loads are never predicated
+// (addresses are clamped instead and the surplus is cancelled by zero activations), so hipcc keeps all of a wave's
+// loads in flight and waits for them one at a time with counted vmcnt.
+template <int NW, int MAXS, int SPG, int XL>
+__global__ __launch_bounds__(NW * 64) void strip_kernel(const StripParams p) {
+  constexpr int NG = MAXS / SPG;  // groups per round (MAXS is a multiple of SPG; rounds start on a group boundary)
+  // dynamic LDS: [0, 16 KB) reduction buffer red[wave][row][col]; then each wave's private copy of its activation
+  // chunk: M rows x (32*spw_pad) halves, row stride padded by 16 B.
+  extern __shared__ __attribute__((aligned(16))) float red[];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, i = lane & 15;
+
+  int pi = 0;
+#pragma unroll
+  for (int q = 1; q < kMaxProblems; ++q)
+    if (q < p.n_prob && (int)blockIdx.x >= p.prob[q].block_begin) pi = q;
+  const StripProblem &pr = p.prob[pi];
+
+  // strips 2j and 2j+1 (the two halves of each 128-byte line) on blocks b and b+8 -> same XCD
+  int b = blockIdx.x - pr.block_begin;
+  if ((pr.n_strips & 15) == 0) {
+    const int x = b & 7, r = b >> 3;
+    b = (((r >> 1) << 3) + x) * 2 + (r & 1);
+  }
+  const int N = pr.N;
+  const int n = b * 16 + i;  // this lane's column
+  const int M = p.M;
+
+  const int t0 = wave * p.spw;                    // spw is a multiple of SPG: every wave starts on a group boundary
+  const int kend = min(32 * (t0 + p.spw), p.K);   // activations at k >= kend are staged as zero
+  const int rounds = (p.spw + MAXS - 1) / MAXS;
+  const int spw_pad = rounds * MAXS;
+
+  // ---- 1. activations: this wave's [M][32*spw_pad] chunk -> registers now, wave-private LDS after the weight
+  //         loads have been issued.  k-slots stored in the (k0,k4,k1,k5,k2,k6,k3,k7) fragment order.
+  const int xrow = spw_pad * 32 + 8;  // halves per staged row (16 B pad spreads rows over banks)
+  half_t *xs = (half_t *)(red + NW * 16 * 16) + (size_t)wave * M * xrow;
+  const int cpr = spw_pad * 4;  // 16-byte chunks per row
+  const int xlast = M * cpr - 1;
+  half8_t xa[XL];
+  int xdst[XL];
+#pragma unroll
+  for (int u = 0; u < XL; ++u) {
+    const int c = min(lane + 64 * u, xlast);  // surplus lanes duplicate the last chunk (same bytes, same slot)
+    const int row = (M == 1) ? 0 : c / cpr;
+    const int kc = c - row * cpr;
+    const int k = 32 * t0 + 8 * kc;
+    const size_t off = (size_t)row * p.K + min(k, p.K - 8);
+    half8_t v;
+    if (p.act_bf16)
+      v = bf16x8_to_h8(*(const uint4_t *)((const uint16_t *)p.x + off));
+    else
+      v = *(const half8_t *)((const half_t *)p.x + off);
+    const half8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
+    xa[u] = (k < kend) ? v : zero;
+    xdst[u] = row * xrow + 8 * kc;
+  }
+  // lanes whose MFMA row is >= M read a valid row: their products only reach output rows that are never stored
+  const half_t *xlane = xs + min(i, M - 1) * xrow + 8 * g;
+
+  float4_t acc = {0.f, 0.f, 0.f, 0.f};
+  const uint32_t nibmask = nib_mask_vgpr();
+  const uint32_t *qw = pr.qweight + n;
+  const int Gmax = (p.K - 1) / p.group_size;
+  const int tmax = p.T - 1;
+  // zero points, branch-free addressing: packed -> word (G, n/8); fp16 -> the dword holding half (G, n);
+  // symmetric -> any valid dword (ignored)
+  const int zk = pr.zero_kind;
+  const uint32_t *zbase = (zk == ZK_SYM) ? (const uint32_t *)pr.scales : (const uint32_t *)pr.qzeros;
+  const int zmul = (zk == ZK_PACKED) ? (N >> 3) : (N >> 1);
+  const int zoff = (zk == ZK_PACKED) ? (n >> 3) : (n >> 1);
+
+  for (int r = 0; r < rounds; ++r) {
+    const int base = t0 + r * MAXS;
+    // ---- 2. scale / zero of every group this round touches: RAW loads only (tiny; issued first so they are back
+    //         first); nothing is consumed before the weight loads below have been issued ------------------------------
+    const int G0 = base / SPG;
+    half_t sc[NG];
+    uint32_t zraw[NG];
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+      const int G = min(G0 + j, Gmax);
+      sc[j] = pr.scales[(size_t)G * N + n];
+      zraw[j] = zbase[(size_t)G * zmul + zoff];
+    }
+    // ---- 3. every weight load of this round: exactly MAXS loads, rows clamped into the matrix -----------------------
+    uint32_t w[MAXS];
+#pragma unroll
+    for (int s = 0; s < MAXS; ++s) w[s] = __builtin_nontemporal_load(qw + (size_t)(4 * min(base + s, tmax) + g) * N);
+
+    half_t zz[NG];
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+      const half_t zp = (half_t)(float)(((zraw[j] >> (4 * (n & 7))) + (uint32_t)p.add_zero_bias) & 15u);
+      const half_t zf = __builtin_bit_cast(half_t, (uint16_t)((n & 1) ? (zraw[j] >> 16) : (zraw[j] & 0xffffu)));
+      zz[j] = (zk == ZK_PACKED) ? zp : ((zk == ZK_F16) ? zf : (half_t)8.f);
+    }
+
+    // ---- 4. activations -> LDS (first round only): needs the OLDEST loads only, the weights stay in flight ----------
+    if (r == 0) {
+#pragma unroll
+      for (int u = 0; u < XL; ++u) *(half8_t *)(xs + xdst[u]) = a_perm_04152637(xa[u]);
+    }
+
+    // ---- 5. straight-line dequant + MFMA --------------------------------------------------------------------------------
+    const half_t *xr = xlane + 32 * (r * MAXS);
+    ColConst cc = make_col_const(sc[0], zz[0]);
+#pragma unroll
+    for (int s = 0; s < MAXS; ++s) {
+      if (s % SPG == 0 && s > 0) cc = make_col_const(sc[s / SPG], zz[s / SPG]);
+      const half8_t av = *(const half8_t *)(xr + 32 * s);
+      const half8_t bf = deq_word_k04(w[s], cc, nibmask);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bf, acc, 0, 0, 0);
+    }
+  }
+
+  // ---- 6. reduce the 16 waves' partials through LDS: red[wave][row][col] ------------------------------------------
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = 4 * g + r;
+    if (row < M) red[(wave * 16 + row) * 16 + i] = acc[r];
+  }
+  __syncthreads();
+  const int e = threadIdx.x;
+  if (e < M * 16) {
+    const int row = e >> 4, col = e & 15;
+    float v = 0.f;
+#pragma unroll
+    for (int wv = 0; wv < NW; ++wv) v += red[(wv * 16 + row) * 16 + col];
+    const int nn = b * 16 + col;
+    if (pr.bias) v += (float)pr.bias[nn];
+    if (p.act_bf16)
+      ((uint16_t *)pr.y)[(size_t)row * N + nn] = f32_to_bf16(v);
+    else
+      ((half_t *)pr.y)[(size_t)row * N + nn] = (half_t)v;
+  }
+}
+
+template <int NW, int MAXS, int SPG, int XL>
+static int launch_strip_t(const StripParams &p, int grid, size_t lds, hipStream_t stream) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    QLLM_HIP_CHECK(hipFuncSetAttribute((const void *)strip_kernel<NW, MAXS, SPG, XL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((strip_kernel<NW, MAXS, SPG, XL>), dim3(grid), dim3(NW * 64), lds, stream, p);
+  QLLM_HIP_CHECK(hipGetLastError());
+  return QLLM_OK;
+}
+
+// (waves per block, weight dwords per lane per round): 16 waves x 8 or 24, or 8 waves x 16
+static int strip_maxs(int nw, int spw) { return nw == 8 ? 16 : (spw <= 8 ? 8 : 24); }
+static int strip_spw_pad(int nw, int spw) { const int m = strip_maxs(nw, spw); return (spw + m - 1) / m * m; }
+static int strip_xl(int nw, int M, int spw) { return (M * strip_spw_pad(nw, spw) * 4 + 63) / 64; }
+
+template <int SPG>
+static int launch_strip_s(const StripParams &p, int grid, size_t lds, hipStream_t stream) {
+  const bool small_x = strip_xl(p.nw, p.M, p.spw) <= 2;
+  if (p.nw == 8)
+    return small_x ? launch_strip_t<8, 16, SPG, 2>(p, grid, lds, stream) : launch_strip_t<8, 16, SPG, 8>(p, grid, lds, stream);
+  if (strip_maxs(16, p.spw) == 8)
+    return small_x ? launch_strip_t<16, 8, SPG, 2>(p, grid, lds, stream) : launch_strip_t<16, 8, SPG, 8>(p, grid, lds, stream);
+  return small_x ? launch_strip_t<16, 24, SPG, 2>(p, grid, lds, stream) : launch_strip_t<16, 24, SPG, 8>(p, grid, lds, stream);
+}
+
+// group sizes the strip kernel serves: 64 and 128 (k-steps per group 2, 4); others use the split-K kernel
+bool strip_group_ok(int group_size) { return group_size == 64 || group_size == 128; }
+
+// waves per block: 8-wave blocks (4 per CU) when there are enough strips to need more than one round of 16-wave
+// blocks (2 per CU) and K is short enough for one 16-dword round per wave; else 16 waves
+int strip_nw(int K, int strips_total) { return (strips_total > 2 * kNumCU && K / 32 <= 8 * 16) ? 8 : 16; }
+
+// k-steps per wave: all of K over nw waves, rounded up to whole groups
+int strip_spw(int K, int group_size, int nw) {
+  const int T = K / 32, spg = group_size / 32;
+  int spw = (T + nw - 1) / nw;
+  return (spw + spg - 1) / spg * spg;
+}
+
+size_t strip_lds_bytes(int M, int spw, int nw) {
+  return (size_t)nw * 16 * 16 * sizeof(float) + (size_t)nw * M * (strip_spw_pad(nw, spw) * 32 + 8) * sizeof(half_t);
+}
+
+// activation staging budget: at most 8 sixteen-byte chunks per lane
+bool strip_x_ok(int M, int spw, int nw) { return strip_xl(nw, M, spw) <= 8; }
+
+int launch_strip(const StripParams &p, int grid, hipStream_t stream) {
+  const size_t lds = strip_lds_bytes(p.M, p.spw, p.nw);
+  if (p.group_size == 64) return launch_strip_s<2>(p, grid, lds, stream);
+  return launch_strip_s<4>(p, grid, lds, stream);
+}
+
+}  // namespace qllm

@@ -48,15 +48,22 @@ class HipForwardMixin:
             self._desc_key = key
         return self._desc
 
+    def decode_descriptor(self, act_order_g_idx=None, add_zero_bias: int = 0):
+        """Descriptor the decode-sized (M <= 16) kernels should stream.  Default: the module's own buffers."""
+        return self._descriptor(act_order_g_idx, add_zero_bias)
+
     def _hip_linear(self, x: torch.Tensor, act_order_g_idx=None, add_zero_bias: int = 0) -> torch.Tensor:
         if not x.is_cuda or not self.qweight.is_cuda:
             raise RuntimeError(
                 f"{type(self).__name__}.forward needs HIP tensors on an MI355X: qllm_amd ships no CPU / eager fallback "
                 f"(x on {x.device}, qweight on {self.qweight.device})")
-        w = self._descriptor(act_order_g_idx, add_zero_bias)
         x2d = x.reshape(-1, x.shape[-1])
         if not x2d.is_contiguous():
             x2d = x2d.contiguous()
+        if x2d.shape[0] <= 16:
+            w = self.decode_descriptor(act_order_g_idx, add_zero_bias)
+        else:
+            w = self._descriptor(act_order_g_idx, add_zero_bias)
         try:
             y = ops.linear_forward(w, x2d)
         except ops.QllmUnsupported:

@@ -55,3 +55,28 @@ def oracle_y(d, x, w=None):
 
 def randx(m, k, seed=1):
     return np.random.default_rng(seed).standard_normal((m, k)).astype(np.float16)
+
+
+class Ref:
+    """Oracle results for one synthetic layer, with the dequantised W converted once (the big-K cases are
+    otherwise dominated by re-converting W to float64 for every M)."""
+
+    def __init__(self, d):
+        self.d = d
+        self.w = oracle_w(d)
+        self.w16 = torch.from_numpy(self.w)
+        self.w64 = self.w16.double()
+        self.b16 = torch.from_numpy(d["bias"]) if d["bias"] is not None else None
+
+    def y16(self, x):
+        """what the reference's CPU path returns: fp16 matmul (+ bias)"""
+        y = torch.matmul(torch.from_numpy(x), self.w16)
+        if self.b16 is not None:
+            y = y + self.b16
+        return y.numpy()
+
+    def y64(self, x):
+        y = torch.from_numpy(x).double() @ self.w64
+        if self.b16 is not None:
+            y = y + self.b16.double()
+        return y.numpy()
