@@ -162,7 +162,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--grouped", type=int, default=int(os.environ.get("QLLM_BENCH_GROUPED", "0")),
+    ap.add_argument("--grouped", type=int, default=int(os.environ.get("QLLM_BENCH_GROUPED", "1")),
                     help="1: q/k/v and gate/up as single grouped launches (4 launches per layer instead of 7)")
     ap.add_argument("--no-extra", action="store_true", help="skip the per-shape / prefill / CPU legs")
     args = ap.parse_args()
@@ -230,7 +230,7 @@ def main():
                    "layers": LAYERS, "linears_per_layer": 7, "batch": 1, "launches_per_step": launches,
                    "grouped_qkv_gateup": grouped, "graph": True, "parallelism": f"replicas x{world}",
                    "device": info["arch"], "compute_units": info["compute_units"]},
-        "roofline": {"bound": "hbm", "kernel": "qllm::skinny_kernel (decode matvec, all 7 linears)",
+        "roofline": {"bound": "hbm", "kernel": "qllm::strip_kernel (decode matvec; serves every launch of the step)",
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
                      "bytes_per_launch": bpt // launches, "avg_launch_us": round(avg_launch_us, 3)},
@@ -246,11 +246,11 @@ def main():
             g, _ = capture(lambda: [l(x) for l in ls])
             ms = time_events(g.replay, 20) / len(ls)
             extra[f"decode_{name}"] = {"us": round(ms * 1e3, 2), "GBps": round(alg_bytes(K, N, 1) / ms / 1e6, 1)}
-        # grouped launches (q/k/v in one launch, gate/up in one launch)
-        gg, _ = capture(lambda: stack.forward(h0, True))
+        # the other launch granularity (grouped: q/k/v and gate/up as single launches; ungrouped: one per linear)
+        gg, _ = capture(lambda: stack.forward(h0, not grouped))
         ms = time_events(gg.replay, 20)
-        extra["decode_grouped_stack"] = {"ms_per_token": round(ms, 4), "tokens_per_s": round(1e3 / ms, 1),
-                                         "GBps": round(bpt / ms / 1e6, 1)}
+        extra["decode_stack_" + ("ungrouped" if grouped else "grouped")] = {
+            "ms_per_token": round(ms, 4), "tokens_per_s": round(1e3 / ms, 1), "GBps": round(bpt / ms / 1e6, 1)}
         # prefill M=2048 (BASELINE configs[2]: GPTQ act-order) and AWQ, one layer's 7 linears x 4 layers
         for tag, cls, act in (("awq", WQLinear_GEMM, False), ("gptq_actorder", QuantLinearGPTQ, True)):
             ps = Stack(cls, 4, dev, seed=99, act_order=act)

@@ -284,6 +284,22 @@ def matmul_f16(x, w_kn, bias=None, num_threads: int | None = None):
     return y
 
 
+def matmul_f16_via_f32(x, w_kn, bias=None):
+    """Same contraction as matmul_f16 carried in fp32 and rounded once to fp16 (+ bias in fp16 like the reference).
+    torch's CPU half GEMM accumulates in fp32 too, so the two agree to about an fp16 ulp (checked in
+    tests/test_oracle_golden.py); this form is used where the half GEMM is impractically slow (M > 16 on hosts
+    without native fp16 GEMM kernels)."""
+    import torch
+
+    xt = x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(x))
+    wt = w_kn if isinstance(w_kn, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(w_kn))
+    y = torch.matmul(xt.float(), wt.float()).to(xt.dtype)
+    if bias is not None:
+        bt = bias if isinstance(bias, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(bias))
+        y = y + bt.to(y.dtype)
+    return y
+
+
 def matmul_f64(x, w_kn, bias=None) -> np.ndarray:
     """High-precision reference (error budgets): float64 accumulate of the same fp16 operands."""
     import torch

@@ -87,21 +87,35 @@ static int strip_min_strips() {
   return v;
 }
 // full-K strip kernel: row-stream layouts, M <= 16, enough 16-column strips to cover the 256 CUs
-static bool strip_ok(const qllm_weight_t *w, int n, int M) {
+struct StripPlan {
+  int cpl, nw, spw;
+};
+static bool strip_plan(const qllm_weight_t *w, int n, int M, StripPlan *plan) {
   if (M > 16 || strip_min_strips() <= 0) return false;
   if (!strip_group_ok(w[0].group_size)) return false;
-  int strips = 0;
+  int cols = 0;
+  bool m64 = true;
   for (int i = 0; i < n; ++i) {
     if (w[i].layout == QLLM_LAYOUT_AWQ_GEMM || w[i].N % 16 != 0) return false;
-    strips += w[i].N / 16;
+    cols += w[i].N;
+    m64 = m64 && (w[i].N % 64 == 0);
   }
-  if (strips < strip_min_strips()) return false;
-  const int nw = strip_nw(w[0].K, strips);
-  const int spw = strip_spw(w[0].K, w[0].group_size, nw);
-  return strip_x_ok(M, spw, nw) && strip_lds_bytes(M, spw, nw) <= 150 * 1024;
+  static int force_cpl = env_int("QLLM_STRIP_CPL", 0);
+  plan->cpl = force_cpl ? ((force_cpl == 4 && m64) ? 4 : 1) : strip_cpl(cols, m64);
+  const int strips = cols / (16 * plan->cpl);
+  if (plan->cpl == 1 && strips < strip_min_strips()) return false;
+  plan->nw = plan->cpl == 4 ? 16 : strip_nw(w[0].K, strips);
+  plan->spw = strip_spw(w[0].K, w[0].group_size, plan->nw);
+  return strip_x_ok(M, plan->spw, plan->nw, plan->cpl) && strip_lds_bytes(M, plan->spw, plan->nw, plan->cpl) <= 150 * 1024;
+}
+static bool strip_ok(const qllm_weight_t *w, int n, int M) {
+  StripPlan pl;
+  return strip_plan(w, n, M, &pl);
 }
 
 static int run_strip(const qllm_weight_t *w, void *const *y, int n, const void *x, int M, int act_dtype, hipStream_t stream) {
+  StripPlan pl;
+  if (!strip_plan(w, n, M, &pl)) return set_error(QLLM_ERR_INVALID, "internal: strip plan");
   StripParams p;
   memset(&p, 0, sizeof(p));
   p.x = x;
@@ -109,10 +123,9 @@ static int run_strip(const qllm_weight_t *w, void *const *y, int n, const void *
   p.M = M;
   p.K = w[0].K;
   p.T = w[0].K / 32;
-  int strips_total = 0;
-  for (int i = 0; i < n; ++i) strips_total += w[i].N / 16;
-  p.nw = strip_nw(w[0].K, strips_total);
-  p.spw = strip_spw(w[0].K, w[0].group_size, p.nw);
+  p.cpl = pl.cpl;
+  p.nw = pl.nw;
+  p.spw = pl.spw;
   p.group_size = w[0].group_size;
   p.add_zero_bias = w[0].add_zero_bias;
   p.act_bf16 = (act_dtype == QLLM_BF16);
@@ -125,7 +138,7 @@ static int run_strip(const qllm_weight_t *w, void *const *y, int n, const void *
     q.bias = (const half_t *)w[i].bias;
     q.y = y[i];
     q.N = w[i].N;
-    q.n_strips = w[i].N / 16;
+    q.n_strips = w[i].N / (16 * pl.cpl);
     q.block_begin = block;
     q.zero_kind = zero_kind_of(w[i]);
     block += q.n_strips;

@@ -51,7 +51,7 @@ struct StripProblem {
   const half_t *bias;
   void *y;
   int N;
-  int n_strips;     // N / 16
+  int n_strips;     // ceil(N / (16 * cpl))
   int block_begin;  // first blockIdx.x of this problem
   int zero_kind;
 };
@@ -62,6 +62,7 @@ struct StripParams {
   int n_prob;
   int M, K, T;  // T = K / 32
   int nw;       // waves per block (8 or 16)
+  int cpl;      // columns per lane: 1 (16-column strips) or 4 (64-column strips)
   int spw;      // k-steps per wave (nw waves per block cover all of K)
   int group_size;
   int add_zero_bias;
@@ -70,8 +71,9 @@ struct StripParams {
 bool strip_group_ok(int group_size);
 int strip_nw(int K, int strips_total);
 int strip_spw(int K, int group_size, int nw);
-size_t strip_lds_bytes(int M, int spw, int nw);
-bool strip_x_ok(int M, int spw, int nw);
+size_t strip_lds_bytes(int M, int spw, int nw, int cpl);
+int strip_cpl(int cols_total, bool all_mult64);
+bool strip_x_ok(int M, int spw, int nw, int cpl);
 int launch_strip(const StripParams &p, int grid, hipStream_t stream);
 
 // ---- gemm.hip ------------------------------------------------------------------------------------------------

@@ -25,14 +25,17 @@ namespace qllm {
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_cvoid_t;
 
-// MAXS: weight dwords per lane per round; SPG: k-steps per quantisation group (group_size / 32);
-// XL: 16-byte activation chunks staged per lane.  Everything below is straight-line: loads are never predicated
-// (addresses are clamped instead and the surplus is cancelled by zero activations), so hipcc keeps all of a wave's
-// loads in flight and waits for them one at a time with counted vmcnt.
-template <int NW, int MAXS, int SPG, int XL>
+// NW: waves per block; CPL: columns per lane (1 -> 16-column strip, 64-byte row segments; 4 -> 64-column strip,
+// 256-byte row segments, 4 MFMAs per k-step); MAXS: k-steps (weight loads) per lane per round; SPG: k-steps per
+// quantisation group (group_size / 32); XL: 16-byte activation chunks staged per lane.  Everything below is
+// straight-line: loads are never predicated (addresses are clamped instead and the surplus is cancelled by zero
+// activations), so hipcc keeps all of a wave's loads in flight and waits for them one at a time with counted vmcnt.
+template <int NW, int CPL, int MAXS, int SPG, int XL>
 __global__ __launch_bounds__(NW * 64) void strip_kernel(const StripParams p) {
-  constexpr int NG = MAXS / SPG;  // groups per round (MAXS is a multiple of SPG; rounds start on a group boundary)
-  // dynamic LDS: [0, 16 KB) reduction buffer red[wave][row][col]; then each wave's private copy of its activation
+  constexpr int NG = MAXS / SPG;   // groups per round (MAXS is a multiple of SPG; rounds start on a group boundary)
+  constexpr int TN = 16 * CPL;     // columns per block
+  typedef uint32_t wvec_t __attribute__((ext_vector_type(CPL)));
+  // dynamic LDS: reduction buffer red[wave][M rows][TN cols] fp32, then each wave's private copy of its activation
   // chunk: M rows x (32*spw_pad) halves, row stride padded by 16 B.
   extern __shared__ __attribute__((aligned(16))) float red[];
 
@@ -46,14 +49,15 @@ __global__ __launch_bounds__(NW * 64) void strip_kernel(const StripParams p) {
     if (q < p.n_prob && (int)blockIdx.x >= p.prob[q].block_begin) pi = q;
   const StripProblem &pr = p.prob[pi];
 
-  // strips 2j and 2j+1 (the two halves of each 128-byte line) on blocks b and b+8 -> same XCD
   int b = blockIdx.x - pr.block_begin;
-  if ((pr.n_strips & 15) == 0) {
+  if (CPL == 1 && (pr.n_strips & 15) == 0) {
+    // 64-byte segments: strips 2j and 2j+1 share every 128-byte line -> put them on blocks b and b+8 (same XCD)
     const int x = b & 7, r = b >> 3;
     b = (((r >> 1) << 3) + x) * 2 + (r & 1);
   }
   const int N = pr.N;
-  const int n = b * 16 + i;  // this lane's column
+  const int n = min(b * TN + i * CPL, N - CPL);  // this lane's first column (clamped for a ragged last strip)
+  const bool col_ok = (b * TN + i * CPL) < N;
   const int M = p.M;
 
   const int t0 = wave * p.spw;                    // spw is a multiple of SPG: every wave starts on a group boundary
@@ -64,7 +68,7 @@ __global__ __launch_bounds__(NW * 64) void strip_kernel(const StripParams p) {
   // ---- 1. activations: this wave's [M][32*spw_pad] chunk -> registers now, wave-private LDS after the weight
   //         loads have been issued.  k-slots stored in the (k0,k4,k1,k5,k2,k6,k3,k7) fragment order.
   const int xrow = spw_pad * 32 + 8;  // halves per staged row (16 B pad spreads rows over banks)
-  half_t *xs = (half_t *)(red + NW * 16 * 16) + (size_t)wave * M * xrow;
+  half_t *xs = (half_t *)(red + NW * M * TN) + (size_t)wave * M * xrow;
   const int cpr = spw_pad * 4;  // 16-byte chunks per row
   const int xlast = M * cpr - 1;
   half8_t xa[XL];
@@ -88,42 +92,57 @@ __global__ __launch_bounds__(NW * 64) void strip_kernel(const StripParams p) {
   // lanes whose MFMA row is >= M read a valid row: their products only reach output rows that are never stored
   const half_t *xlane = xs + min(i, M - 1) * xrow + 8 * g;
 
-  float4_t acc = {0.f, 0.f, 0.f, 0.f};
+  float4_t acc[CPL];
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) acc[c] = float4_t{0.f, 0.f, 0.f, 0.f};
   const uint32_t nibmask = nib_mask_vgpr();
   const uint32_t *qw = pr.qweight + n;
   const int Gmax = (p.K - 1) / p.group_size;
   const int tmax = p.T - 1;
-  // zero points, branch-free addressing: packed -> word (G, n/8); fp16 -> the dword holding half (G, n);
-  // symmetric -> any valid dword (ignored)
+  // zero points, branch-free addressing: packed -> word (G, n/8) (CPL | 8: one word holds the lane's columns);
+  // fp16 -> the dword(s) holding halves (G, n..n+CPL-1); symmetric -> any valid dword (ignored)
   const int zk = pr.zero_kind;
   const uint32_t *zbase = (zk == ZK_SYM) ? (const uint32_t *)pr.scales : (const uint32_t *)pr.qzeros;
   const int zmul = (zk == ZK_PACKED) ? (N >> 3) : (N >> 1);
   const int zoff = (zk == ZK_PACKED) ? (n >> 3) : (n >> 1);
+  const int zoff2 = (zk == ZK_F16 && CPL == 4) ? 1 : 0;
 
   for (int r = 0; r < rounds; ++r) {
     const int base = t0 + r * MAXS;
     // ---- 2. scale / zero of every group this round touches: RAW loads only (tiny; issued first so they are back
     //         first); nothing is consumed before the weight loads below have been issued ------------------------------
     const int G0 = base / SPG;
-    half_t sc[NG];
-    uint32_t zraw[NG];
+    half_t sc[NG][CPL];
+    uint32_t zraw[NG][2];
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
       const int G = min(G0 + j, Gmax);
-      sc[j] = pr.scales[(size_t)G * N + n];
-      zraw[j] = zbase[(size_t)G * zmul + zoff];
+      if constexpr (CPL == 4) {
+        const half4_t sv = *(const half4_t *)(pr.scales + (size_t)G * N + n);
+        sc[j][0] = sv.x; sc[j][1] = sv.y; sc[j][2] = sv.z; sc[j][3] = sv.w;
+      } else {
+        sc[j][0] = pr.scales[(size_t)G * N + n];
+      }
+      zraw[j][0] = zbase[(size_t)G * zmul + zoff];
+      zraw[j][1] = (CPL == 4) ? zbase[(size_t)G * zmul + zoff + zoff2] : 0u;
     }
     // ---- 3. every weight load of this round: exactly MAXS loads, rows clamped into the matrix -----------------------
-    uint32_t w[MAXS];
+    wvec_t w[MAXS];
 #pragma unroll
-    for (int s = 0; s < MAXS; ++s) w[s] = __builtin_nontemporal_load(qw + (size_t)(4 * min(base + s, tmax) + g) * N);
+    for (int s = 0; s < MAXS; ++s)
+      w[s] = __builtin_nontemporal_load((const wvec_t *)(qw + (size_t)(4 * min(base + s, tmax) + g) * N));
 
-    half_t zz[NG];
+    half_t zz[NG][CPL];
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
-      const half_t zp = (half_t)(float)(((zraw[j] >> (4 * (n & 7))) + (uint32_t)p.add_zero_bias) & 15u);
-      const half_t zf = __builtin_bit_cast(half_t, (uint16_t)((n & 1) ? (zraw[j] >> 16) : (zraw[j] & 0xffffu)));
-      zz[j] = (zk == ZK_PACKED) ? zp : ((zk == ZK_F16) ? zf : (half_t)8.f);
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        const half_t zp = (half_t)(float)(((zraw[j][0] >> (4 * ((n + c) & 7))) + (uint32_t)p.add_zero_bias) & 15u);
+        const uint32_t zd = (CPL == 4) ? zraw[j][c >> 1] : zraw[j][0];
+        const bool hi = (CPL == 4) ? (c & 1) : (n & 1);
+        const half_t zf = __builtin_bit_cast(half_t, (uint16_t)(hi ? (zd >> 16) : (zd & 0xffffu)));
+        zz[j][c] = (zk == ZK_PACKED) ? zp : ((zk == ZK_F16) ? zf : (half_t)8.f);
+      }
     }
 
     // ---- 4. activations -> LDS (first round only): needs the OLDEST loads only, the weights stay in flight ----------
@@ -134,63 +153,79 @@ __global__ __launch_bounds__(NW * 64) void strip_kernel(const StripParams p) {
 
     // ---- 5. straight-line dequant + MFMA --------------------------------------------------------------------------------
     const half_t *xr = xlane + 32 * (r * MAXS);
-    ColConst cc = make_col_const(sc[0], zz[0]);
+    ColConst cc[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) cc[c] = make_col_const(sc[0][c], zz[0][c]);
 #pragma unroll
     for (int s = 0; s < MAXS; ++s) {
-      if (s % SPG == 0 && s > 0) cc = make_col_const(sc[s / SPG], zz[s / SPG]);
+      if (s % SPG == 0 && s > 0) {
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) cc[c] = make_col_const(sc[s / SPG][c], zz[s / SPG][c]);
+      }
       const half8_t av = *(const half8_t *)(xr + 32 * s);
-      const half8_t bf = deq_word_k04(w[s], cc, nibmask);
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bf, acc, 0, 0, 0);
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        const half8_t bf = deq_word_k04(w[s][c], cc[c], nibmask);
+        acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bf, acc[c], 0, 0, 0);
+      }
     }
   }
 
-  // ---- 6. reduce the 16 waves' partials through LDS: red[wave][row][col] ------------------------------------------
+  // ---- 6. reduce the NW waves' partials through LDS: red[wave][row][col] -------------------------------------------
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int row = 4 * g + r;
-    if (row < M) red[(wave * 16 + row) * 16 + i] = acc[r];
+    if (row < M) {
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) red[(wave * M + row) * TN + i * CPL + c] = acc[c][r];
+    }
   }
   __syncthreads();
-  const int e = threadIdx.x;
-  if (e < M * 16) {
-    const int row = e >> 4, col = e & 15;
+  for (int e = threadIdx.x; e < M * TN; e += NW * 64) {
+    const int row = e / TN, col = e - row * TN;
     float v = 0.f;
 #pragma unroll
-    for (int wv = 0; wv < NW; ++wv) v += red[(wv * 16 + row) * 16 + col];
-    const int nn = b * 16 + col;
-    if (pr.bias) v += (float)pr.bias[nn];
-    if (p.act_bf16)
-      ((uint16_t *)pr.y)[(size_t)row * N + nn] = f32_to_bf16(v);
-    else
-      ((half_t *)pr.y)[(size_t)row * N + nn] = (half_t)v;
+    for (int wv = 0; wv < NW; ++wv) v += red[(wv * M + row) * TN + col];
+    const int nn = b * TN + col;
+    if (nn < N) {
+      if (pr.bias) v += (float)pr.bias[nn];
+      if (p.act_bf16)
+        ((uint16_t *)pr.y)[(size_t)row * N + nn] = f32_to_bf16(v);
+      else
+        ((half_t *)pr.y)[(size_t)row * N + nn] = (half_t)v;
+    }
   }
+  (void)col_ok;
 }
 
-template <int NW, int MAXS, int SPG, int XL>
+template <int NW, int CPL, int MAXS, int SPG, int XL>
 static int launch_strip_t(const StripParams &p, int grid, size_t lds, hipStream_t stream) {
   static bool attr_done = false;
   if (!attr_done) {
-    QLLM_HIP_CHECK(hipFuncSetAttribute((const void *)strip_kernel<NW, MAXS, SPG, XL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    QLLM_HIP_CHECK(hipFuncSetAttribute((const void *)strip_kernel<NW, CPL, MAXS, SPG, XL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
-  hipLaunchKernelGGL((strip_kernel<NW, MAXS, SPG, XL>), dim3(grid), dim3(NW * 64), lds, stream, p);
+  hipLaunchKernelGGL((strip_kernel<NW, CPL, MAXS, SPG, XL>), dim3(grid), dim3(NW * 64), lds, stream, p);
   QLLM_HIP_CHECK(hipGetLastError());
   return QLLM_OK;
 }
 
-// (waves per block, weight dwords per lane per round): 16 waves x 8 or 24, or 8 waves x 16
-static int strip_maxs(int nw, int spw) { return nw == 8 ? 16 : (spw <= 8 ? 8 : 24); }
-static int strip_spw_pad(int nw, int spw) { const int m = strip_maxs(nw, spw); return (spw + m - 1) / m * m; }
-static int strip_xl(int nw, int M, int spw) { return (M * strip_spw_pad(nw, spw) * 4 + 63) / 64; }
+// (waves per block, weight loads per lane per round): 16 waves x 8 or 24, or 8 waves x 16
+// (64-column strips always use rounds of 8: 4 dwords per load keep the register budget of a 1024-thread block)
+static int strip_maxs(int nw, int spw, int cpl) { return cpl == 4 ? 8 : (nw == 8 ? 16 : (spw <= 8 ? 8 : 24)); }
+static int strip_spw_pad(int nw, int spw, int cpl) { const int m = strip_maxs(nw, spw, cpl); return (spw + m - 1) / m * m; }
+static int strip_xl(int nw, int M, int spw, int cpl) { return (M * strip_spw_pad(nw, spw, cpl) * 4 + 63) / 64; }
 
 template <int SPG>
 static int launch_strip_s(const StripParams &p, int grid, size_t lds, hipStream_t stream) {
-  const bool small_x = strip_xl(p.nw, p.M, p.spw) <= 2;
+  const bool small_x = strip_xl(p.nw, p.M, p.spw, p.cpl) <= 2;
+  if (p.cpl == 4)  // 64-column strips: 16 waves, rounds of 8 k-steps
+    return small_x ? launch_strip_t<16, 4, 8, SPG, 2>(p, grid, lds, stream) : launch_strip_t<16, 4, 8, SPG, 8>(p, grid, lds, stream);
   if (p.nw == 8)
-    return small_x ? launch_strip_t<8, 16, SPG, 2>(p, grid, lds, stream) : launch_strip_t<8, 16, SPG, 8>(p, grid, lds, stream);
-  if (strip_maxs(16, p.spw) == 8)
-    return small_x ? launch_strip_t<16, 8, SPG, 2>(p, grid, lds, stream) : launch_strip_t<16, 8, SPG, 8>(p, grid, lds, stream);
-  return small_x ? launch_strip_t<16, 24, SPG, 2>(p, grid, lds, stream) : launch_strip_t<16, 24, SPG, 8>(p, grid, lds, stream);
+    return small_x ? launch_strip_t<8, 1, 16, SPG, 2>(p, grid, lds, stream) : launch_strip_t<8, 1, 16, SPG, 8>(p, grid, lds, stream);
+  if (strip_maxs(16, p.spw, 1) == 8)
+    return small_x ? launch_strip_t<16, 1, 8, SPG, 2>(p, grid, lds, stream) : launch_strip_t<16, 1, 8, SPG, 8>(p, grid, lds, stream);
+  return small_x ? launch_strip_t<16, 1, 24, SPG, 2>(p, grid, lds, stream) : launch_strip_t<16, 1, 24, SPG, 8>(p, grid, lds, stream);
 }
 
 // group sizes the strip kernel serves: 64 and 128 (k-steps per group 2, 4); others use the split-K kernel
@@ -207,15 +242,18 @@ int strip_spw(int K, int group_size, int nw) {
   return (spw + spg - 1) / spg * spg;
 }
 
-size_t strip_lds_bytes(int M, int spw, int nw) {
-  return (size_t)nw * 16 * 16 * sizeof(float) + (size_t)nw * M * (strip_spw_pad(nw, spw) * 32 + 8) * sizeof(half_t);
+size_t strip_lds_bytes(int M, int spw, int nw, int cpl) {
+  return (size_t)nw * M * 16 * cpl * sizeof(float) + (size_t)nw * M * (strip_spw_pad(nw, spw, cpl) * 32 + 8) * sizeof(half_t);
 }
 
+// columns per lane: 64-column strips (256-byte row segments) once they alone give enough blocks, else 16-column strips
+int strip_cpl(int cols_total, bool all_mult64) { return (all_mult64 && cols_total / 64 >= 160) ? 4 : 1; }
+
 // activation staging budget: at most 8 sixteen-byte chunks per lane
-bool strip_x_ok(int M, int spw, int nw) { return strip_xl(nw, M, spw) <= 8; }
+bool strip_x_ok(int M, int spw, int nw, int cpl) { return strip_xl(nw, M, spw, cpl) <= 8; }
 
 int launch_strip(const StripParams &p, int grid, hipStream_t stream) {
-  const size_t lds = strip_lds_bytes(p.M, p.spw, p.nw);
+  const size_t lds = strip_lds_bytes(p.M, p.spw, p.nw, p.cpl);
   if (p.group_size == 64) return launch_strip_s<2>(p, grid, lds, stream);
   return launch_strip_s<4>(p, grid, lds, stream);
 }

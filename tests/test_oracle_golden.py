@@ -74,6 +74,10 @@ def test_forward_matches_reference(golden):
     y1 = O.forward(g["layout"], g["x"][:1], g["qweight"], g["scales"], g["qzeros"], g["g_idx"], g["bias"],
                    g["bits"], g["groupsize"], g["K"], g["compat"]).numpy()
     assert O.rel_err(y1, g["y1"]) <= 1e-3
+    # the fp32-carried form used for large M agrees with the half GEMM to rounding
+    gi0 = g["g_idx"] if (g["layout"] == "GPTQ" and O.is_act_order(g["g_idx"], g["groupsize"])) else None
+    w0 = O.dequant(g["layout"], g["qweight"], g["scales"], g["qzeros"], gi0, g["bits"], g["groupsize"], g["K"], g["compat"])
+    assert O.rel_err(O.matmul_f16_via_f32(g["x"], w0, g["bias"]).numpy(), g["y"]) <= 1e-3
     # and the fp16 path is itself close to exact arithmetic on the same operands
     gi = g["g_idx"] if (g["layout"] == "GPTQ" and O.is_act_order(g["g_idx"], g["groupsize"])) else None
     w = O.dequant(g["layout"], g["qweight"], g["scales"], g["qzeros"], gi, g["bits"], g["groupsize"], g["K"],
