@@ -290,15 +290,16 @@ def test_reference_named_entry_points():
 def test_c_abi_error_codes_on_device():
     from qllm_amd import _lib, ops
     lib = _lib.load()
-    d = synth("GPTQ", 4, 128, 4096, 4096, seed=60)
+    # a narrow layer (48 column strips) is served by the split-K kernel, which needs the workspace
+    d = synth("GPTQ", 4, 128, 3072, 768, seed=60)
     layer = to_layer(d, DEV)
     w = layer._descriptor(None, 0)
-    x = torch.from_numpy(randx(1, 4096)).to(DEV)
-    y = torch.empty((1, 4096), dtype=torch.float16, device=DEV)
+    x = torch.from_numpy(randx(1, 3072)).to(DEV)
+    y = torch.empty((1, 768), dtype=torch.float16, device=DEV)
     # split-K needs a workspace
     rc = lib.qllm_linear_forward(ctypes.byref(w), x.data_ptr(), y.data_ptr(), 1, 0, None, 0, None)
     assert rc == _lib.QLLM_ERR_WORKSPACE
-    small = torch.zeros(32768, dtype=torch.uint8, device=DEV)
+    small = torch.zeros(16384 + 256, dtype=torch.uint8, device=DEV)
     rc = lib.qllm_linear_forward(ctypes.byref(w), x.data_ptr(), y.data_ptr(), 1, 0, small.data_ptr(), small.numel(), None)
     assert rc == _lib.QLLM_ERR_WORKSPACE and "workspace too small" in _lib.last_error()
     with pytest.raises(RuntimeError):
