@@ -221,6 +221,13 @@ def main():
     avg_launch_us = ev_ms * 1e3 / (args.steps * launches)
     achieved = (bpt / launches) / (avg_launch_us * 1e-6) / 1e9
 
+    traffic = None
+    try:  # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command (profiles/)
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc.json")))
+        traffic = pmc["bytes_per_launch_avg_over_step"] if grouped else None
+    except Exception:  # noqa: BLE001
+        pass
+
     result = {
         "metric": "decode_tokens_per_s_llama2_7b_w4a16_g128_linear_stack", "value": round(tokens_per_s, 2),
         "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -232,7 +239,8 @@ def main():
                    "device": info["arch"], "compute_units": info["compute_units"]},
         "roofline": {"bound": "hbm", "kernel": "qllm::strip_kernel (decode matvec; serves every launch of the step)",
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                     "traffic_source": "profiles/r01_pmc.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)",
                      "bytes_per_launch": bpt // launches, "avg_launch_us": round(avg_launch_us, 3)},
     }
 
