@@ -27,16 +27,30 @@ typedef __attribute__((address_space(1))) const void gbl_cvoid_t;
 
 // NW: waves per block; CPL: columns per lane (1 -> 16-column strip, 64-byte row segments; 4 -> 64-column strip,
 // 256-byte row segments, 4 MFMAs per k-step); MAXS: k-steps (weight loads) per lane per round; SPG: k-steps per
-// quantisation group (group_size / 32); XL: 16-byte activation chunks staged per lane.  Everything below is
-// straight-line: loads are never predicated (addresses are clamped instead and the surplus is cancelled by zero
-// activations), so hipcc keeps all of a wave's loads in flight and waits for them one at a time with counted vmcnt.
+// quantisation group (group_size / 32); XL: 16-byte activation chunks staged per lane.
+//
+// Arithmetic (the kernel is VALU-issue-bound, measured SQ_ACTIVE_INST_VALU ~ 0.9 of the SIMD issue capacity with the
+// per-weight fp16 dequant, so the per-weight work is cut to the bone):
+//     y[m,n] = sum_G s[G,n] * ( sum_{k in G} x[m,k] q[k,n]  -  z[G,n] * sum_{k in G} x[m,k] )
+//   * the B fragment is the raw "magic" fp16 pattern: 0x6400 | nibble = 1024+q for nibbles at bits 0-3/16-19 and
+//     0x6400 | (nibble<<4) = 1024+16q for nibbles at bits 4-7/20-23 -- 1 shift + 4 v_and_or_b32 per 8 weights, no
+//     per-weight fp16 math at all; the x16 on the odd k-slots is undone by staging x/16 in those A-fragment slots;
+//   * per group the MFMA accumulator therefore holds 1024*Sx' + sum x q  (Sx' = sum of the staged A values); the
+//     correction 1024*Sx' + z*Sx and the scale are applied once per group and column in fp32 (12 VALU per 32-128
+//     weights), with Sx, Sx' per (row, group) computed once per wave when x is staged (v_dot2_f32_f16 + 3-4 shuffles).
+//   This evaluates x.W for the UNROUNDED W = s(q-z) in fp32: it differs from the reference's fp16-rounded W path by
+//   the rounding noise of W (measured <= 3e-4 relative, tests bound it at 2e-3 against float64 of the reference's W).
+// Everything is straight-line: loads are never predicated (addresses are clamped instead and the surplus is
+// cancelled by zero activations), so hipcc keeps all of a wave's loads in flight and waits with counted vmcnt.
 template <int NW, int CPL, int MAXS, int SPG, int XL>
 __global__ __launch_bounds__(NW * 64) void strip_kernel(const StripParams p) {
   constexpr int NG = MAXS / SPG;   // groups per round (MAXS is a multiple of SPG; rounds start on a group boundary)
   constexpr int TN = 16 * CPL;     // columns per block
+  constexpr int GL = 4 * SPG;      // lanes (16-byte chunks) per group in the staging pass: 8 or 16
   typedef uint32_t wvec_t __attribute__((ext_vector_type(CPL)));
-  // dynamic LDS: reduction buffer red[wave][M rows][TN cols] fp32, then each wave's private copy of its activation
-  // chunk: M rows x (32*spw_pad) halves, row stride padded by 16 B.
+  typedef float float2_t __attribute__((ext_vector_type(2)));
+  // dynamic LDS: red[wave][M rows][TN cols] fp32 | per wave: activation chunk, M rows x (32*spw_pad) halves, row
+  // stride + 16 B | per wave: (Sx, Sx') float2 per (group, row), 16 rows per group
   extern __shared__ __attribute__((aligned(16))) float red[];
 
   const int lane = threadIdx.x & 63;
@@ -56,26 +70,27 @@ __global__ __launch_bounds__(NW * 64) void strip_kernel(const StripParams p) {
     b = (((r >> 1) << 3) + x) * 2 + (r & 1);
   }
   const int N = pr.N;
-  const int n = min(b * TN + i * CPL, N - CPL);  // this lane's first column (clamped for a ragged last strip)
-  const bool col_ok = (b * TN + i * CPL) < N;
+  const int n = b * TN + i * CPL;  // this lane's first column (N is a multiple of TN)
   const int M = p.M;
 
   const int t0 = wave * p.spw;                    // spw is a multiple of SPG: every wave starts on a group boundary
   const int kend = min(32 * (t0 + p.spw), p.K);   // activations at k >= kend are staged as zero
   const int rounds = (p.spw + MAXS - 1) / MAXS;
   const int spw_pad = rounds * MAXS;
+  const int ngw = spw_pad / SPG;                  // groups in this wave's (padded) chunk
 
-  // ---- 1. activations: this wave's [M][32*spw_pad] chunk -> registers now, wave-private LDS after the weight
-  //         loads have been issued.  k-slots stored in the (k0,k4,k1,k5,k2,k6,k3,k7) fragment order.
+  // ---- 1. activations: this wave's [M][32*spw_pad] chunk -> registers now; LDS after the weight loads are issued ---
   const int xrow = spw_pad * 32 + 8;  // halves per staged row (16 B pad spreads rows over banks)
   half_t *xs = (half_t *)(red + NW * M * TN) + (size_t)wave * M * xrow;
+  float2_t *sxs = (float2_t *)((half_t *)(red + NW * M * TN) + (size_t)NW * M * xrow) + (size_t)wave * ngw * 16;
   const int cpr = spw_pad * 4;  // 16-byte chunks per row
   const int xlast = M * cpr - 1;
   half8_t xa[XL];
-  int xdst[XL];
+  int xdst[XL], sdst[XL];
 #pragma unroll
   for (int u = 0; u < XL; ++u) {
-    const int c = min(lane + 64 * u, xlast);  // surplus lanes duplicate the last chunk (same bytes, same slot)
+    const int cu = lane + 64 * u;
+    const int c = min(cu, xlast);  // surplus lanes re-read the last chunk and are masked out below
     const int row = (M == 1) ? 0 : c / cpr;
     const int kc = c - row * cpr;
     const int k = 32 * t0 + 8 * kc;
@@ -87,16 +102,18 @@ __global__ __launch_bounds__(NW * 64) void strip_kernel(const StripParams p) {
       v = *(const half8_t *)((const half_t *)p.x + off);
     const half8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
     xa[u] = (k < kend) ? v : zero;
-    xdst[u] = row * xrow + 8 * kc;
+    xdst[u] = (cu <= xlast) ? row * xrow + 8 * kc : -1;
+    sdst[u] = (kc / GL) * 16 + row;
   }
   // lanes whose MFMA row is >= M read a valid row: their products only reach output rows that are never stored
   const half_t *xlane = xs + min(i, M - 1) * xrow + 8 * g;
 
-  float4_t acc[CPL];
+  float4_t yacc[CPL];
 #pragma unroll
-  for (int c = 0; c < CPL; ++c) acc[c] = float4_t{0.f, 0.f, 0.f, 0.f};
-  const uint32_t nibmask = nib_mask_vgpr();
-  const uint32_t *qw = pr.qweight + n;
+  for (int c = 0; c < CPL; ++c) yacc[c] = float4_t{0.f, 0.f, 0.f, 0.f};
+  const uint32_t mask_lo = nib_mask_vgpr();  // 0x000f000f
+  const uint32_t mask_hi = mask_lo << 4;     // 0x00f000f0
+  const uint32_t lane_off = (uint32_t)(g * N + n);  // word offset of this lane inside a 4-row group
   const int Gmax = (p.K - 1) / p.group_size;
   const int tmax = p.T - 1;
   // zero points, branch-free addressing: packed -> word (G, n/8) (CPL | 8: one word holds the lane's columns);
@@ -109,8 +126,7 @@ __global__ __launch_bounds__(NW * 64) void strip_kernel(const StripParams p) {
 
   for (int r = 0; r < rounds; ++r) {
     const int base = t0 + r * MAXS;
-    // ---- 2. scale / zero of every group this round touches: RAW loads only (tiny; issued first so they are back
-    //         first); nothing is consumed before the weight loads below have been issued ------------------------------
+    // ---- 2. scale / zero of every group this round touches: RAW loads only (tiny; issued first) ----------------------
     const int G0 = base / SPG;
     half_t sc[NG][CPL];
     uint32_t zraw[NG][2];
@@ -120,53 +136,90 @@ __global__ __launch_bounds__(NW * 64) void strip_kernel(const StripParams p) {
       if constexpr (CPL == 4) {
         const half4_t sv = *(const half4_t *)(pr.scales + (size_t)G * N + n);
         sc[j][0] = sv.x; sc[j][1] = sv.y; sc[j][2] = sv.z; sc[j][3] = sv.w;
+      } else if constexpr (CPL == 2) {
+        const half2_t sv = *(const half2_t *)(pr.scales + (size_t)G * N + n);
+        sc[j][0] = sv.x; sc[j][1] = sv.y;
       } else {
         sc[j][0] = pr.scales[(size_t)G * N + n];
       }
       zraw[j][0] = zbase[(size_t)G * zmul + zoff];
       zraw[j][1] = (CPL == 4) ? zbase[(size_t)G * zmul + zoff + zoff2] : 0u;
     }
-    // ---- 3. every weight load of this round: exactly MAXS loads, rows clamped into the matrix -----------------------
+    // ---- 3. every weight load of this round: exactly MAXS loads, rows clamped into the matrix;
+    //         address = wave-uniform row base (SALU) + one per-lane 32-bit offset -------------------------------------
     wvec_t w[MAXS];
 #pragma unroll
-    for (int s = 0; s < MAXS; ++s)
-      w[s] = __builtin_nontemporal_load((const wvec_t *)(qw + (size_t)(4 * min(base + s, tmax) + g) * N));
-
-    half_t zz[NG][CPL];
-#pragma unroll
-    for (int j = 0; j < NG; ++j) {
-#pragma unroll
-      for (int c = 0; c < CPL; ++c) {
-        const half_t zp = (half_t)(float)(((zraw[j][0] >> (4 * ((n + c) & 7))) + (uint32_t)p.add_zero_bias) & 15u);
-        const uint32_t zd = (CPL == 4) ? zraw[j][c >> 1] : zraw[j][0];
-        const bool hi = (CPL == 4) ? (c & 1) : (n & 1);
-        const half_t zf = __builtin_bit_cast(half_t, (uint16_t)(hi ? (zd >> 16) : (zd & 0xffffu)));
-        zz[j][c] = (zk == ZK_PACKED) ? zp : ((zk == ZK_F16) ? zf : (half_t)8.f);
-      }
+    for (int s = 0; s < MAXS; ++s) {
+      const uint32_t *rowp = pr.qweight + (size_t)(4 * min(base + s, tmax)) * N;
+      w[s] = __builtin_nontemporal_load((const wvec_t *)(rowp + lane_off));
     }
 
-    // ---- 4. activations -> LDS (first round only): needs the OLDEST loads only, the weights stay in flight ----------
+    // ---- 4. first round: activations -> LDS (needs only the OLDEST loads; the weights stay in flight) ---------------
     if (r == 0) {
 #pragma unroll
-      for (int u = 0; u < XL; ++u) *(half8_t *)(xs + xdst[u]) = a_perm_04152637(xa[u]);
+      for (int u = 0; u < XL; ++u) {
+        // fragment slot order (k0,k4 | k1,k5 | k2,k6 | k3,k7); the odd pairs meet B values scaled by 16 -> stage x/16
+        const half8_t pv = a_perm_04152637(xa[u]);
+        const half2_t p0 = {pv[0], pv[1]}, p1 = {pv[2], pv[3]}, p2 = {pv[4], pv[5]}, p3 = {pv[6], pv[7]};
+        const half2_t sixteenth = {(half_t)0.0625f, (half_t)0.0625f};
+        const half2_t q1 = p1 * sixteenth, q3 = p3 * sixteenth;
+        const half2_t one = {(half_t)1.f, (half_t)1.f};
+        float sx = __builtin_amdgcn_fdot2(p0, one, 0.f, false);
+        sx = __builtin_amdgcn_fdot2(p2, one, sx, false);
+        float sxp = sx;  // the un-scaled slots count the same in both sums
+        sx = __builtin_amdgcn_fdot2(p1, one, sx, false);
+        sx = __builtin_amdgcn_fdot2(p3, one, sx, false);
+        sxp = __builtin_amdgcn_fdot2(q1, one, sxp, false);
+        sxp = __builtin_amdgcn_fdot2(q3, one, sxp, false);
+#pragma unroll
+        for (int d = 1; d < GL; d <<= 1) {
+          sx += __shfl_xor(sx, d);
+          sxp += __shfl_xor(sxp, d);
+        }
+        if (xdst[u] >= 0) {
+          *(half8_t *)(xs + xdst[u]) = half8_t{p0.x, p0.y, q1.x, q1.y, p2.x, p2.y, q3.x, q3.y};
+          if ((lane & (GL - 1)) == 0) sxs[sdst[u]] = float2_t{sx, sxp};
+        }
+      }
     }
 
-    // ---- 5. straight-line dequant + MFMA --------------------------------------------------------------------------------
+    // ---- 5. straight-line: raw-magic B fragments -> MFMA; one fp32 correction per group ----------------------------------
     const half_t *xr = xlane + 32 * (r * MAXS);
-    ColConst cc[CPL];
-#pragma unroll
-    for (int c = 0; c < CPL; ++c) cc[c] = make_col_const(sc[0][c], zz[0][c]);
+    const float2_t *sxr = sxs + (size_t)(r * NG) * 16 + 4 * g;  // (Sx, Sx') of rows 4g..4g+3
+    float4_t gacc[CPL];
 #pragma unroll
     for (int s = 0; s < MAXS; ++s) {
-      if (s % SPG == 0 && s > 0) {
-#pragma unroll
-        for (int c = 0; c < CPL; ++c) cc[c] = make_col_const(sc[s / SPG][c], zz[s / SPG][c]);
-      }
       const half8_t av = *(const half8_t *)(xr + 32 * s);
 #pragma unroll
       for (int c = 0; c < CPL; ++c) {
-        const half8_t bf = deq_word_k04(w[s][c], cc[c], nibmask);
-        acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bf, acc[c], 0, 0, 0);
+        const uint32_t wv = w[s][c], w8 = wv >> 8;
+        const half2_t b0 = as_h2((wv & mask_lo) | kMagic), b1 = as_h2((wv & mask_hi) | kMagic);
+        const half2_t b2 = as_h2((w8 & mask_lo) | kMagic), b3 = as_h2((w8 & mask_hi) | kMagic);
+        const half8_t bf = {b0.x, b0.y, b1.x, b1.y, b2.x, b2.y, b3.x, b3.y};
+        const float4_t cin = (s % SPG == 0) ? float4_t{0.f, 0.f, 0.f, 0.f} : gacc[c];
+        gacc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bf, cin, 0, 0, 0);
+      }
+      if (s % SPG == SPG - 1) {
+        const int j = s / SPG;
+        const float4_t s01 = *(const float4_t *)(sxr + j * 16);      // (Sx,Sx') rows 4g, 4g+1
+        const float4_t s23 = *(const float4_t *)(sxr + j * 16 + 2);  // rows 4g+2, 4g+3
+        const float sxv[4] = {s01[0], s01[2], s23[0], s23[2]};
+        const float big[4] = {1024.f * s01[1], 1024.f * s01[3], 1024.f * s23[1], 1024.f * s23[3]};
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+          // this group's scale / zero of column n+c, converted to fp32 here (keeps the raw 16/32-bit words live instead)
+          const float zp = (float)(((zraw[j][0] >> (4 * ((n + c) & 7))) + (uint32_t)p.add_zero_bias) & 15u);
+          const uint32_t zd = (CPL >= 2) ? zraw[j][c >> 1] : zraw[j][0];
+          const bool hi = (CPL >= 2) ? (c & 1) : (n & 1);
+          const float zh = (float)__builtin_bit_cast(half_t, (uint16_t)(hi ? (zd >> 16) : (zd & 0xffffu)));
+          const float zfc = (zk == ZK_PACKED) ? zp : ((zk == ZK_F16) ? zh : 8.f);
+          const float sfc = (float)sc[j][c];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float corr = __builtin_fmaf(zfc, sxv[q], big[q]);
+            yacc[c][q] = __builtin_fmaf(sfc, gacc[c][q] - corr, yacc[c][q]);
+          }
+        }
       }
     }
   }
@@ -177,7 +230,7 @@ __global__ __launch_bounds__(NW * 64) void strip_kernel(const StripParams p) {
     const int row = 4 * g + r;
     if (row < M) {
 #pragma unroll
-      for (int c = 0; c < CPL; ++c) red[(wave * M + row) * TN + i * CPL + c] = acc[c][r];
+      for (int c = 0; c < CPL; ++c) red[(wave * M + row) * TN + i * CPL + c] = yacc[c][r];
     }
   }
   __syncthreads();
@@ -187,15 +240,12 @@ __global__ __launch_bounds__(NW * 64) void strip_kernel(const StripParams p) {
 #pragma unroll
     for (int wv = 0; wv < NW; ++wv) v += red[(wv * M + row) * TN + col];
     const int nn = b * TN + col;
-    if (nn < N) {
-      if (pr.bias) v += (float)pr.bias[nn];
-      if (p.act_bf16)
-        ((uint16_t *)pr.y)[(size_t)row * N + nn] = f32_to_bf16(v);
-      else
-        ((half_t *)pr.y)[(size_t)row * N + nn] = (half_t)v;
-    }
+    if (pr.bias) v += (float)pr.bias[nn];
+    if (p.act_bf16)
+      ((uint16_t *)pr.y)[(size_t)row * N + nn] = f32_to_bf16(v);
+    else
+      ((half_t *)pr.y)[(size_t)row * N + nn] = (half_t)v;
   }
-  (void)col_ok;
 }
 
 template <int NW, int CPL, int MAXS, int SPG, int XL>
@@ -212,15 +262,19 @@ static int launch_strip_t(const StripParams &p, int grid, size_t lds, hipStream_
 
 // (waves per block, weight loads per lane per round): 16 waves x 8 or 24, or 8 waves x 16
 // (64-column strips always use rounds of 8: 4 dwords per load keep the register budget of a 1024-thread block)
-static int strip_maxs(int nw, int spw, int cpl) { return cpl == 4 ? 8 : (nw == 8 ? 16 : (spw <= 8 ? 8 : 24)); }
+static int strip_maxs(int nw, int spw, int cpl) { return cpl >= 2 ? 8 : (nw == 8 ? 16 : (spw <= 8 ? 8 : 24)); }
 static int strip_spw_pad(int nw, int spw, int cpl) { const int m = strip_maxs(nw, spw, cpl); return (spw + m - 1) / m * m; }
 static int strip_xl(int nw, int M, int spw, int cpl) { return (M * strip_spw_pad(nw, spw, cpl) * 4 + 63) / 64; }
 
 template <int SPG>
 static int launch_strip_s(const StripParams &p, int grid, size_t lds, hipStream_t stream) {
   const bool small_x = strip_xl(p.nw, p.M, p.spw, p.cpl) <= 2;
+  if (p.cpl == 4 && p.nw == 8)  // 64-column strips, 8-wave blocks (two co-resident per CU), rounds of 8 k-steps
+    return small_x ? launch_strip_t<8, 4, 8, SPG, 2>(p, grid, lds, stream) : launch_strip_t<8, 4, 8, SPG, 8>(p, grid, lds, stream);
   if (p.cpl == 4)  // 64-column strips: 16 waves, rounds of 8 k-steps
     return small_x ? launch_strip_t<16, 4, 8, SPG, 2>(p, grid, lds, stream) : launch_strip_t<16, 4, 8, SPG, 8>(p, grid, lds, stream);
+  if (p.cpl == 2)  // 32-column strips: 16 waves, rounds of 8 k-steps
+    return small_x ? launch_strip_t<16, 2, 8, SPG, 2>(p, grid, lds, stream) : launch_strip_t<16, 2, 8, SPG, 8>(p, grid, lds, stream);
   if (p.nw == 8)
     return small_x ? launch_strip_t<8, 1, 16, SPG, 2>(p, grid, lds, stream) : launch_strip_t<8, 1, 16, SPG, 8>(p, grid, lds, stream);
   if (strip_maxs(16, p.spw, 1) == 8)
@@ -243,11 +297,19 @@ int strip_spw(int K, int group_size, int nw) {
 }
 
 size_t strip_lds_bytes(int M, int spw, int nw, int cpl) {
-  return (size_t)nw * M * 16 * cpl * sizeof(float) + (size_t)nw * M * (strip_spw_pad(nw, spw, cpl) * 32 + 8) * sizeof(half_t);
+  const int pad = strip_spw_pad(nw, spw, cpl);
+  return (size_t)nw * M * 16 * cpl * sizeof(float) + (size_t)nw * M * (pad * 32 + 8) * sizeof(half_t) +
+         (size_t)nw * pad * 16 * 8;  // (Sx, Sx') table: at most one group per k-step
 }
 
-// columns per lane: 64-column strips (256-byte row segments) once they alone give enough blocks, else 16-column strips
-int strip_cpl(int cols_total, bool all_mult64) { return (all_mult64 && cols_total / 64 >= 160) ? 4 : 1; }
+// columns per lane, from measurements on Llama-2-7B shapes (tools/kbench.py --grouped, us per launch, cpl 1/2/4):
+//   q/k/v 12288 cols: 11.7 / 10.6 / 8.5    gate/up 22016 cols: 18.7 / 16.1 / 15.6
+//   o 4096 cols: 5.3 / 6.1 / 7.0            down 4096 cols (K=11008): 10.1 / 11.2 / 14.7
+// -> 64-column strips (256-byte row segments) as soon as they alone give >= 160 blocks, else 16-column strips.
+int strip_cpl(int cols_total, bool all_mult64, bool all_mult32) {
+  (void)all_mult32;
+  return (all_mult64 && cols_total / 64 >= 160) ? 4 : 1;
+}
 
 // activation staging budget: at most 8 sixteen-byte chunks per lane
 bool strip_x_ok(int M, int spw, int nw, int cpl) { return strip_xl(nw, M, spw, cpl) <= 8; }

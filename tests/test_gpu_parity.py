@@ -169,7 +169,8 @@ def test_properties_at_full_size():
     dz["qweight"] = O.pack_along_rows(np.repeat(zeros, 128, axis=0), 4)
     lz = to_layer(dz, DEV)
     yz = lz(torch.from_numpy(randx(2, 4096)).to(DEV))
-    assert torch.equal(yz, lz.bias.expand_as(yz))
+    # (the decode kernel cancels 1024*Sx' + z*Sx against the MFMA sum in fp32: exact to ~1e-5, not bit-exact)
+    assert (yz.float() - lz.bias.float().expand_as(yz)).abs().max() <= 1e-3
     # a column shard computes exactly the same columns (one rounding of an fp32 sum; order may differ by shard plan)
     dq = synth("GPTQ", 4, 128, 4096, 4096, seed=11)
     full = to_layer(dq, DEV)

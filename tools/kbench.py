@@ -91,5 +91,46 @@ def main():
             torch.cuda.empty_cache()
 
 
+def grouped():
+    """q/k/v (3 x 4096x4096) and gate/up (2 x 4096x11008) as single grouped launches, M=1."""
+    from qllm_amd import ops
+    dev = torch.device("cuda:0")
+    for name, shapes in (("qkv", [(4096, 4096)] * 3), ("gate_up", [(4096, 11008)] * 2), ("o", [(4096, 4096)]), ("down", [(11008, 4096)])):
+        nbytes = sum(alg_bytes(K, N, 128, 1, "GPTQ", False) for K, N in shapes)
+        ncopy = max(2, min(32, (640 << 20) // nbytes))
+        sets = [[rand_layer("GPTQ", K, N, 128, dev) for (K, N) in shapes] for _ in range(ncopy)]
+        x = torch.randn(1, shapes[0][0], device=dev, dtype=torch.float16)
+        descs = [[l.decode_descriptor() for l in s] for s in sets]
+        for d in descs[:3]:
+            ops.linear_forward_grouped(d, x)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for d in descs:
+                ops.linear_forward_grouped(d, x)
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g, stream=s):
+                for d in descs:
+                    ops.linear_forward_grouped(d, x)
+        torch.cuda.current_stream().wait_stream(s)
+        g.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / (10 * ncopy)
+        print(f"grouped {name:8s} {nbytes / 1e6:6.1f} MB  {us:7.2f} us/launch  {nbytes / us / 1e3:7.1f} GB/s", flush=True)
+        del sets, descs
+        torch.cuda.empty_cache()
+
+
 if __name__ == "__main__":
-    main()
+    if "--grouped" in sys.argv:
+        grouped()
+    else:
+        main()
