@@ -89,4 +89,8 @@ struct GemmParams {
 };
 int launch_gemm(const GemmParams &p, int layout, hipStream_t stream);
 
+// ---- gemm2.hip (256x256 tile; fp16 activations, trivial groups, N % 256 == 0) -------------------------------------
+bool gemm2_ok(const GemmParams &p, int layout);
+int launch_gemm2(const GemmParams &p, int layout, hipStream_t stream);
+
 }  // namespace qllm

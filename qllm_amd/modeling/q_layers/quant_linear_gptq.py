@@ -3,6 +3,7 @@ the fused MI355X kernel path (no W materialisation, no CPU branch)."""
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -60,10 +61,55 @@ class QuantLinearGPTQ(nn.Module, CompressWeight, HipForwardMixin):
         self.qzeros = new_q
         self._desc = None
 
+    # ---- act-order: row-sorted shadow ---------------------------------------------------------------------------------
+    _ao = None
+    _ao_key = None
+
+    def _act_order_shadow(self, add_zero_bias: int):
+        """With act-order every k has its own group (g_idx gather per nibble).  GPTQ assigns whole groups of
+        `groupsize` rows, so sorting the rows by group (perm = argsort(g_idx)) gives a plain contiguous-group layer:
+        the module keeps that row-permuted copy of its own 4-bit integers (built once on device with the library's
+        unpack/pack kernels; bit-exact, state dict untouched) and feeds it x[..., perm].  The fused kernels then run
+        at their no-act-order speed plus one gather of x.  Returns (descriptor, perm) or None if the groups are not
+        uniform / the shadow is disabled (QLLM_ACTORDER_SHADOW=0) -> the in-place gather kernel is used."""
+        if os.environ.get("QLLM_ACTORDER_SHADOW", "1") == "0" or self.bits != 4 or not self.qweight.is_cuda:
+            return None
+        from ... import ops
+        key = (self.qweight.data_ptr(), self.scales.data_ptr(), self.qzeros.data_ptr(), self.g_idx.data_ptr(),
+               self.bias.data_ptr() if self.bias is not None else 0, add_zero_bias)
+        if self._ao is None or key != self._ao_key:
+            dev = self.qweight.device
+            g = self.g_idx.to(dev).long()
+            groups = math.ceil(self.infeatures / self.groupsize)
+            counts = torch.bincount(g, minlength=groups)
+            if self.infeatures % self.groupsize != 0 or counts.numel() != groups or not bool((counts == self.groupsize).all()):
+                self._ao, self._ao_key = False, key
+            else:
+                perm = torch.argsort(g, stable=True)
+                q = ops.unpack_qweight(self.qweight.contiguous(), "GPTQ", 4, self.infeatures, self.outfeatures)
+                qw = ops.pack_qweight(q.index_select(0, perm).contiguous(), "GPTQ", 4)
+                del q
+                b = self._f16(self.bias).contiguous() if self.bias is not None else None
+                desc = ops.make_weight("GPTQ", qw, self._f16(self.scales).contiguous(), self.qzeros.contiguous(), None, b,
+                                       self.infeatures, self.outfeatures, self.groupsize, 4, add_zero_bias)
+                self._ao, self._ao_key = (desc, perm), key
+        return self._ao if self._ao else None
+
     def forward(self, x):
         if self.act_order is None:
             # lazy detect, as the reference: trivial g_idx => first `groupsize` entries are all zero (:137-138)
             self.act_order = bool(self.g_idx[: self.groupsize].sum() != 0)
-        g_idx = self.g_idx if self.act_order else None
         # COMPATIBLE_WITH_AUTOGPTQ is read per forward by the reference (:75); it becomes add_zero_bias here
-        return self._hip_linear(x, g_idx, autogptq_compat())
+        azb = autogptq_compat()
+        if self.act_order and x.is_cuda:
+            ao = self._act_order_shadow(azb)
+            if ao is not None:
+                from ... import ops
+                (desc, _keep), perm = ao
+                x2d = x.reshape(-1, x.shape[-1]).index_select(1, perm)
+                try:
+                    return ops.linear_forward(desc, x2d).reshape(x.shape[:-1] + (self.outfeatures,))
+                except ops.QllmUnsupported:
+                    pass
+        g_idx = self.g_idx if self.act_order else None
+        return self._hip_linear(x, g_idx, azb)

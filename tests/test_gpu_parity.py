@@ -221,6 +221,21 @@ def test_act_order_decode_sizes():
         assert O.rel_err(y, oracle_y(d, x, w)) <= TOL
 
 
+def test_act_order_nonuniform_groups_use_inplace_gather():
+    """g_idx that is not a permutation of whole groups (the row-sorted shadow does not apply): in-place LDS-gather kernel."""
+    d = synth("GPTQ", 4, 128, 1024, 512, "asym", False, True, seed=22)
+    rng = np.random.default_rng(3)
+    d["g_idx"] = rng.integers(0, 8, size=1024).astype(np.int32)
+    d["g_idx"][:4] = 7
+    layer = to_layer(d, DEV)
+    ref = Ref(d)
+    for m in (1, 16, 200):
+        x = randx(m, 1024, seed=m)
+        y = layer(torch.from_numpy(x).to(DEV)).cpu().numpy()
+        assert layer._ao is False  # shadow rejected
+        assert O.rel_err(y, ref.y16(x)) <= TOL
+
+
 def test_odd_bits_route_through_dequant_kernel():
     for layout, bits, g in (("HQQ", 3, 64), ("GPTQ", 3, 128), ("GPTQ", 8, 128), ("HQQ", 2, 64)):
         d = synth(layout, bits, g, 4096, 1024, seed=bits)
