@@ -321,3 +321,39 @@ def test_c_abi_error_codes_on_device():
     with pytest.raises(RuntimeError):
         ops.linear_forward(w, x.float())
     torch.cuda.synchronize()
+
+
+# ---- --load / --eval drop-in on a tiny HF model (SURVEY 8(f) row 1 + 4) ---------------------------------------------------
+@pytest.mark.parametrize("pack_mode", ["GPTQ", "GEMM"])
+def test_load_and_eval_tiny_llama(tmp_path, pack_mode):
+    """Save a quantized tiny Llama, load it with the loader, run it on the GPU through the fused kernels and compare
+    logits / greedy tokens with the same model evaluated on the CPU from the dequantised weights (float32)."""
+    import copy
+    from test_loader_repack_cpu import _quantize_in_place, _tiny_llama
+    from qllm_amd.modeling import base
+    from qllm_amd.utils import modelutils
+    from qllm_amd.modeling.q_layers import QuantLinearGPTQ, WQLinear_GEMM
+
+    model, names = _quantize_in_place(_tiny_llama(), pack_mode)
+    d = str(tmp_path / pack_mode)
+    base.save_quantized(model, d)
+    # CPU reference: every q_layer -> nn.Linear holding unpack()[0] (the reference's own CPU truth), float32 math
+    ref = copy.deepcopy(model)
+    for n, layer in modelutils.find_layers(ref, [QuantLinearGPTQ, WQLinear_GEMM]).items():
+        lin = torch.nn.Linear(layer.infeatures, layer.outfeatures, bias=False)
+        lin.weight.data = layer.unpack()[0].float()
+        modelutils.set_op_by_name(ref, n, lin)
+    ref = ref.float().eval()
+    ids = torch.randint(0, 128, (2, 24), generator=torch.Generator().manual_seed(0))
+    with torch.no_grad():
+        logits_ref = ref(ids).logits
+
+    loaded = base.load_quantized(d, device=DEV)
+    assert loaded.load_report["quantized_layers"] == 14
+    with torch.no_grad():
+        logits = loaded(ids.to(DEV)).logits.float().cpu()          # prefill-sized (M = 48 rows)
+        step = loaded(ids[:, :1].to(DEV)).logits.float().cpu()     # decode-sized (M = 2 rows)
+    assert O.rel_err(logits.numpy(), logits_ref.numpy()) <= 2e-2    # whole-model fp16 vs fp32, 2 layers deep
+    assert O.rel_err(step.numpy(), logits_ref[:, :1].numpy()) <= 2e-2
+    agree = (logits.argmax(-1) == logits_ref.argmax(-1)).float().mean().item()
+    assert agree >= 0.9
