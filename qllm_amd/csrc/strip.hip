@@ -108,6 +108,35 @@ __global__ __launch_bounds__(NW * 64) void strip_kernel(const StripParams p) {
   // lanes whose MFMA row is >= M read a valid row: their products only reach output rows that are never stored
   const half_t *xlane = xs + min(i, M - 1) * xrow + 8 * g;
 
+  auto stage_x = [&]() {
+#pragma unroll
+    for (int u = 0; u < XL; ++u) {
+      // fragment slot order (k0,k4 | k1,k5 | k2,k6 | k3,k7); the odd pairs meet B values scaled by 16 -> stage x/16
+      const half8_t pv = a_perm_04152637(xa[u]);
+      const half2_t p0 = {pv[0], pv[1]}, p1 = {pv[2], pv[3]}, p2 = {pv[4], pv[5]}, p3 = {pv[6], pv[7]};
+      const half2_t sixteenth = {(half_t)0.0625f, (half_t)0.0625f};
+      const half2_t q1 = p1 * sixteenth, q3 = p3 * sixteenth;
+      const half2_t one = {(half_t)1.f, (half_t)1.f};
+      float sx = __builtin_amdgcn_fdot2(p0, one, 0.f, false);
+      sx = __builtin_amdgcn_fdot2(p2, one, sx, false);
+      float sxp = sx;  // the un-scaled slots count the same in both sums
+      sx = __builtin_amdgcn_fdot2(p1, one, sx, false);
+      sx = __builtin_amdgcn_fdot2(p3, one, sx, false);
+      sxp = __builtin_amdgcn_fdot2(q1, one, sxp, false);
+      sxp = __builtin_amdgcn_fdot2(q3, one, sxp, false);
+#pragma unroll
+    for (int d = 1; d < GL; d <<= 1) {
+        sx += __shfl_xor(sx, d);
+        sxp += __shfl_xor(sxp, d);
+      }
+      if (xdst[u] >= 0) {
+        *(half8_t *)(xs + xdst[u]) = half8_t{p0.x, p0.y, q1.x, q1.y, p2.x, p2.y, q3.x, q3.y};
+        if ((lane & (GL - 1)) == 0) sxs[sdst[u]] = float2_t{sx, sxp};
+      }
+    }
+  };
+  if (XL > 2) stage_x();
+
   float4_t yacc[CPL];
 #pragma unroll
   for (int c = 0; c < CPL; ++c) yacc[c] = float4_t{0.f, 0.f, 0.f, 0.f};
@@ -154,34 +183,9 @@ __global__ __launch_bounds__(NW * 64) void strip_kernel(const StripParams p) {
       w[s] = __builtin_nontemporal_load((const wvec_t *)(rowp + lane_off));
     }
 
-    // ---- 4. first round: activations -> LDS (needs only the OLDEST loads; the weights stay in flight) ---------------
-    if (r == 0) {
-#pragma unroll
-      for (int u = 0; u < XL; ++u) {
-        // fragment slot order (k0,k4 | k1,k5 | k2,k6 | k3,k7); the odd pairs meet B values scaled by 16 -> stage x/16
-        const half8_t pv = a_perm_04152637(xa[u]);
-        const half2_t p0 = {pv[0], pv[1]}, p1 = {pv[2], pv[3]}, p2 = {pv[4], pv[5]}, p3 = {pv[6], pv[7]};
-        const half2_t sixteenth = {(half_t)0.0625f, (half_t)0.0625f};
-        const half2_t q1 = p1 * sixteenth, q3 = p3 * sixteenth;
-        const half2_t one = {(half_t)1.f, (half_t)1.f};
-        float sx = __builtin_amdgcn_fdot2(p0, one, 0.f, false);
-        sx = __builtin_amdgcn_fdot2(p2, one, sx, false);
-        float sxp = sx;  // the un-scaled slots count the same in both sums
-        sx = __builtin_amdgcn_fdot2(p1, one, sx, false);
-        sx = __builtin_amdgcn_fdot2(p3, one, sx, false);
-        sxp = __builtin_amdgcn_fdot2(q1, one, sxp, false);
-        sxp = __builtin_amdgcn_fdot2(q3, one, sxp, false);
-#pragma unroll
-        for (int d = 1; d < GL; d <<= 1) {
-          sx += __shfl_xor(sx, d);
-          sxp += __shfl_xor(sxp, d);
-        }
-        if (xdst[u] >= 0) {
-          *(half8_t *)(xs + xdst[u]) = half8_t{p0.x, p0.y, q1.x, q1.y, p2.x, p2.y, q3.x, q3.y};
-          if ((lane & (GL - 1)) == 0) sxs[sdst[u]] = float2_t{sx, sxp};
-        }
-      }
-    }
+    // ---- 4. first round: activations -> LDS (needs only the OLDEST loads; the weights stay in flight).  For many rows
+    //         (XL > 2) the chunk was staged before the weight loads instead, to keep its registers out of this region.
+    if (XL <= 2 && r == 0) stage_x();
 
     // ---- 5. straight-line: raw-magic B fragments -> MFMA; one fp32 correction per group ----------------------------------
     const half_t *xr = xlane + 32 * (r * MAXS);
