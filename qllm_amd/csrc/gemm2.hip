@@ -4,8 +4,11 @@
 // the MI355X guide measures as the first big step for MFMA GEMMs (cdna_hip_programming.md section 5):
 //   * 8 waves (2 M x 4 N), each 128x64 = 8x4 tiles of v_mfma_f32_16x16x32_f16: 12 fragment reads per 32 MFMAs
 //     (the 128x128 kernel needs 8 per 16), and each weight is dequantised once per 256 rows of M;
-//   * A (activations) goes global -> LDS by LDS-DMA (global_load_lds, 16 B per lane, no VGPRs, no VALU); the
-//     16-byte-slot XOR swizzle is applied on the SOURCE address (the DMA destination is lane-linear);
+//   * every global load is an ORDINARY load into registers (A: 4 x 16 B per thread, issued at the top of a k-tile and
+//     written to the other LDS buffer after its MFMAs; packed B words: two register sets, loaded TWO k-tiles ahead).
+//     Weights stream from HBM (~2 us latency) while a k-tile is ~0.4-0.9 us of MFMA: with one tile of look-ahead the
+//     whole block stalls on its weight panel every step.  LDS-DMA for A (tried first) makes hipcc drain vmcnt(0) at
+//     every barrier, which caps the look-ahead at one tile; plain loads survive the barrier (counted vmcnt);
 //   * B: packed words -> registers -> bit-exact fp16 dequant -> ds_write into the k-contiguous [n][64 k] image
 //     (the MFMA B-fragment order), same swizzle; the dequant of tile t+1 is split in two halves placed after each
 //     32-MFMA sub-step of tile t so the VALU work rides under the other waves' MFMAs;
@@ -69,18 +72,22 @@ __global__ __launch_bounds__(512) void gemm2_kernel(const GemmParams p) {
   const int tm = bid % tiles_m, tn = bid / tiles_m;
   const int m0 = tm * BM, n0 = tn * BN;
 
-  // ---- A: LDS-DMA.  One wave-instruction fills 8 rows x 128 B; lane l -> row l/8, destination slot l%8, source
-  //         chunk (l%8) ^ swizzle(row).  Wave w covers rows [32w, 32w+32) in 4 instructions. ---------------------------
-  const int arow = lane >> 3, aslot = lane & 7;
-  auto load_a = [&](int kt, int buf) {
+  // ---- A: registers -> LDS.  chunk c = tid + 512 q: row c/8, 16-byte k-chunk c%8 (8 lanes cover one 128-byte row) -----
+  uint4_t areg[4];
+  auto load_a = [&](int kt) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = tid + 512 * q, row = c >> 3, kc = c & 7;
+      const int grow = min(m0 + row, p.M - 1);  // rows past M re-read the last row; their outputs are never stored
+      areg[q] = *(const uint4_t *)((const half_t *)p.x + (size_t)grow * p.K + kt * BK + 8 * kc);
+    }
+  };
+  auto store_a = [&](int buf) {
     half_t *Ab = As + buf * kTile;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int row = wave * 32 + q * 8 + arow;
-      const int grow = min(m0 + row, p.M - 1);  // rows past M re-read the last row; their outputs are never stored
-      const int chunk = aslot ^ ((row ^ (row >> 3)) & 7);
-      const half_t *src = (const half_t *)p.x + (size_t)grow * p.K + kt * BK + 8 * chunk;
-      __builtin_amdgcn_global_load_lds((gbl_cvoid_t *)src, (lds_void_t *)(Ab + (wave * 32 + q * 8) * BK), 16, 0, 0);
+      const int c = tid + 512 * q, row = c >> 3, kc = c & 7;
+      *(uint4_t *)(Ab + tile_off(row, kc)) = areg[q];
     }
   };
 
@@ -90,61 +97,72 @@ __global__ __launch_bounds__(512) void gemm2_kernel(const GemmParams p) {
   const int bcol = (LAYOUT == 0) ? (tid % BN) : 8 * (tid % (BN / 8));
   const int brow = (LAYOUT == 0) ? WPT * (tid / BN) : WPT * (tid / (BN / 8));
   const int nB = n0 + bcol;
-  constexpr int NC = (LAYOUT == 0) ? 1 : 8;
-  ColConst cc[NC];
-#pragma unroll
-  for (int c = 0; c < NC; ++c) cc[c] = make_col_const((half_t)0.f, (half_t)0.f);
-  int curG = -1;
   const uint32_t nibmask = nib_mask_vgpr();
+  auto group_of = [&](int k) { return k >> p.gs_shift; };  // power-of-two group sizes only (gemm2_ok): no branch
+  // zero points, branch-free addressing (see strip.hip): packed -> word (G, n/8); fp16 -> dword holding half (G, n)
+  const int zk = p.zero_kind;
+  const uint32_t *zbase = (zk == ZK_SYM) ? (const uint32_t *)p.scales : (const uint32_t *)p.qzeros;
+  const int zmul = (zk == ZK_PACKED) ? (p.N >> 3) : (p.N >> 1);
+  const int zoff = (zk == ZK_PACKED) ? (nB >> 3) : (nB >> 1);
 
-  auto group_of = [&](int k) { return p.gs_shift >= 0 ? (k >> p.gs_shift) : (k / p.group_size); };
-  auto set_group = [&](int G) {
-    if (G == curG) return;
-    curG = G;
-    if constexpr (LAYOUT == 0) {
-      cc[0] = make_col_const(p.scales[(size_t)G * p.N + nB], zero_gptq(p, G, nB));
-    } else {
-      const half8_t sv = *(const half8_t *)(p.scales + (size_t)G * p.N + nB);
-#pragma unroll
-      for (int c = 0; c < 8; ++c) cc[c] = make_col_const(sv[c], zero_awq(p, G, nB + c));
-    }
+  // One register set = everything this thread needs to dequantise its share of one k-tile: WPT packed words plus the
+  // RAW scale / zero words of their group (a thread's rows span <= 32 k: one group, group_size % 32 == 0).  Two sets:
+  // set (t & 1) belongs to k-tile t and is loaded two tiles ahead; nothing is converted before it is needed, so no
+  // load is ever waited for early.
+  struct BSet {
+    uint32_t w[WPT];
+    half8_t s8;     // AWQ: the 8 columns' scales
+    uint32_t sraw;  // GPTQ: the column's scale, raw 16 bits in its own register (no read-modify-write of a packed reg)
+    uint32_t z;
   };
-
-  uint32_t breg[WPT];
-  auto load_b = [&](int kt) {
+  BSet bset[2];
+  const int KT = p.K / BK;
+  auto load_b = [&](int kt, BSet &bs) {
+    const int ktc = min(kt, KT - 1);  // past the end: harmless re-read, never used
 #pragma unroll
     for (int r = 0; r < WPT; ++r) {
       if constexpr (LAYOUT == 0)
-        breg[r] = p.qweight[(size_t)(kt * 8 + brow + r) * p.N + nB];
+        bs.w[r] = p.qweight[(size_t)(ktc * 8 + brow + r) * p.N + nB];
       else
-        breg[r] = p.qweight[(size_t)(kt * BK + brow + r) * (p.N >> 3) + (nB >> 3)];
+        bs.w[r] = p.qweight[(size_t)(ktc * BK + brow + r) * (p.N >> 3) + (nB >> 3)];
     }
-  };
-  // dequant + LDS write of this thread's 4 words, in two halves (h = 0, 1)
-  auto store_b = [&](int kt, int buf, int h) {
-    half_t *Bb = Bs + buf * kTile;
-    const int k0 = kt * BK;
+    const int G = group_of(ktc * BK + ((LAYOUT == 0) ? 8 * brow : brow));
     if constexpr (LAYOUT == 0) {
+      bs.sraw = ((const uint16_t *)p.scales)[(size_t)G * p.N + nB];
+    } else {
+      bs.s8 = *(const half8_t *)(p.scales + (size_t)G * p.N + nB);
+    }
+    bs.z = zbase[(size_t)G * zmul + zoff];
+  };
+  // dequant + LDS write of this thread's words, in two halves (h = 0, 1)
+  auto store_b = [&](int kt, int buf, int h, const BSet &bs) {
+    half_t *Bb = Bs + buf * kTile;
+    if constexpr (LAYOUT == 0) {
+      const half_t zp = (half_t)(float)(((bs.z >> (4 * (nB & 7))) + (uint32_t)p.add_zero_bias) & 15u);
+      const half_t zf = __builtin_bit_cast(half_t, (uint16_t)((nB & 1) ? (bs.z >> 16) : (bs.z & 0xffffu)));
+      const half_t sc = __builtin_bit_cast(half_t, (uint16_t)bs.sraw);
+      const ColConst cc = make_col_const(sc, (zk == ZK_PACKED) ? zp : ((zk == ZK_F16) ? zf : (half_t)8.f));
 #pragma unroll
       for (int r = (WPT / 2) * h; r < (WPT / 2) * (h + 1); ++r) {
-        set_group(group_of(k0 + 8 * (brow + r)));
-        const half8_t w = unperm_04152637(deq_word_k04(breg[r], cc[0], nibmask));
+        const half8_t w = unperm_04152637(deq_word_k04(bs.w[r], cc, nibmask));
         *(half8_t *)(Bb + tile_off(bcol, brow + r)) = w;
       }
     } else {
       if (WPT == 2 && h == 1) return;  // two rows = one k pair, done in the first half
-      set_group(group_of(k0 + brow));
-      const uint32_t P = __builtin_amdgcn_perm(breg[2 * h + 1], breg[2 * h], 0x05040100u);
-      const uint32_t Q = __builtin_amdgcn_perm(breg[2 * h + 1], breg[2 * h], 0x07060302u);
+      const uint32_t P = __builtin_amdgcn_perm(bs.w[2 * h + 1], bs.w[2 * h], 0x05040100u);
+      const uint32_t Q = __builtin_amdgcn_perm(bs.w[2 * h + 1], bs.w[2 * h], 0x07060302u);
       // rows brow+2h, brow+2h+1 -> one k pair per column: 4-byte writes
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
         const int sh = 4 * (c >> 1);
         const uint32_t s0 = (c & 1) ? Q : P;
-        const half2_t b0 = deq_pair(and_or(s0 >> sh, nibmask, kMagic), cc[c]);
+        const half_t z = (half_t)(float)((bs.z >> (4 * awq_nibble_of_col(c))) & 15u);
+        const ColConst cc = make_col_const(bs.s8[c], z);
+        const half2_t b0 = deq_pair(and_or(s0 >> sh, nibmask, kMagic), cc);
         *(half2_t *)(Bb + tile_off(bcol + c, brow >> 3) + (brow & 7) + 2 * h) = b0;
       }
     }
+    (void)kt;
   };
 
   float4_t acc[AM][4];
@@ -153,20 +171,22 @@ __global__ __launch_bounds__(512) void gemm2_kernel(const GemmParams p) {
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = float4_t{0.f, 0.f, 0.f, 0.f};
 
-  const int KT = p.K / BK;
-  load_a(0, 0);
-  load_b(0);
-  store_b(0, 0, 0);
-  store_b(0, 0, 1);
-  __syncthreads();  // (waits for the LDS-DMA: hipcc drains vmcnt before the barrier when a DMA is in flight)
+  // prologue: tile 0 staged, tile 1's words in flight
+  load_a(0);
+  load_b(0, bset[0]);
+  load_b(1, bset[1]);
+  store_b(0, 0, 0, bset[0]);
+  store_b(0, 0, 1, bset[0]);
+  store_a(0);
+  __syncthreads();
 
-  for (int kt = 0; kt < KT; ++kt) {
+  // one k-tile: MFMAs on buffer `buf`; meanwhile load A(kt+1) and B(kt+2), dequantise B(kt+1) into the other buffer
+  auto k_tile = [&](int kt, BSet &b_next, BSet &b_free) {
     const int buf = kt & 1;
-    const bool more = kt + 1 < KT;
-    if (more) {
-      load_a(kt + 1, buf ^ 1);
-      load_b(kt + 1);
-    }
+    // no conditionals in here: a branch around a load makes hipcc's counted vmcnt collapse to vmcnt(0) at the join.
+    // Past the last tile the loads re-read it and the stores fill a buffer nobody reads again.
+    load_a(min(kt + 1, KT - 1));
+    load_b(kt + 2, b_free);  // b_free held tile kt (dequantised during tile kt-1): refill it ~1.5 tiles ahead of use
     const half_t *Ab = As + buf * kTile, *Bb = Bs + buf * kTile;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -179,9 +199,14 @@ __global__ __launch_bounds__(512) void gemm2_kernel(const GemmParams p) {
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[b], acc[a][b], 0, 0, 0);
       }
-      if (more) store_b(kt + 1, buf ^ 1, ks);
+      store_b(kt + 1, buf ^ 1, ks, b_next);
     }
+    store_a(buf ^ 1);
     __syncthreads();
+  };
+  for (int kt = 0; kt < KT; kt += 2) {
+    k_tile(kt, bset[1], bset[0]);
+    if (kt + 1 < KT) k_tile(kt + 1, bset[0], bset[1]);
   }
 
   // ---- epilogue: + bias, round once, transpose through wave-private LDS, 16-byte row-contiguous stores ---------------
@@ -210,8 +235,7 @@ bool gemm2_ok(const GemmParams &p, int layout) {
   static const char *e = getenv("QLLM_GEMM2");
   if (e && e[0] == '0') return false;
   if (p.act_bf16 || p.g_idx || p.K % 64 != 0 || p.N % 128 != 0 || p.M < 192) return false;
-  if (layout == QLLM_LAYOUT_AWQ_GEMM) return p.group_size % 4 == 0;
-  return p.group_size % 8 == 0;
+  return p.group_size % 32 == 0 && p.gs_shift >= 0;  // one group per thread per k-tile; power-of-two group size
 }
 
 template <int LAYOUT, int BN>
