@@ -69,20 +69,27 @@ __global__ __launch_bounds__(512) void gemm2_kernel(const GemmParams p) {
     const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, idx = bid / 8;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int tm = bid % tiles_m, tn = bid / tiles_m;
+  // p.raster 0: m fastest (an XCD's run shares weight panels); 1: n fastest (an XCD's run shares activation rows:
+  // 256 rows x K x 2 B = 2 MB per row block stays in its 4 MB L2 while the small packed weights stream)
+  const int tm = p.raster ? (bid / tiles_n) : (bid % tiles_m);
+  const int tn = p.raster ? (bid % tiles_n) : (bid / tiles_m);
   const int m0 = tm * BM, n0 = tn * BN;
 
   // ---- A: registers -> LDS.  chunk c = tid + 512 q: row c/8, 16-byte k-chunk c%8 (8 lanes cover one 128-byte row) -----
-  uint4_t areg[4];
-  auto load_a = [&](int kt) {
+  // two register sets like B (set (t & 1) = k-tile t) when the register budget allows (BN = 128): the activation
+  // tile is then requested TWO k-tiles before it is written to LDS; with BN = 256 (250 VGPRs) one set, one tile ahead.
+  constexpr int ASETS = (BN == 128) ? 2 : 1;
+  uint4_t aset[ASETS][4];
+  auto load_a = [&](int kt, uint4_t (&areg)[4]) {
+    const int ktc = min(kt, p.K / BK - 1);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int c = tid + 512 * q, row = c >> 3, kc = c & 7;
       const int grow = min(m0 + row, p.M - 1);  // rows past M re-read the last row; their outputs are never stored
-      areg[q] = *(const uint4_t *)((const half_t *)p.x + (size_t)grow * p.K + kt * BK + 8 * kc);
+      areg[q] = *(const uint4_t *)((const half_t *)p.x + (size_t)grow * p.K + ktc * BK + 8 * kc);
     }
   };
-  auto store_a = [&](int buf) {
+  auto store_a = [&](int buf, const uint4_t (&areg)[4]) {
     half_t *Ab = As + buf * kTile;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -172,22 +179,27 @@ __global__ __launch_bounds__(512) void gemm2_kernel(const GemmParams p) {
     for (int b = 0; b < 4; ++b) acc[a][b] = float4_t{0.f, 0.f, 0.f, 0.f};
 
   // prologue: tile 0 staged, tile 1's words in flight
-  load_a(0);
+  load_a(0, aset[0]);
   load_b(0, bset[0]);
   load_b(1, bset[1]);
+  if (ASETS == 2) load_a(1, aset[ASETS - 1]);
   store_b(0, 0, 0, bset[0]);
   store_b(0, 0, 1, bset[0]);
-  store_a(0);
+  store_a(0, aset[0]);
   __syncthreads();
 
   // one k-tile: MFMAs on buffer `buf`; meanwhile load A(kt+1) and B(kt+2), dequantise B(kt+1) into the other buffer
-  auto k_tile = [&](int kt, BSet &b_next, BSet &b_free) {
+  auto k_tile = [&](int kt, BSet &b_next, BSet &b_free, uint4_t (&a_next)[4], uint4_t (&a_free)[4]) {
     const int buf = kt & 1;
     // no conditionals in here: a branch around a load makes hipcc's counted vmcnt collapse to vmcnt(0) at the join.
     // Past the last tile the loads re-read it and the stores fill a buffer nobody reads again.
-    load_a(min(kt + 1, KT - 1));
+    // ASETS == 2: a_free held tile kt (already in LDS) -> request tile kt+2; a_next holds tile kt+1 (requested one tile ago)
+    // ASETS == 1: a_free == a_next: request tile kt+1 now, write it at the end of this tile
+    load_a(kt + ASETS, a_free);
     load_b(kt + 2, b_free);  // b_free held tile kt (dequantised during tile kt-1): refill it ~1.5 tiles ahead of use
     const half_t *Ab = As + buf * kTile, *Bb = Bs + buf * kTile;
+    // (Tried: staggering the two waves of each SIMD -- waves 4-7 doing their dequant/LDS stores before their MFMAs.
+    //  The uniform branch around the stores made hipcc collapse the counted vmcnt waits to vmcnt(0): 805 -> 698 TFLOP/s.)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       half8_t bf[4];
@@ -201,12 +213,12 @@ __global__ __launch_bounds__(512) void gemm2_kernel(const GemmParams p) {
       }
       store_b(kt + 1, buf ^ 1, ks, b_next);
     }
-    store_a(buf ^ 1);
+    store_a(buf ^ 1, a_next);
     __syncthreads();
   };
   for (int kt = 0; kt < KT; kt += 2) {
-    k_tile(kt, bset[1], bset[0]);
-    if (kt + 1 < KT) k_tile(kt + 1, bset[0], bset[1]);
+    k_tile(kt, bset[1], bset[0], aset[ASETS - 1], aset[0]);
+    if (kt + 1 < KT) k_tile(kt + 1, bset[0], bset[1], aset[0], aset[ASETS - 1]);
   }
 
   // ---- epilogue: + bias, round once, transpose through wave-private LDS, 16-byte row-contiguous stores ---------------
@@ -253,7 +265,10 @@ static int launch_gemm2_t(const GemmParams &p, hipStream_t stream) {
   return QLLM_OK;
 }
 
-int launch_gemm2(const GemmParams &p, int layout, hipStream_t stream) {
+int launch_gemm2(const GemmParams &p_in, int layout, hipStream_t stream) {
+  GemmParams p = p_in;
+  static int raster = getenv("QLLM_GEMM2_RASTER") ? atoi(getenv("QLLM_GEMM2_RASTER")) : 1;  // measured +2-3 %
+  p.raster = raster;
   // 256x256 tiles when they fill the chip well; else 256x128 (twice the blocks)
   static int force_bn = getenv("QLLM_GEMM2_BN") ? atoi(getenv("QLLM_GEMM2_BN")) : 0;
   const int tiles256 = ((p.M + 255) / 256) * (p.N / 256);

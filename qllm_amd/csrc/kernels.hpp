@@ -86,6 +86,7 @@ struct GemmParams {
   const half_t *bias;
   void *y;
   int M, K, N, group_size, gs_shift, add_zero_bias, zero_kind, act_bf16, n_groups;
+  int raster;  // gemm2 tile order: 0 = m fastest, 1 = n fastest inside an XCD's run
 };
 int launch_gemm(const GemmParams &p, int layout, hipStream_t stream);
 
