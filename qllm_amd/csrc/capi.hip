@@ -319,6 +319,7 @@ int qllm_linear_forward(const qllm_weight_t *w, const void *x, void *y, int32_t 
     p.act_bf16 = (act_dtype == QLLM_BF16);
     p.n_groups = (w->K + w->group_size - 1) / w->group_size;
     p.raster = 0;
+    p.stagger = 0;
     if (gemm2_ok(p, w->layout)) return launch_gemm2(p, w->layout, (hipStream_t)stream);
     return launch_gemm(p, w->layout, (hipStream_t)stream);
   }

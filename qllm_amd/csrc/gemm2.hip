@@ -16,6 +16,8 @@
 //   * epilogue through wave-private LDS: 16-byte row-contiguous stores instead of 2-byte scattered ones.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "kernels.hpp"
 
 namespace qllm {
@@ -188,8 +190,24 @@ __global__ __launch_bounds__(512) void gemm2_kernel(const GemmParams p) {
   store_a(0, aset[0]);
   __syncthreads();
 
-  // one k-tile: MFMAs on buffer `buf`; meanwhile load A(kt+1) and B(kt+2), dequantise B(kt+1) into the other buffer
-  auto k_tile = [&](int kt, BSet &b_next, BSet &b_free, uint4_t (&a_next)[4], uint4_t (&a_free)[4]) {
+  // one k-tile: MFMAs on buffer `buf`; meanwhile load A(kt+ASETS) and B(kt+2), dequantise B(kt+1) into the other buffer.
+  // EARLY = true: the dequant + LDS stores of tile kt+1 come BEFORE this tile's MFMAs instead of between/after them.
+  // Waves w and w+4 share a SIMD; running waves 4-7 with EARLY (two fully separate straight-line bodies, joined only at
+  // the barrier, so hipcc's counted vmcnt waits survive) puts one wave of every SIMD in its VALU phase while the other
+  // is in its MFMA phase.  Needs the tile-(kt+1) words to be resident already, i.e. two register sets (BN = 128).
+  auto mfma_sub = [&](const half_t *Ab, const half_t *Bb, int ks) {
+    half8_t bf[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) bf[b] = *(const half8_t *)(Bb + tile_off(wn * 64 + b * 16 + i, ks * 4 + g));
+#pragma unroll
+    for (int a = 0; a < AM; ++a) {
+      const half8_t af = *(const half8_t *)(Ab + tile_off(wm * WROWS + a * 16 + i, ks * 4 + g));
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[b], acc[a][b], 0, 0, 0);
+    }
+  };
+  auto k_tile = [&](int kt, BSet &b_next, BSet &b_free, uint4_t (&a_next)[4], uint4_t (&a_free)[4], auto early_tag) {
+    constexpr bool EARLY = decltype(early_tag)::value;
     const int buf = kt & 1;
     // no conditionals in here: a branch around a load makes hipcc's counted vmcnt collapse to vmcnt(0) at the join.
     // Past the last tile the loads re-read it and the stores fill a buffer nobody reads again.
@@ -198,27 +216,33 @@ __global__ __launch_bounds__(512) void gemm2_kernel(const GemmParams p) {
     load_a(kt + ASETS, a_free);
     load_b(kt + 2, b_free);  // b_free held tile kt (dequantised during tile kt-1): refill it ~1.5 tiles ahead of use
     const half_t *Ab = As + buf * kTile, *Bb = Bs + buf * kTile;
-    // (Tried: staggering the two waves of each SIMD -- waves 4-7 doing their dequant/LDS stores before their MFMAs.
-    //  The uniform branch around the stores made hipcc collapse the counted vmcnt waits to vmcnt(0): 805 -> 698 TFLOP/s.)
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      half8_t bf[4];
-#pragma unroll
-      for (int b = 0; b < 4; ++b) bf[b] = *(const half8_t *)(Bb + tile_off(wn * 64 + b * 16 + i, ks * 4 + g));
-#pragma unroll
-      for (int a = 0; a < AM; ++a) {
-        const half8_t af = *(const half8_t *)(Ab + tile_off(wm * WROWS + a * 16 + i, ks * 4 + g));
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[b], acc[a][b], 0, 0, 0);
-      }
-      store_b(kt + 1, buf ^ 1, ks, b_next);
+    if constexpr (EARLY) {
+      store_b(kt + 1, buf ^ 1, 0, b_next);
+      store_b(kt + 1, buf ^ 1, 1, b_next);
+      store_a(buf ^ 1, a_next);
+      mfma_sub(Ab, Bb, 0);
+      mfma_sub(Ab, Bb, 1);
+    } else {
+      mfma_sub(Ab, Bb, 0);
+      store_b(kt + 1, buf ^ 1, 0, b_next);
+      mfma_sub(Ab, Bb, 1);
+      store_b(kt + 1, buf ^ 1, 1, b_next);
+      store_a(buf ^ 1, a_next);
     }
-    store_a(buf ^ 1, a_next);
     __syncthreads();
   };
-  for (int kt = 0; kt < KT; kt += 2) {
-    k_tile(kt, bset[1], bset[0], aset[ASETS - 1], aset[0]);
-    if (kt + 1 < KT) k_tile(kt + 1, bset[0], bset[1], aset[0], aset[ASETS - 1]);
+  using TagT = std::integral_constant<bool, true>;
+  using TagF = std::integral_constant<bool, false>;
+  if (ASETS == 2 && p.stagger && wave >= 4) {
+    for (int kt = 0; kt < KT; kt += 2) {
+      k_tile(kt, bset[1], bset[0], aset[ASETS - 1], aset[0], TagT{});
+      if (kt + 1 < KT) k_tile(kt + 1, bset[0], bset[1], aset[0], aset[ASETS - 1], TagT{});
+    }
+  } else {
+    for (int kt = 0; kt < KT; kt += 2) {
+      k_tile(kt, bset[1], bset[0], aset[ASETS - 1], aset[0], TagF{});
+      if (kt + 1 < KT) k_tile(kt + 1, bset[0], bset[1], aset[0], aset[ASETS - 1], TagF{});
+    }
   }
 
   // ---- epilogue: + bias, round once, transpose through wave-private LDS, 16-byte row-contiguous stores ---------------
@@ -269,6 +293,8 @@ int launch_gemm2(const GemmParams &p_in, int layout, hipStream_t stream) {
   GemmParams p = p_in;
   static int raster = getenv("QLLM_GEMM2_RASTER") ? atoi(getenv("QLLM_GEMM2_RASTER")) : 1;  // measured +2-3 %
   p.raster = raster;
+  static int stagger = getenv("QLLM_GEMM2_STAGGER") ? atoi(getenv("QLLM_GEMM2_STAGGER")) : 0;  // measured: 771 vs 808 TFLOP/s with it on
+  p.stagger = stagger;
   // 256x256 tiles when they fill the chip well; else 256x128 (twice the blocks)
   static int force_bn = getenv("QLLM_GEMM2_BN") ? atoi(getenv("QLLM_GEMM2_BN")) : 0;
   const int tiles256 = ((p.M + 255) / 256) * (p.N / 256);

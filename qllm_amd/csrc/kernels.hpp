@@ -86,7 +86,8 @@ struct GemmParams {
   const half_t *bias;
   void *y;
   int M, K, N, group_size, gs_shift, add_zero_bias, zero_kind, act_bf16, n_groups;
-  int raster;  // gemm2 tile order: 0 = m fastest, 1 = n fastest inside an XCD's run
+  int raster;   // gemm2 tile order: 0 = m fastest, 1 = n fastest inside an XCD's run
+  int stagger;  // gemm2: waves 4-7 run their VALU phase before their MFMA phase
 };
 int launch_gemm(const GemmParams &p, int layout, hipStream_t stream);
 
