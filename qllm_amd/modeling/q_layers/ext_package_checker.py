@@ -11,15 +11,21 @@ from ... import _lib
 
 @functools.lru_cache()
 def has_package(package_name: str) -> bool:
+    """True iff `package_name` can actually be imported (kept for callers that probe optional packages by name)."""
     import importlib
+    import importlib.util
 
     try:
-        if importlib.util.find_spec(package_name) is not None:
-            importlib.import_module(package_name)
-            return True
+        spec = importlib.util.find_spec(package_name)
+    except (ImportError, ValueError):
+        return False
+    if spec is None:
+        return False
+    try:
+        importlib.import_module(package_name)
     except Exception:  # noqa: BLE001
-        pass
-    return False
+        return False
+    return True
 
 
 @functools.lru_cache()

@@ -13,24 +13,28 @@ from .compress_weight import CompressWeight
 
 
 class QuantLinearHQQ(nn.Module, CompressWeight, HipForwardMixin):
+    """Buffers: qweight i32 [K//32*bits, N] (column bit streams, as GPTQ); qzeros and scales in the module dtype,
+    [ceil(K/g), N] each (the zeros are real numbers: HQQ does not round them); bias [N] or None.  g_idx is a plain
+    attribute (never act-order), exactly as in the reference."""
+
+    SUPPORTED_BITS = (2, 3, 4, 5, 6, 7, 8)
+
     def __init__(self, bits, groupsize, infeatures, outfeatures, bias, dtype=None):
         super().__init__()
-        self.dtype = torch.get_default_dtype() if dtype is None else dtype
-        if bits not in [2, 3, 4, 5, 6, 7, 8]:
+        if bits not in self.SUPPORTED_BITS:
             raise NotImplementedError("Only 2,4,5,6,7,8 bits are supported.")
-        self.infeatures = infeatures
-        self.outfeatures = outfeatures
-        self.bits = bits
-        self.groupsize = groupsize if groupsize != -1 else infeatures
-        self.pack_mode = "HQQ"
-        self.orig_fp_weight = None
-        self.g_idx = (torch.arange(infeatures) // self.groupsize).to(torch.int32)  # plain attribute, as the reference
-        groups = math.ceil(infeatures / self.groupsize)
-        self.register_buffer("qweight", torch.zeros((infeatures // 32 * self.bits, outfeatures), dtype=torch.int32))
-        self.register_buffer("qzeros", torch.zeros((groups, outfeatures), dtype=self.dtype))
-        self.register_buffer("scales", torch.zeros((groups, outfeatures), dtype=self.dtype))
+        self.dtype = dtype if dtype is not None else torch.get_default_dtype()
+        self.bits, self.infeatures, self.outfeatures = bits, infeatures, outfeatures
+        self.groupsize = infeatures if groupsize == -1 else groupsize
+        self.pack_mode, self.orig_fp_weight = "HQQ", None
+        n_groups = math.ceil(infeatures / self.groupsize)
+        self.g_idx = torch.div(torch.arange(infeatures), self.groupsize, rounding_mode="floor").to(torch.int32)
+        per_group = lambda: torch.zeros((n_groups, outfeatures), dtype=self.dtype)  # noqa: E731
+        self.register_buffer("qweight", torch.zeros((infeatures // 32 * bits, outfeatures), dtype=torch.int32))
+        self.register_buffer("qzeros", per_group())
+        self.register_buffer("scales", per_group())
         if bias:
-            self.register_buffer("bias", torch.zeros((outfeatures), dtype=self.dtype))
+            self.register_buffer("bias", torch.zeros(outfeatures, dtype=self.dtype))
         else:
             self.bias = None
 
