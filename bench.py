@@ -269,6 +269,25 @@ def main():
             extra[f"prefill_m2048_{tag}"] = {"ms_per_4_layers": round(ms, 3), "TFLOPs": round(tf, 1),
                                              "frac_of_mfma_peak": round(tf / MFMA_PEAK_TFLOPS, 4)}
             del ps
+        # BASELINE configs[3]: HQQ g64 fp16 zeros, batch 16, alternating 4-bit / 3-bit layers (3-bit has no fused kernel
+        # yet: library dequant + GEMM).  Two decoder layers' 7 linears each.
+        from qllm_amd.modeling.q_layers import QuantLinearHQQ
+        hq = []
+        for li, bits in enumerate((4, 3)):
+            for (K, N) in [(HIDDEN, HIDDEN)] * 4 + [(HIDDEN, INTER)] * 2 + [(INTER, HIDDEN)]:
+                l = QuantLinearHQQ(bits, 64, K, N, False, dtype=torch.float16)
+                l.qweight = torch.randint(-2 ** 31, 2 ** 31 - 1, l.qweight.shape, dtype=torch.int32, device=dev)
+                l.qzeros = (torch.rand(l.qzeros.shape, device=dev) * (2 ** bits - 1)).half()
+                l.scales = ((torch.rand(l.scales.shape, device=dev) * 0.4 + 0.8) / (K ** 0.5 * 6.5)).half()
+                hq.append((l.to(dev), K))
+        xs16 = {K: torch.randn(16, K, device=dev, dtype=torch.float16) for K in (HIDDEN, INTER)}
+        for bits_sel, tag in ((4, "hqq_w4_g64_m16"), (3, "hqq_w3_g64_m16")):
+            ls = [(l, K) for (l, K) in hq if l.bits == bits_sel]
+            for l, K in ls:
+                l(xs16[K])
+            ms = time_events(lambda: [l(xs16[K]) for l, K in ls], 10)
+            nbytes = sum(alg_bytes(l.infeatures, l.outfeatures, 16, 64, "f16") * bits_sel // 4 for l, _ in ls)
+            extra[tag] = {"ms_per_layer": round(ms, 4), "GBps": round(nbytes / ms / 1e6, 1)}
         result["extra"] = extra
         result["cpu_baseline"] = cpu_baseline_leg()
     elif rank == 0:
