@@ -102,18 +102,35 @@ static bool strip_plan(const qllm_weight_t *w, int n, int M, StripPlan *plan) {
     m32 = m32 && (w[i].N % 32 == 0);
   }
   static int force_cpl = env_int("QLLM_STRIP_CPL", 0);
-  plan->cpl = strip_cpl(cols, m64, m32);
-  if (force_cpl == 4 && m64) plan->cpl = 4;
-  if (force_cpl == 2 && m32) plan->cpl = 2;
-  if (force_cpl == 1) plan->cpl = 1;
-  const int strips = cols / (16 * plan->cpl);
-  if (plan->cpl == 1 && strips < strip_min_strips()) return false;
-  // 64-column strips use 128 VGPRs -> 16 waves per CU: 8-wave blocks keep two strips co-resident per CU (one
-  // round) instead of 16-wave blocks in two rounds (gate/up 15.6 -> 13.8 us, q/k/v 8.5 -> 8.3 us)
   static int nw4 = env_int("QLLM_STRIP_NW4", 0);
-  plan->nw = plan->cpl == 4 ? (nw4 ? nw4 : 8) : (plan->cpl == 2 ? 16 : strip_nw(w[0].K, strips));
-  plan->spw = strip_spw(w[0].K, w[0].group_size, plan->nw);
-  return strip_x_ok(M, plan->spw, plan->nw, plan->cpl) && strip_lds_bytes(M, plan->spw, plan->nw, plan->cpl) <= 150 * 1024;
+  int first = strip_cpl(cols, m64, m32);
+  if (force_cpl == 4 && m64) first = 4;
+  if (force_cpl == 2 && m32) first = 2;
+  if (force_cpl == 1) first = 1;
+  // candidates: the measured-best strip width first; if its activation slab does not fit in LDS (many rows), narrower
+  // strips with 16 waves (each wave stages a shorter K chunk)
+  const int cand_cpl[2] = {first, 1};
+  for (int ci = 0; ci < 2; ++ci) {
+    const int cpl = cand_cpl[ci];
+    if (ci == 1 && cpl == first) break;
+    const int strips = cols / (16 * cpl);
+    if (cpl == 1 && strips < strip_min_strips()) continue;
+    // 64-column strips use 128 VGPRs -> 16 waves per CU: 8-wave blocks keep two strips co-resident per CU (one
+    // round) instead of 16-wave blocks in two rounds (gate/up 15.6 -> 13.8 us, q/k/v 8.5 -> 8.3 us)
+    int nw = cpl == 4 ? (nw4 ? nw4 : 8) : (cpl == 2 ? 16 : strip_nw(w[0].K, strips));
+    for (int tries = 0; tries < 2; ++tries) {
+      const int spw = strip_spw(w[0].K, w[0].group_size, nw);
+      if (strip_x_ok(M, spw, nw, cpl) && strip_lds_bytes(M, spw, nw, cpl, w[0].group_size) <= 156 * 1024) {
+        plan->cpl = cpl;
+        plan->nw = nw;
+        plan->spw = spw;
+        return true;
+      }
+      if (nw == 16) break;
+      nw = 16;  // shorter per-wave chunks
+    }
+  }
+  return false;
 }
 static bool strip_ok(const qllm_weight_t *w, int n, int M) {
   StripPlan pl;

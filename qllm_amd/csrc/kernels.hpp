@@ -71,7 +71,7 @@ struct StripParams {
 bool strip_group_ok(int group_size);
 int strip_nw(int K, int strips_total);
 int strip_spw(int K, int group_size, int nw);
-size_t strip_lds_bytes(int M, int spw, int nw, int cpl);
+size_t strip_lds_bytes(int M, int spw, int nw, int cpl, int group_size);
 int strip_cpl(int cols_total, bool all_mult64, bool all_mult32);
 bool strip_x_ok(int M, int spw, int nw, int cpl);
 int launch_strip(const StripParams &p, int grid, hipStream_t stream);

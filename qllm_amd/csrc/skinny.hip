@@ -20,6 +20,8 @@
 //     sc1 stores, arrival ticket, last-arriving block sums the slabs in fixed order -> deterministic; the
 //     reference's fp16 split-k partials, gemm_cuda_gen.cu:1115,1160, are not reproduced).
 //   * up to 8 layers that share x (q/k/v, gate/up) run as ONE launch (block ranges per problem).
+#include <stdlib.h>
+
 #include "kernels.hpp"
 
 namespace qllm {
@@ -43,7 +45,10 @@ __device__ __forceinline__ void load_a(const SkinnyParams &p, int t, int g, int 
 
 // LAYOUT 0: GPTQ/HQQ row stream, lane owns 4 adjacent columns (one dwordx4 per k-step), TN = 64
 // LAYOUT 1: AWQ GEMM, lane owns W words = 8W adjacent columns (8 loads of W dwords per k-step), TN = 128 W
-template <int LAYOUT, int W, int MT>
+// XLDS: the block's activation slab x[M][its K range] is staged once into LDS (permuted to the fragment's k-slot order for
+//       LAYOUT 0) and A fragments are read from there; without it every k-step loads its A fragment from L2, which is
+//       latency-bound (measured 2x on the strip kernel).  Used whenever the slab fits.
+template <int LAYOUT, int W, int MT, bool XLDS>
 __global__ __launch_bounds__(256) void skinny_kernel(const SkinnyParams p) {
   constexpr int CPL = (LAYOUT == 0) ? 4 : 8 * W;  // columns per lane
   constexpr int TN = 16 * CPL;
@@ -154,8 +159,16 @@ __global__ __launch_bounds__(256) void skinny_kernel(const SkinnyParams p) {
           }
         }
       }
-      load_a<MT>(p, t, g, i, s.a);
+      if constexpr (!XLDS) load_a<MT>(p, t, g, i, s.a);
     }
+  };
+
+  // activation slab of this block in LDS: rows M x (4*spw k-steps), row stride + 16 B
+  const int kb0 = kb * 4 * pr.spw;                 // first k-step of the block
+  const int xrow = 4 * pr.spw * 32 + 8;            // halves per staged row
+  half_t *xs = (half_t *)(red + 4 * min(p.M, 16) * TN + 4);
+  auto lds_a = [&](int t, int mt) -> half8_t {
+    return *(const half8_t *)(xs + min(16 * mt + i, p.M - 1) * xrow + 32 * (t - kb0) + 8 * g);
   };
 
   auto compute_step = [&](int t, const Step &s) {
@@ -165,7 +178,7 @@ __global__ __launch_bounds__(256) void skinny_kernel(const SkinnyParams p) {
     if constexpr (LAYOUT == 0) {
       half8_t ap[MT];
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) ap[mt] = a_perm_04152637(s.a[mt]);
+      for (int mt = 0; mt < MT; ++mt) ap[mt] = XLDS ? lds_a(t, mt) : a_perm_04152637(s.a[mt]);
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const half8_t bf = deq_word_k04(s.w[c], cc[c]);
@@ -174,6 +187,9 @@ __global__ __launch_bounds__(256) void skinny_kernel(const SkinnyParams p) {
           acc[mt][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ap[mt], bf, acc[mt][c], 0, 0, 0);
       }
     } else {
+      half8_t an[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) an[mt] = XLDS ? lds_a(t, mt) : s.a[mt];
 #pragma unroll
       for (int e = 0; e < W; ++e) {
         uint32_t P[4], Q[4];
@@ -202,7 +218,7 @@ __global__ __launch_bounds__(256) void skinny_kernel(const SkinnyParams p) {
           const half8_t bf = {b0.x, b0.y, b1.x, b1.y, b2.x, b2.y, b3.x, b3.y};  // natural (k0..k7)
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
-            acc[mt][8 * e + c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(s.a[mt], bf, acc[mt][8 * e + c], 0, 0, 0);
+            acc[mt][8 * e + c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(an[mt], bf, acc[mt][8 * e + c], 0, 0, 0);
         }
       }
     }
@@ -213,6 +229,24 @@ __global__ __launch_bounds__(256) void skinny_kernel(const SkinnyParams p) {
   Step sa[U], sb[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) load_step(t0 + u, sa[u]);
+  if constexpr (XLDS) {
+    // stage the slab while the first weight loads are in flight; k >= K is staged as zero
+    const int cpr = 4 * pr.spw * 4;  // 16-byte chunks per row
+    for (int c = threadIdx.x; c < p.M * cpr; c += 256) {
+      const int row = c / cpr, kc = c - row * cpr;
+      const int k = 32 * kb0 + 8 * kc;
+      half8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (k < p.K) {
+        const size_t off = (size_t)row * p.K + k;
+        if (p.act_bf16)
+          v = bf16x8_to_h8(*(const uint4_t *)((const uint16_t *)p.x + off));
+        else
+          v = *(const half8_t *)((const half_t *)p.x + off);
+      }
+      *(half8_t *)(xs + row * xrow + 8 * kc) = (LAYOUT == 0) ? a_perm_04152637(v) : v;
+    }
+    __syncthreads();
+  }
   for (int tb = t0; tb < t1; tb += 2 * U) {
 #pragma unroll
     for (int u = 0; u < U; ++u) load_step(tb + U + u, sb[u]);
@@ -311,17 +345,28 @@ void skinny_plan(int K, int M, int tiles_total, int target_waves, int *S_out, in
   *spw_out = spw;
 }
 
-template <int LAYOUT, int W>
+template <int LAYOUT, int W, bool XLDS>
 static int launch_mt(const SkinnyParams &p, int mt, int grid, size_t lds, hipStream_t stream) {
+#define QLLM_SK(MT_)                                                                                              \
+  do {                                                                                                            \
+    static bool attr_done = false;                                                                                \
+    if (!attr_done) {                                                                                             \
+      QLLM_HIP_CHECK(hipFuncSetAttribute((const void *)skinny_kernel<LAYOUT, W, MT_, XLDS>,                       \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                \
+      attr_done = true;                                                                                           \
+    }                                                                                                             \
+    hipLaunchKernelGGL((skinny_kernel<LAYOUT, W, MT_, XLDS>), dim3(grid), dim3(256), lds, stream, p);             \
+  } while (0)
   if constexpr (W == 2) {  // the 16-columns-per-lane AWQ variant only exists for one M-tile (register budget)
-    hipLaunchKernelGGL((skinny_kernel<LAYOUT, W, 1>), dim3(grid), dim3(256), lds, stream, p);
+    QLLM_SK(1);
   } else {
     switch (mt) {
-      case 1: hipLaunchKernelGGL((skinny_kernel<LAYOUT, W, 1>), dim3(grid), dim3(256), lds, stream, p); break;
-      case 2: hipLaunchKernelGGL((skinny_kernel<LAYOUT, W, 2>), dim3(grid), dim3(256), lds, stream, p); break;
-      default: hipLaunchKernelGGL((skinny_kernel<LAYOUT, W, 4>), dim3(grid), dim3(256), lds, stream, p); break;
+      case 1: QLLM_SK(1); break;
+      case 2: QLLM_SK(2); break;
+      default: QLLM_SK(4); break;
     }
   }
+#undef QLLM_SK
   QLLM_HIP_CHECK(hipGetLastError());
   return QLLM_OK;
 }
@@ -329,13 +374,19 @@ static int launch_mt(const SkinnyParams &p, int mt, int grid, size_t lds, hipStr
 int launch_skinny(const SkinnyParams &p, int layout, int awq_w, int grid, hipStream_t stream) {
   const int mt = p.M <= 16 ? 1 : (p.M <= 32 ? 2 : 4);
   const int tn = skinny_tile_cols(layout, awq_w);
-  const size_t lds = (size_t)4 * (p.M < 16 ? p.M : 16) * tn * sizeof(float) + 16;
+  const size_t red_bytes = (size_t)4 * (p.M < 16 ? p.M : 16) * tn * sizeof(float) + 16;
+  int spw = 0;
+  for (int i = 0; i < p.n_prob; ++i) spw = p.prob[i].spw > spw ? p.prob[i].spw : spw;
+  const size_t x_bytes = (size_t)p.M * (4 * spw * 32 + 8) * sizeof(half_t);
+  static const bool no_xlds = getenv("QLLM_SKINNY_XLDS") && getenv("QLLM_SKINNY_XLDS")[0] == '0';
+  const bool xlds = !no_xlds && red_bytes + x_bytes <= 144 * 1024;
+  const size_t lds = red_bytes + (xlds ? x_bytes : 0);
   if (layout == QLLM_LAYOUT_AWQ_GEMM) {
-    if (awq_w == 2 && mt == 1) return launch_mt<1, 2>(p, mt, grid, lds, stream);
-    if (awq_w == 2) return set_error(QLLM_ERR_INVALID, "internal: AWQ W=2 needs M <= 16");
-    return launch_mt<1, 1>(p, mt, grid, lds, stream);
+    if (awq_w == 2 && mt != 1) return set_error(QLLM_ERR_INVALID, "internal: AWQ W=2 needs M <= 16");
+    if (awq_w == 2) return xlds ? launch_mt<1, 2, true>(p, mt, grid, lds, stream) : launch_mt<1, 2, false>(p, mt, grid, lds, stream);
+    return xlds ? launch_mt<1, 1, true>(p, mt, grid, lds, stream) : launch_mt<1, 1, false>(p, mt, grid, lds, stream);
   }
-  return launch_mt<0, 1>(p, mt, grid, lds, stream);
+  return xlds ? launch_mt<0, 1, true>(p, mt, grid, lds, stream) : launch_mt<0, 1, false>(p, mt, grid, lds, stream);
 }
 
 }  // namespace qllm

@@ -300,10 +300,11 @@ int strip_spw(int K, int group_size, int nw) {
   return (spw + spg - 1) / spg * spg;
 }
 
-size_t strip_lds_bytes(int M, int spw, int nw, int cpl) {
+size_t strip_lds_bytes(int M, int spw, int nw, int cpl, int group_size) {
   const int pad = strip_spw_pad(nw, spw, cpl);
+  const int groups = pad / (group_size / 32);  // groups per wave chunk
   return (size_t)nw * M * 16 * cpl * sizeof(float) + (size_t)nw * M * (pad * 32 + 8) * sizeof(half_t) +
-         (size_t)nw * pad * 16 * 8;  // (Sx, Sx') table: at most one group per k-step
+         (size_t)nw * groups * 16 * 8;  // (Sx, Sx') float2 per (group, row), 16 rows per group
 }
 
 // columns per lane, from measurements on Llama-2-7B shapes (tools/kbench.py --grouped, us per launch, cpl 1/2/4):
@@ -319,7 +320,7 @@ int strip_cpl(int cols_total, bool all_mult64, bool all_mult32) {
 bool strip_x_ok(int M, int spw, int nw, int cpl) { return strip_xl(nw, M, spw, cpl) <= 8; }
 
 int launch_strip(const StripParams &p, int grid, hipStream_t stream) {
-  const size_t lds = strip_lds_bytes(p.M, p.spw, p.nw, p.cpl);
+  const size_t lds = strip_lds_bytes(p.M, p.spw, p.nw, p.cpl, p.group_size);
   if (p.group_size == 64) return launch_strip_s<2>(p, grid, lds, stream);
   return launch_strip_s<4>(p, grid, lds, stream);
 }
