@@ -93,6 +93,14 @@ struct StripPlan {
 static bool strip_plan(const qllm_weight_t *w, int n, int M, StripPlan *plan) {
   if (M > 16 || strip_min_strips() <= 0) return false;
   if (!strip_group_ok(w[0].group_size)) return false;
+  const int bits = w[0].bits;
+  if (bits != 4 && bits != 3) return false;
+  for (int i = 0; i < n; ++i) {
+    if (w[i].bits != bits || w[i].K % 32 != 0 || w[i].g_idx) return false;
+    // 3-bit: fp16 (HQQ) or symmetric zeros only -- packed 3-bit zero points straddle words
+    if (bits == 3 && !(w[i].layout == QLLM_LAYOUT_HQQ || (w[i].layout == QLLM_LAYOUT_GPTQ && !w[i].qzeros))) return false;
+    if ((uintptr_t)w[i].qweight % 16 || (uintptr_t)w[i].scales % 16 || (w[i].qzeros && (uintptr_t)w[i].qzeros % 8)) return false;
+  }
   int cols = 0;
   bool m64 = true, m32 = true;
   for (int i = 0; i < n; ++i) {
@@ -103,9 +111,9 @@ static bool strip_plan(const qllm_weight_t *w, int n, int M, StripPlan *plan) {
   }
   static int force_cpl = env_int("QLLM_STRIP_CPL", 0);
   static int nw4 = env_int("QLLM_STRIP_NW4", 0);
-  int first = strip_cpl(cols, m64, m32);
-  if (force_cpl == 4 && m64) first = 4;
-  if (force_cpl == 2 && m32) first = 2;
+  int first = bits == 3 ? 1 : strip_cpl(cols, m64, m32);
+  if (force_cpl == 4 && m64 && bits == 4) first = 4;
+  if (force_cpl == 2 && m32 && bits == 4) first = 2;
   if (force_cpl == 1) first = 1;
   // candidates: the measured-best strip width first; if its activation slab does not fit in LDS (many rows), narrower
   // strips with 16 waves (each wave stages a shorter K chunk)
@@ -117,7 +125,7 @@ static bool strip_plan(const qllm_weight_t *w, int n, int M, StripPlan *plan) {
     if (cpl == 1 && strips < strip_min_strips()) continue;
     // 64-column strips use 128 VGPRs -> 16 waves per CU: 8-wave blocks keep two strips co-resident per CU (one
     // round) instead of 16-wave blocks in two rounds (gate/up 15.6 -> 13.8 us, q/k/v 8.5 -> 8.3 us)
-    int nw = cpl == 4 ? (nw4 ? nw4 : 8) : (cpl == 2 ? 16 : strip_nw(w[0].K, strips));
+    int nw = cpl == 4 ? (nw4 ? nw4 : 8) : ((cpl == 2 || bits == 3) ? 16 : strip_nw(w[0].K, strips));
     for (int tries = 0; tries < 2; ++tries) {
       const int spw = strip_spw(w[0].K, w[0].group_size, nw);
       if (strip_x_ok(M, spw, nw, cpl) && strip_lds_bytes(M, spw, nw, cpl, w[0].group_size) <= 156 * 1024) {
@@ -148,6 +156,7 @@ static int run_strip(const qllm_weight_t *w, void *const *y, int n, const void *
   p.K = w[0].K;
   p.T = w[0].K / 32;
   p.cpl = pl.cpl;
+  p.bits = w[0].bits;
   p.nw = pl.nw;
   p.spw = pl.spw;
   p.group_size = w[0].group_size;
@@ -299,9 +308,11 @@ int qllm_linear_forward_grouped(const qllm_weight_t *w, void *const *y, int32_t 
     if (w[i].K != w[0].K || w[i].group_size != w[0].group_size || w[i].bits != w[0].bits || rows0 != rowsi ||
         w[i].add_zero_bias != w[0].add_zero_bias)
       return set_error(QLLM_ERR_INVALID, "grouped weights must agree on K, group_size, bits, layout family and add_zero_bias");
+    if (w[i].bits == 3) continue;  // decided as a group by strip_ok below
     if (!skinny_ok(w[i], M)) return set_error(QLLM_ERR_UNSUPPORTED, "grouped forward needs the decode kernel (4-bit, M<=%d, K%%32==0, no act-order)", skinny_max_m());
   }
   if (strip_ok(w, n_weights, M)) return run_strip(w, y, n_weights, x, M, act_dtype, (hipStream_t)stream);
+  if (w[0].bits != 4) return set_error(QLLM_ERR_UNSUPPORTED, "grouped forward: no fused kernel for %d-bit weights in this shape", w[0].bits);
   return run_skinny(w, y, n_weights, x, M, act_dtype, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
@@ -312,6 +323,10 @@ int qllm_linear_forward(const qllm_weight_t *w, const void *x, void *y, int32_t 
   if (rc) return rc;
   rc = check_io(x, y, M, act_dtype);
   if (rc) return rc;
+  if (w->bits == 3 && strip_ok(w, 1, M)) {
+    void *ys[1] = {y};
+    return run_strip(w, ys, 1, x, M, act_dtype, (hipStream_t)stream);
+  }
   if (skinny_ok(*w, M)) {
     void *ys[1] = {y};
     if (strip_ok(w, 1, M)) return run_strip(w, ys, 1, x, M, act_dtype, (hipStream_t)stream);

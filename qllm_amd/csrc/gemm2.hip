@@ -44,11 +44,11 @@ __device__ __forceinline__ half_t zero_awq(const GemmParams &p, int G, int n) {
 }
 }  // namespace g2
 
-// LAYOUT 0 = GPTQ/HQQ row stream, 1 = AWQ GEMM.  Requires: fp16 activations, K % 64 == 0, N % 256 == 0,
+// LAYOUT 0 = GPTQ/HQQ row stream, 1 = AWQ GEMM.  Requires: K % 64 == 0, N % 128 == 0 (bf16 activations are converted on load),
 // group_size % 8 == 0 (GPTQ) / % 4 == 0 (AWQ), no g_idx.
 // BN = 256: waves 2 (M) x 4 (N), 128x64 per wave.  BN = 128: waves 4 x 2, 64x64 per wave -- twice the blocks, for
 // problems whose 256x256 tiling leaves CUs idle (M=2048 x N=4096 is only 128 such tiles).
-template <int LAYOUT, int BN>
+template <int LAYOUT, int BN, bool BF16>
 __global__ __launch_bounds__(512) void gemm2_kernel(const GemmParams p) {
   using namespace g2;
   constexpr int AM = (BN == 256) ? 8 : 4;        // 16-row MFMA tiles per wave along M
@@ -96,7 +96,10 @@ __global__ __launch_bounds__(512) void gemm2_kernel(const GemmParams p) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int c = tid + 512 * q, row = c >> 3, kc = c & 7;
-      *(uint4_t *)(Ab + tile_off(row, kc)) = areg[q];
+      if constexpr (BF16)  // bf16 activations are converted to fp16 (RNE) on their way into LDS
+        *(half8_t *)(Ab + tile_off(row, kc)) = bf16x8_to_h8(areg[q]);
+      else
+        *(uint4_t *)(Ab + tile_off(row, kc)) = areg[q];
     }
   };
 
@@ -231,18 +234,12 @@ __global__ __launch_bounds__(512) void gemm2_kernel(const GemmParams p) {
     }
     __syncthreads();
   };
-  using TagT = std::integral_constant<bool, true>;
   using TagF = std::integral_constant<bool, false>;
-  if (ASETS == 2 && p.stagger && wave >= 4) {
-    for (int kt = 0; kt < KT; kt += 2) {
-      k_tile(kt, bset[1], bset[0], aset[ASETS - 1], aset[0], TagT{});
-      if (kt + 1 < KT) k_tile(kt + 1, bset[0], bset[1], aset[0], aset[ASETS - 1], TagT{});
-    }
-  } else {
-    for (int kt = 0; kt < KT; kt += 2) {
-      k_tile(kt, bset[1], bset[0], aset[ASETS - 1], aset[0], TagF{});
-      if (kt + 1 < KT) k_tile(kt + 1, bset[0], bset[1], aset[0], aset[ASETS - 1], TagF{});
-    }
+  // (Tried twice: running waves 4-7 with EARLY = true so that the two waves of every SIMD alternate VALU and MFMA phases --
+  //  771 vs 808 TFLOP/s, and the second body costs 17-35 VGPRs; the instantiation is left out.)
+  for (int kt = 0; kt < KT; kt += 2) {
+    k_tile(kt, bset[1], bset[0], aset[ASETS - 1], aset[0], TagF{});
+    if (kt + 1 < KT) k_tile(kt + 1, bset[0], bset[1], aset[0], aset[ASETS - 1], TagF{});
   }
 
   // ---- epilogue: + bias, round once, transpose through wave-private LDS, 16-byte row-contiguous stores ---------------
@@ -255,7 +252,13 @@ __global__ __launch_bounds__(512) void gemm2_kernel(const GemmParams p) {
 #pragma unroll
     for (int b = 0; b < 4; ++b)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) ep[(4 * g + r) * 72 + b * 16 + i] = (half_t)(acc[a][b][r] + bv[b]);
+      for (int r = 0; r < 4; ++r) {
+        const float v = acc[a][b][r] + bv[b];
+        if constexpr (BF16)
+          ((uint16_t *)ep)[(4 * g + r) * 72 + b * 16 + i] = f32_to_bf16(v);
+        else
+          ep[(4 * g + r) * 72 + b * 16 + i] = (half_t)v;
+      }
     // 16 rows x 128 B = 128 chunks of 16 B: 2 per lane
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -270,23 +273,28 @@ __global__ __launch_bounds__(512) void gemm2_kernel(const GemmParams p) {
 bool gemm2_ok(const GemmParams &p, int layout) {
   static const char *e = getenv("QLLM_GEMM2");
   if (e && e[0] == '0') return false;
-  if (p.act_bf16 || p.g_idx || p.K % 64 != 0 || p.N % 128 != 0 || p.M < 192) return false;
+  if (p.g_idx || p.K % 64 != 0 || p.N % 128 != 0 || p.M < 192) return false;
   return p.group_size % 32 == 0 && p.gs_shift >= 0;  // one group per thread per k-tile; power-of-two group size
 }
 
-template <int LAYOUT, int BN>
-static int launch_gemm2_t(const GemmParams &p, hipStream_t stream) {
+template <int LAYOUT, int BN, bool BF16>
+static int launch_gemm2_b(const GemmParams &p, hipStream_t stream) {
   using namespace g2;
   static bool attr_done = false;
   if (!attr_done) {
-    QLLM_HIP_CHECK(hipFuncSetAttribute((const void *)gemm2_kernel<LAYOUT, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    QLLM_HIP_CHECK(hipFuncSetAttribute((const void *)gemm2_kernel<LAYOUT, BN, BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
   const int tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
   const size_t lds = (size_t)4 * kTile * sizeof(half_t);  // 128 KB (A 2 x 32 KB, B 2 x <= 32 KB)
-  hipLaunchKernelGGL((gemm2_kernel<LAYOUT, BN>), dim3(tiles), dim3(512), lds, stream, p);
+  hipLaunchKernelGGL((gemm2_kernel<LAYOUT, BN, BF16>), dim3(tiles), dim3(512), lds, stream, p);
   QLLM_HIP_CHECK(hipGetLastError());
   return QLLM_OK;
+}
+
+template <int LAYOUT, int BN>
+static int launch_gemm2_t(const GemmParams &p, hipStream_t stream) {
+  return p.act_bf16 ? launch_gemm2_b<LAYOUT, BN, true>(p, stream) : launch_gemm2_b<LAYOUT, BN, false>(p, stream);
 }
 
 int launch_gemm2(const GemmParams &p_in, int layout, hipStream_t stream) {

@@ -63,6 +63,7 @@ struct StripParams {
   int M, K, T;  // T = K / 32
   int nw;       // waves per block (8 or 16)
   int cpl;      // columns per lane: 1 (16-column strips) or 4 (64-column strips)
+  int bits;     // 4, or 3 (bit-stream layout; cpl = 1, fp16 or symmetric zeros)
   int spw;      // k-steps per wave (nw waves per block cover all of K)
   int group_size;
   int add_zero_bias;

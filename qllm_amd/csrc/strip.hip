@@ -42,8 +42,13 @@ typedef __attribute__((address_space(1))) const void gbl_cvoid_t;
 //   the rounding noise of W (measured <= 3e-4 relative, tests bound it at 2e-3 against float64 of the reference's W).
 // Everything is straight-line: loads are never predicated (addresses are clamped instead and the surplus is
 // cancelled by zero activations), so hipcc keeps all of a wave's loads in flight and waits with counted vmcnt.
-template <int NW, int CPL, int MAXS, int SPG, int XL>
+// BITS: 4, or 3 (bit-stream layout, 32 k = 3 words per column; CPL = 1 only).  For 3 bits the lane assembles its 24-bit
+//       field (8 values) from two words with v_alignbit, and the magic patterns put the fields at different bit offsets
+//       of the fp16 mantissa: slot scales (2,1 | 16,8 | 128,64 | 1,1) for k-slots (k0,k5 | k1,k6 | k2,k7 | k3,k4), undone by
+//       staging x divided by the same factors -- 9 VALU per 8 weights instead of 5.
+template <int NW, int CPL, int MAXS, int SPG, int XL, int BITS>
 __global__ __launch_bounds__(NW * 64) void strip_kernel(const StripParams p) {
+  static_assert(BITS == 4 || (BITS == 3 && CPL == 1), "3-bit strips are 16 columns wide");
   constexpr int NG = MAXS / SPG;   // groups per round (MAXS is a multiple of SPG; rounds start on a group boundary)
   constexpr int TN = 16 * CPL;     // columns per block
   constexpr int GL = 4 * SPG;      // lanes (16-byte chunks) per group in the staging pass: 8 or 16
@@ -111,18 +116,31 @@ __global__ __launch_bounds__(NW * 64) void strip_kernel(const StripParams p) {
   auto stage_x = [&]() {
 #pragma unroll
     for (int u = 0; u < XL; ++u) {
-      // fragment slot order (k0,k4 | k1,k5 | k2,k6 | k3,k7); the odd pairs meet B values scaled by 16 -> stage x/16
-      const half8_t pv = a_perm_04152637(xa[u]);
-      const half2_t p0 = {pv[0], pv[1]}, p1 = {pv[2], pv[3]}, p2 = {pv[4], pv[5]}, p3 = {pv[6], pv[7]};
-      const half2_t sixteenth = {(half_t)0.0625f, (half_t)0.0625f};
-      const half2_t q1 = p1 * sixteenth, q3 = p3 * sixteenth;
+      // fragment slot order and per-slot divisors (see the B-fragment construction below):
+      //   4 bits: (k0,k4 | k1,k5 | k2,k6 | k3,k7), divisors (1,1 | 16,16 | 1,1 | 16,16)
+      //   3 bits: (k0,k5 | k1,k6 | k2,k7 | k3,k4), divisors (2,1 | 16,8 | 128,64 | 1,1)
+      half2_t p0, p1, p2, p3, q0, q1, q2, q3;
+      if constexpr (BITS == 4) {
+        const half8_t pv = a_perm_04152637(xa[u]);
+        p0 = half2_t{pv[0], pv[1]}; p1 = half2_t{pv[2], pv[3]}; p2 = half2_t{pv[4], pv[5]}; p3 = half2_t{pv[6], pv[7]};
+        const half2_t sixteenth = {(half_t)0.0625f, (half_t)0.0625f};
+        q0 = p0; q1 = p1 * sixteenth; q2 = p2; q3 = p3 * sixteenth;
+      } else {
+        const half8_t pv = __builtin_shufflevector(xa[u], xa[u], 0, 5, 1, 6, 2, 7, 3, 4);
+        p0 = half2_t{pv[0], pv[1]}; p1 = half2_t{pv[2], pv[3]}; p2 = half2_t{pv[4], pv[5]}; p3 = half2_t{pv[6], pv[7]};
+        q0 = p0 * half2_t{(half_t)0.5f, (half_t)1.f};
+        q1 = p1 * half2_t{(half_t)0.0625f, (half_t)0.125f};
+        q2 = p2 * half2_t{(half_t)0.0078125f, (half_t)0.015625f};
+        q3 = p3;
+      }
       const half2_t one = {(half_t)1.f, (half_t)1.f};
       float sx = __builtin_amdgcn_fdot2(p0, one, 0.f, false);
-      sx = __builtin_amdgcn_fdot2(p2, one, sx, false);
-      float sxp = sx;  // the un-scaled slots count the same in both sums
       sx = __builtin_amdgcn_fdot2(p1, one, sx, false);
+      sx = __builtin_amdgcn_fdot2(p2, one, sx, false);
       sx = __builtin_amdgcn_fdot2(p3, one, sx, false);
+      float sxp = __builtin_amdgcn_fdot2(q0, one, 0.f, false);
       sxp = __builtin_amdgcn_fdot2(q1, one, sxp, false);
+      sxp = __builtin_amdgcn_fdot2(q2, one, sxp, false);
       sxp = __builtin_amdgcn_fdot2(q3, one, sxp, false);
 #pragma unroll
     for (int d = 1; d < GL; d <<= 1) {
@@ -130,7 +148,7 @@ __global__ __launch_bounds__(NW * 64) void strip_kernel(const StripParams p) {
         sxp += __shfl_xor(sxp, d);
       }
       if (xdst[u] >= 0) {
-        *(half8_t *)(xs + xdst[u]) = half8_t{p0.x, p0.y, q1.x, q1.y, p2.x, p2.y, q3.x, q3.y};
+        *(half8_t *)(xs + xdst[u]) = half8_t{q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, q3.x, q3.y};
         if ((lane & (GL - 1)) == 0) sxs[sdst[u]] = float2_t{sx, sxp};
       }
     }
@@ -142,7 +160,17 @@ __global__ __launch_bounds__(NW * 64) void strip_kernel(const StripParams p) {
   for (int c = 0; c < CPL; ++c) yacc[c] = float4_t{0.f, 0.f, 0.f, 0.f};
   const uint32_t mask_lo = nib_mask_vgpr();  // 0x000f000f
   const uint32_t mask_hi = mask_lo << 4;     // 0x00f000f0
+  // 3-bit field masks, derived from the opaque VGPR so hipcc can fuse each (x & m) | magic into one v_and_or_b32
+  const uint32_t m3a = ((mask_lo & 0x7u) << 1) | (mask_lo & 0x00070000u);                          // 0x0007000E
+  const uint32_t m3b = m3a << 3;                                                                 // 0x00380070
+  const uint32_t m3c = m3a << 6;                                                                 // 0x01C00380
+  const uint32_t m3d = mask_lo & 0x00000007u;                                                    // 0x00000007
+  const uint32_t m3e = mask_lo & 0x00070000u;                                                    // 0x00070000
   const uint32_t lane_off = (uint32_t)(g * N + n);  // word offset of this lane inside a 4-row group
+  // 3-bit: word rows {0,0,1,2}[g] / {0,1,2,2}[g] of the 3-row group, and the funnel shift {0,24,16,8}[g]
+  const uint32_t lane_off3_lo = (uint32_t)((g == 0 ? 0 : g - 1) * N + n);
+  const uint32_t lane_off3_hi = (uint32_t)((g == 3 ? 2 : g) * N + n);
+  const uint32_t shift3 = (uint32_t)((32 - 8 * g) & 31);
   const int Gmax = (p.K - 1) / p.group_size;
   const int tmax = p.T - 1;
   // zero points, branch-free addressing: packed -> word (G, n/8) (CPL | 8: one word holds the lane's columns);
@@ -177,10 +205,18 @@ __global__ __launch_bounds__(NW * 64) void strip_kernel(const StripParams p) {
     // ---- 3. every weight load of this round: exactly MAXS loads, rows clamped into the matrix;
     //         address = wave-uniform row base (SALU) + one per-lane 32-bit offset -------------------------------------
     wvec_t w[MAXS];
+    uint32_t w_hi[BITS == 3 ? MAXS : 1];
 #pragma unroll
     for (int s = 0; s < MAXS; ++s) {
-      const uint32_t *rowp = pr.qweight + (size_t)(4 * min(base + s, tmax)) * N;
-      w[s] = __builtin_nontemporal_load((const wvec_t *)(rowp + lane_off));
+      if constexpr (BITS == 4) {
+        const uint32_t *rowp = pr.qweight + (size_t)(4 * min(base + s, tmax)) * N;
+        w[s] = __builtin_nontemporal_load((const wvec_t *)(rowp + lane_off));
+      } else {
+        // 32 k = 3 words: lane group g needs stream bits [24g, 24g+24) = words {0,0,1,2}[g] and {0,1,2,2}[g]
+        const uint32_t *rowp = pr.qweight + (size_t)(3 * min(base + s, tmax)) * N;
+        w[s][0] = __builtin_nontemporal_load(rowp + lane_off3_lo);
+        w_hi[s] = __builtin_nontemporal_load(rowp + lane_off3_hi);
+      }
     }
 
     // ---- 4. first round: activations -> LDS (needs only the OLDEST loads; the weights stay in flight).  For many rows
@@ -196,9 +232,23 @@ __global__ __launch_bounds__(NW * 64) void strip_kernel(const StripParams p) {
       const half8_t av = *(const half8_t *)(xr + 32 * s);
 #pragma unroll
       for (int c = 0; c < CPL; ++c) {
-        const uint32_t wv = w[s][c], w8 = wv >> 8;
-        const half2_t b0 = as_h2((wv & mask_lo) | kMagic), b1 = as_h2((wv & mask_hi) | kMagic);
-        const half2_t b2 = as_h2((w8 & mask_lo) | kMagic), b3 = as_h2((w8 & mask_hi) | kMagic);
+        half2_t b0, b1, b2, b3;
+        if constexpr (BITS == 4) {
+          const uint32_t wv = w[s][c], w8 = wv >> 8;
+          b0 = as_h2((wv & mask_lo) | kMagic); b1 = as_h2((wv & mask_hi) | kMagic);
+          b2 = as_h2((w8 & mask_lo) | kMagic); b3 = as_h2((w8 & mask_hi) | kMagic);
+        } else {
+          // f: the lane's 8 three-bit values at bits 0,3,..,21.  f1 = f << 1 puts q5,q6,q7 at bits 16,19,22 (upper half,
+          // offsets 0,3,6) and q0,q1,q2 at bits 1,4,7 (lower half): three v_and_or give (2 q0, q5), (16 q1, 8 q6),
+          // (128 q2, 64 q7) on top of 1024; q3,q4 (bits 9,12) are moved to bit 0 / bit 16 separately.
+          const uint32_t f = __builtin_amdgcn_alignbit(w_hi[s], w[s][0], shift3);
+          const uint32_t f1 = f << 1;
+          b0 = as_h2((f1 & m3a) | kMagic);
+          b1 = as_h2((f1 & m3b) | kMagic);
+          b2 = as_h2((f1 & m3c) | kMagic);
+          const uint32_t lo34 = ((f >> 9) & m3d) | kMagic;
+          b3 = as_h2(((f << 4) & m3e) | lo34);
+        }
         const half8_t bf = {b0.x, b0.y, b1.x, b1.y, b2.x, b2.y, b3.x, b3.y};
         const float4_t cin = (s % SPG == 0) ? float4_t{0.f, 0.f, 0.f, 0.f} : gacc[c];
         gacc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bf, cin, 0, 0, 0);
@@ -216,7 +266,7 @@ __global__ __launch_bounds__(NW * 64) void strip_kernel(const StripParams p) {
           const uint32_t zd = (CPL >= 2) ? zraw[j][c >> 1] : zraw[j][0];
           const bool hi = (CPL >= 2) ? (c & 1) : (n & 1);
           const float zh = (float)__builtin_bit_cast(half_t, (uint16_t)(hi ? (zd >> 16) : (zd & 0xffffu)));
-          const float zfc = (zk == ZK_PACKED) ? zp : ((zk == ZK_F16) ? zh : 8.f);
+          const float zfc = (zk == ZK_PACKED) ? zp : ((zk == ZK_F16) ? zh : (float)(1 << (BITS - 1)));
           const float sfc = (float)sc[j][c];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
@@ -252,14 +302,14 @@ __global__ __launch_bounds__(NW * 64) void strip_kernel(const StripParams p) {
   }
 }
 
-template <int NW, int CPL, int MAXS, int SPG, int XL>
+template <int NW, int CPL, int MAXS, int SPG, int XL, int BITS = 4>
 static int launch_strip_t(const StripParams &p, int grid, size_t lds, hipStream_t stream) {
   static bool attr_done = false;
   if (!attr_done) {
-    QLLM_HIP_CHECK(hipFuncSetAttribute((const void *)strip_kernel<NW, CPL, MAXS, SPG, XL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    QLLM_HIP_CHECK(hipFuncSetAttribute((const void *)strip_kernel<NW, CPL, MAXS, SPG, XL, BITS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
-  hipLaunchKernelGGL((strip_kernel<NW, CPL, MAXS, SPG, XL>), dim3(grid), dim3(NW * 64), lds, stream, p);
+  hipLaunchKernelGGL((strip_kernel<NW, CPL, MAXS, SPG, XL, BITS>), dim3(grid), dim3(NW * 64), lds, stream, p);
   QLLM_HIP_CHECK(hipGetLastError());
   return QLLM_OK;
 }
@@ -273,6 +323,11 @@ static int strip_xl(int nw, int M, int spw, int cpl) { return (M * strip_spw_pad
 template <int SPG>
 static int launch_strip_s(const StripParams &p, int grid, size_t lds, hipStream_t stream) {
   const bool small_x = strip_xl(p.nw, p.M, p.spw, p.cpl) <= 2;
+  if (p.bits == 3) {  // 16-column strips, 16 waves
+    if (strip_maxs(16, p.spw, 1) == 8)
+      return small_x ? launch_strip_t<16, 1, 8, SPG, 2, 3>(p, grid, lds, stream) : launch_strip_t<16, 1, 8, SPG, 8, 3>(p, grid, lds, stream);
+    return small_x ? launch_strip_t<16, 1, 24, SPG, 2, 3>(p, grid, lds, stream) : launch_strip_t<16, 1, 24, SPG, 8, 3>(p, grid, lds, stream);
+  }
   if (p.cpl == 4 && p.nw == 8)  // 64-column strips, 8-wave blocks (two co-resident per CU), rounds of 8 k-steps
     return small_x ? launch_strip_t<8, 4, 8, SPG, 2>(p, grid, lds, stream) : launch_strip_t<8, 4, 8, SPG, 8>(p, grid, lds, stream);
   if (p.cpl == 4)  // 64-column strips: 16 waves, rounds of 8 k-steps

@@ -236,6 +236,31 @@ def test_act_order_nonuniform_groups_use_inplace_gather():
         assert O.rel_err(y, ref.y16(x)) <= TOL
 
 
+@pytest.mark.parametrize("layout,g,K,N,zk", [("HQQ", 64, 4096, 4096, "f16"), ("HQQ", 128, 11008, 4096, "f16"),
+                                             ("GPTQ", 128, 4096, 4096, "sym")])
+def test_three_bit_decode_kernel(layout, g, K, N, zk):
+    """3-bit bit-stream weights through the fused strip kernel (BASELINE configs[3]: HQQ mixed 3/4-bit layers)."""
+    d = synth(layout, 3, g, K, N, zk, False, layout == "GPTQ", seed=K + N + 3)
+    if layout == "GPTQ":
+        d["qzeros"] = None  # symmetric: zero point 2^(bits-1), no qzeros buffer at the C boundary
+    ref = Ref(dict(d, qzeros=O.pack_along_cols(np.full((K // g, N), 4, np.int32), 3)) if layout == "GPTQ" else d)
+    layer = to_layer(d, DEV) if layout != "GPTQ" else None
+    from qllm_amd import ops
+    for m in (1, 5, 16):
+        x = randx(m, K, seed=m)
+        xt = torch.from_numpy(x).to(DEV)
+        if layout == "GPTQ":
+            qw = torch.from_numpy(d["qweight"]).to(DEV)
+            sc = torch.from_numpy(d["scales"]).to(DEV)
+            b = torch.from_numpy(d["bias"]).to(DEV)
+            w, keep = ops.make_weight("GPTQ", qw, sc, None, None, b, K, N, g, 3, 0)
+            y = ops.linear_forward(w, xt).cpu().numpy()
+        else:
+            y = layer(xt).cpu().numpy()
+        assert O.rel_err(y, ref.y16(x)) <= TOL, (layout, m)
+        assert O.rel_err(y, ref.y64(x)) <= 2e-3, (layout, m)
+
+
 def test_odd_bits_route_through_dequant_kernel():
     for layout, bits, g in (("HQQ", 3, 64), ("GPTQ", 3, 128), ("GPTQ", 8, 128), ("HQQ", 2, 64)):
         d = synth(layout, bits, g, 4096, 1024, seed=bits)
