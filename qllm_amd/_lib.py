@@ -11,7 +11,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libqllm_mi355x.so"
-LIB_PATH = os.path.join(_HERE, LIB_NAME)
+LIB_PATH = os.environ.get("QLLM_MI355X_LIB") or os.path.join(_HERE, LIB_NAME)  # override: A/B-testing kernel builds
 
 QLLM_OK, QLLM_ERR_INVALID, QLLM_ERR_UNSUPPORTED, QLLM_ERR_WORKSPACE, QLLM_ERR_LAUNCH, QLLM_ERR_DEVICE = range(6)
 LAYOUT_GPTQ, LAYOUT_AWQ_GEMM, LAYOUT_HQQ = 0, 1, 2

@@ -21,7 +21,7 @@ namespace qllm {
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int kTileHalves = 128 * BK;  // one A or B tile, in halves (16 KB)
 
-__device__ __forceinline__ int swz(int row, int slot) { return slot ^ ((row ^ (row >> 3)) & 7); }
+__device__ __forceinline__ int swz(int row, int slot) { return slot ^ lds_row_swizzle(row); }
 
 // byte offset of 16-byte slot `slot` (8 halves of k) of row/column `row` inside a [128][64]-half tile
 __device__ __forceinline__ int tile_off(int row, int slot) { return row * BK + swz(row, slot) * 8; }

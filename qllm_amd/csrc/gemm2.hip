@@ -29,7 +29,7 @@ constexpr int kTile = 256 * BK;  // halves per A tile (32 KB); the B tile uses B
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_cvoid_t;
 
-__device__ __forceinline__ int swz(int row, int slot) { return slot ^ ((row ^ (row >> 3)) & 7); }
+__device__ __forceinline__ int swz(int row, int slot) { return slot ^ lds_row_swizzle(row); }
 __device__ __forceinline__ int tile_off(int row, int slot) { return row * BK + swz(row, slot) * 8; }  // in halves
 
 __device__ __forceinline__ half_t zero_gptq(const GemmParams &p, int G, int n) {
@@ -91,10 +91,10 @@ __global__ __launch_bounds__(512) void gemm2_kernel(const GemmParams p) {
       areg[q] = *(const uint4_t *)((const half_t *)p.x + (size_t)grow * p.K + ktc * BK + 8 * kc);
     }
   };
-  auto store_a = [&](int buf, const uint4_t (&areg)[4]) {
+  auto store_a = [&](int buf, const uint4_t (&areg)[4], int q0 = 0, int q1 = 4) {
     half_t *Ab = As + buf * kTile;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = q0; q < q1; ++q) {
       const int c = tid + 512 * q, row = c >> 3, kc = c & 7;
       if constexpr (BF16)  // bf16 activations are converted to fp16 (RNE) on their way into LDS
         *(half8_t *)(Ab + tile_off(row, kc)) = bf16x8_to_h8(areg[q]);
@@ -226,20 +226,91 @@ __global__ __launch_bounds__(512) void gemm2_kernel(const GemmParams p) {
       mfma_sub(Ab, Bb, 0);
       mfma_sub(Ab, Bb, 1);
     } else {
-      mfma_sub(Ab, Bb, 0);
-      store_b(kt + 1, buf ^ 1, 0, b_next);
-      mfma_sub(Ab, Bb, 1);
-      store_b(kt + 1, buf ^ 1, 1, b_next);
-      store_a(buf ^ 1, a_next);
+      // Order of the LDS stores relative to the two MFMA sub-steps is a COMPILE-TIME choice: a runtime switch between
+      // the two orders cost 2.7x (826 -> 305 TFLOP/s, branch joins collapse the counted waits).  Measured at M=2048:
+      // AWQ-layout tiles gain 3-5% with both sub-steps first, GPTQ tiles lose 3-5%.
+      if constexpr (LAYOUT == QLLM_LAYOUT_AWQ_GEMM) {
+        mfma_sub(Ab, Bb, 0);
+        mfma_sub(Ab, Bb, 1);
+        store_b(kt + 1, buf ^ 1, 0, b_next);
+        store_b(kt + 1, buf ^ 1, 1, b_next);
+        store_a(buf ^ 1, a_next);
+      } else {
+        mfma_sub(Ab, Bb, 0);
+        store_b(kt + 1, buf ^ 1, 0, b_next);
+        mfma_sub(Ab, Bb, 1);
+        store_b(kt + 1, buf ^ 1, 1, b_next);
+        store_a(buf ^ 1, a_next);
+      }
     }
     __syncthreads();
   };
   using TagF = std::integral_constant<bool, false>;
   // (Tried twice: running waves 4-7 with EARLY = true so that the two waves of every SIMD alternate VALU and MFMA phases --
   //  771 vs 808 TFLOP/s, and the second body costs 17-35 VGPRs; the instantiation is left out.)
-  for (int kt = 0; kt < KT; kt += 2) {
-    k_tile(kt, bset[1], bset[0], aset[ASETS - 1], aset[0], TagF{});
-    if (kt + 1 < KT) k_tile(kt + 1, bset[0], bset[1], aset[0], aset[ASETS - 1], TagF{});
+  if constexpr (BN == 128) {
+    // Fragment-pipelined body.  The plain body above starts every k-tile with "barrier -> 8 ds_read_b128 -> wait -> MFMA":
+    // all 8 waves sit out the LDS round trip together, then the stores, then the barrier -- the MFMA pipe idles 2/3 of
+    // the time.  Here the fragments of sub-step 1 are read BEFORE sub-step 0's MFMAs and those of the next tile's
+    // sub-step 0 right after the barrier, before sub-step 1's MFMAs: every LDS read has 16 MFMAs (>= 256 cycles) of
+    // cover, and the dequant + LDS stores of tile kt+1 are cut in four pieces placed between the 4-MFMA rows of sub-step 0.
+    half8_t fa0[AM], fb0[4], fa1[AM], fb1[4];
+    auto read_frags = [&](int buf, int ks, half8_t (&fa)[AM], half8_t (&fb)[4]) {
+      const half_t *Ab = As + buf * kTile, *Bb = Bs + buf * kTile;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) fb[b] = *(const half8_t *)(Bb + tile_off(wn * 64 + b * 16 + i, ks * 4 + g));
+#pragma unroll
+      for (int a = 0; a < AM; ++a) fa[a] = *(const half8_t *)(Ab + tile_off(wm * WROWS + a * 16 + i, ks * 4 + g));
+    };
+    auto mfma_rows = [&](const half8_t (&fa)[AM], const half8_t (&fb)[4], int a0, int a1) {
+#pragma unroll
+      for (int a = a0; a < a1; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+    };
+    // Measured at M=2048 (TFLOP/s, 4096x4096 / 4096x11008 / 11008x4096; plain body = 835/849/949 GPTQ, 794/795/881 AWQ):
+    // GPTQ tiles are best with hipcc free to interleave the pieces (870/881/976; pinned 826/838/926); AWQ tiles, whose
+    // dequant is 8 scalar columns per word, with the pieces pinned by sched_barriers (801/814/876; free 784/795/869).
+#define G2_SB()                                                                          \
+  do {                                                                                   \
+    if constexpr (LAYOUT == QLLM_LAYOUT_AWQ_GEMM) __builtin_amdgcn_sched_barrier(0);     \
+  } while (0)
+    auto k_tile_p = [&](int kt, BSet &b_next, BSet &b_free, uint4_t (&a_next)[4], uint4_t (&a_free)[4]) {
+      const int buf = kt & 1;
+      read_frags(buf, 1, fa1, fb1);
+      load_a(kt + ASETS, a_free);
+      load_b(kt + 2, b_free);
+      G2_SB();
+      mfma_rows(fa0, fb0, 0, 1);
+      store_b(kt + 1, buf ^ 1, 0, b_next);
+      G2_SB();
+      mfma_rows(fa0, fb0, 1, 2);
+      store_b(kt + 1, buf ^ 1, 1, b_next);
+      G2_SB();
+      mfma_rows(fa0, fb0, 2, 3);
+      store_a(buf ^ 1, a_next, 0, 2);
+      G2_SB();
+      mfma_rows(fa0, fb0, 3, 4);
+      store_a(buf ^ 1, a_next, 2, 4);
+      G2_SB();
+      __syncthreads();
+      read_frags(buf ^ 1, 0, fa0, fb0);  // past the last tile: reads a buffer nobody uses
+      G2_SB();
+      mfma_rows(fa1, fb1, 0, AM);
+      G2_SB();
+    };
+#undef G2_SB
+    read_frags(0, 0, fa0, fb0);
+    for (int kt = 0; kt < KT; kt += 2) {
+      k_tile_p(kt, bset[1], bset[0], aset[ASETS - 1], aset[0]);
+      if (kt + 1 < KT) k_tile_p(kt + 1, bset[0], bset[1], aset[0], aset[ASETS - 1]);
+    }
+    __syncthreads();  // the epilogue reuses the tile buffers: the stray fragment reads above must have landed
+  } else {
+    for (int kt = 0; kt < KT; kt += 2) {
+      k_tile(kt, bset[1], bset[0], aset[ASETS - 1], aset[0], TagF{});
+      if (kt + 1 < KT) k_tile(kt + 1, bset[0], bset[1], aset[0], aset[ASETS - 1], TagF{});
+    }
   }
 
   // ---- epilogue: + bias, round once, transpose through wave-private LDS, 16-byte row-contiguous stores ---------------
