@@ -88,7 +88,7 @@ static int strip_min_strips() {
 }
 // full-K strip kernel: row-stream layouts, M <= 16, enough 16-column strips to cover the 256 CUs
 struct StripPlan {
-  int cpl, nw, spw;
+  int cpl, nw, spw, ra;
 };
 static bool strip_plan(const qllm_weight_t *w, int n, int M, StripPlan *plan) {
   if (M > 16 || strip_min_strips() <= 0) return false;
@@ -111,6 +111,12 @@ static bool strip_plan(const qllm_weight_t *w, int n, int M, StripPlan *plan) {
   }
   static int force_cpl = env_int("QLLM_STRIP_CPL", 0);
   static int nw4 = env_int("QLLM_STRIP_NW4", 0);
+  // rows from which the activation slab in LDS (staged once per block: M*K/8 chunk operations) loses to per-lane
+  // fragment loads + two bookkeeping MFMAs per k-step (strip.hip, RA)
+  // measured (graph replay, us; slab -> RA): 4096x4096 M=4 5.3 -> 6.2, M=8 9.6 -> 7.1, M=16 9.9 -> 8.5; 4096x11008 M=4 9.8 -> 9.3,
+  // M=8 10.0 -> 9.7, M=16 25.7 -> 11.9; 11008x4096 M=4 13.6 -> 13.0, M=8 20.2 -> 14.6, M=16 26.4 (split-K fallback) -> 18.9
+  static int ra_min = env_int("QLLM_STRIP_RA_MIN", 5);
+  const int ra = (M >= ra_min) ? 1 : 0;
   int first = bits == 3 ? 1 : strip_cpl(cols, m64, m32);
   if (force_cpl == 4 && m64 && bits == 4) first = 4;
   if (force_cpl == 2 && m32 && bits == 4) first = 2;
@@ -128,10 +134,11 @@ static bool strip_plan(const qllm_weight_t *w, int n, int M, StripPlan *plan) {
     int nw = cpl == 4 ? (nw4 ? nw4 : 8) : ((cpl == 2 || bits == 3) ? 16 : strip_nw(w[0].K, strips));
     for (int tries = 0; tries < 2; ++tries) {
       const int spw = strip_spw(w[0].K, w[0].group_size, nw);
-      if (strip_x_ok(M, spw, nw, cpl) && strip_lds_bytes(M, spw, nw, cpl, w[0].group_size) <= 156 * 1024) {
+      if ((ra || strip_x_ok(M, spw, nw, cpl)) && strip_lds_bytes(M, spw, nw, cpl, w[0].group_size, ra) <= 156 * 1024) {
         plan->cpl = cpl;
         plan->nw = nw;
         plan->spw = spw;
+        plan->ra = ra;
         return true;
       }
       if (nw == 16) break;
@@ -159,6 +166,7 @@ static int run_strip(const qllm_weight_t *w, void *const *y, int n, const void *
   p.bits = w[0].bits;
   p.nw = pl.nw;
   p.spw = pl.spw;
+  p.ra = pl.ra;
   p.group_size = w[0].group_size;
   p.add_zero_bias = w[0].add_zero_bias;
   p.act_bf16 = (act_dtype == QLLM_BF16);

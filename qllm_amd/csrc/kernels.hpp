@@ -65,6 +65,7 @@ struct StripParams {
   int cpl;      // columns per lane: 1 (16-column strips) or 4 (64-column strips)
   int bits;     // 4, or 3 (bit-stream layout; cpl = 1, fp16 or symmetric zeros)
   int spw;      // k-steps per wave (nw waves per block cover all of K)
+  int ra;       // 1: "register A" variant (no activation slab in LDS; Sx / Sx' from two extra MFMAs), used for M > 2
   int group_size;
   int add_zero_bias;
   int act_bf16;
@@ -72,7 +73,7 @@ struct StripParams {
 bool strip_group_ok(int group_size);
 int strip_nw(int K, int strips_total);
 int strip_spw(int K, int group_size, int nw);
-size_t strip_lds_bytes(int M, int spw, int nw, int cpl, int group_size);
+size_t strip_lds_bytes(int M, int spw, int nw, int cpl, int group_size, int ra);
 int strip_cpl(int cols_total, bool all_mult64, bool all_mult32);
 bool strip_x_ok(int M, int spw, int nw, int cpl);
 int launch_strip(const StripParams &p, int grid, hipStream_t stream);

@@ -25,6 +25,12 @@ namespace qllm {
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_cvoid_t;
 
+// v + (v from the lane selected by the DPP control): folds into one v_add_f32_dpp
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
 // NW: waves per block; CPL: columns per lane (1 -> 16-column strip, 64-byte row segments; 4 -> 64-column strip,
 // 256-byte row segments, 4 MFMAs per k-step); MAXS: k-steps (weight loads) per lane per round; SPG: k-steps per
 // quantisation group (group_size / 32); XL: 16-byte activation chunks staged per lane.
@@ -46,9 +52,18 @@ typedef __attribute__((address_space(1))) const void gbl_cvoid_t;
 //       field (8 values) from two words with v_alignbit, and the magic patterns put the fields at different bit offsets
 //       of the fp16 mantissa: slot scales (2,1 | 16,8 | 128,64 | 1,1) for k-slots (k0,k5 | k1,k6 | k2,k7 | k3,k4), undone by
 //       staging x divided by the same factors -- 9 VALU per 8 weights instead of 5.
-template <int NW, int CPL, int MAXS, int SPG, int XL, int BITS>
+// RA ("register A", used for M > 2): no activation slab in LDS at all.  Staging costs M*K/8 chunk operations per BLOCK
+//       (permute, Sx/Sx' dot products, LDS write) -- at M = 16 four times the main loop's work, repeated by every strip --
+//       and the [M][K] slab (128 KB at M=16, K=4096) limits a CU to one block and K to ~5000.  Instead every lane loads
+//       its own A fragment (16 B of row i, k-slots 8g..8g+7) straight from L2 for each k-step, permutes/scales it in
+//       registers (4 v_perm + 4 v_pk_mul), and Sx / Sx' come out of the matrix core in exactly the accumulator layout
+//       the correction needs: two more MFMAs per k-step against constant B fragments (all ones -> Sx' = sum of the
+//       staged values; the per-slot multipliers -> Sx).  Rounds are 8 k-steps (8 x 16 B of x + 8 weight loads in flight
+//       per lane); LDS holds only the cross-wave reduction buffer.
+template <int NW, int CPL, int MAXS, int SPG, int XL, int BITS, bool RA = false, bool RA_BF16 = false>
 __global__ __launch_bounds__(NW * 64) void strip_kernel(const StripParams p) {
   static_assert(BITS == 4 || (BITS == 3 && CPL == 1), "3-bit strips are 16 columns wide");
+  static_assert(!RA || MAXS == 8, "register-A rounds are 8 k-steps");
   constexpr int NG = MAXS / SPG;   // groups per round (MAXS is a multiple of SPG; rounds start on a group boundary)
   constexpr int TN = 16 * CPL;     // columns per block
   constexpr int GL = 4 * SPG;      // lanes (16-byte chunks) per group in the staging pass: 8 or 16
@@ -142,18 +157,20 @@ __global__ __launch_bounds__(NW * 64) void strip_kernel(const StripParams p) {
       sxp = __builtin_amdgcn_fdot2(q1, one, sxp, false);
       sxp = __builtin_amdgcn_fdot2(q2, one, sxp, false);
       sxp = __builtin_amdgcn_fdot2(q3, one, sxp, false);
-#pragma unroll
-    for (int d = 1; d < GL; d <<= 1) {
-        sx += __shfl_xor(sx, d);
-        sxp += __shfl_xor(sxp, d);
-      }
+      // sum over the GL (8 or 16) lanes of the group with DPP adds: xor 1, xor 2 (quad_perm), then row_half_mirror and
+      // row_mirror (reversals are as good as xor once the quads are uniform) -- one VALU op per step instead of
+      // __shfl_xor's address VALU + ds_bpermute round trip (16 LDS ops per chunk at g128)
+      sx = dpp_add<0xB1>(sx); sxp = dpp_add<0xB1>(sxp);
+      sx = dpp_add<0x4E>(sx); sxp = dpp_add<0x4E>(sxp);
+      sx = dpp_add<0x141>(sx); sxp = dpp_add<0x141>(sxp);
+      if constexpr (GL == 16) { sx = dpp_add<0x140>(sx); sxp = dpp_add<0x140>(sxp); }
       if (xdst[u] >= 0) {
         *(half8_t *)(xs + xdst[u]) = half8_t{q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, q3.x, q3.y};
         if ((lane & (GL - 1)) == 0) sxs[sdst[u]] = float2_t{sx, sxp};
       }
     }
   };
-  if (XL > 2) stage_x();
+  if (!RA && XL > 2) stage_x();
 
   float4_t yacc[CPL];
 #pragma unroll
@@ -180,6 +197,13 @@ __global__ __launch_bounds__(NW * 64) void strip_kernel(const StripParams p) {
   const int zmul = (zk == ZK_PACKED) ? (N >> 3) : (N >> 1);
   const int zoff = (zk == ZK_PACKED) ? (n >> 3) : (n >> 1);
   const int zoff2 = (zk == ZK_F16 && CPL == 4) ? 1 : 0;
+  // RA: this lane's activation row (MFMA row i; rows >= M re-read row M-1, their outputs are never stored), k-slot 8g
+  const uint16_t *xrow_ra = (const uint16_t *)p.x + (size_t)min(i, M - 1) * p.K + 8 * g;
+  // constant B fragments: all ones, and the per-slot multipliers that undo the staged divisors (4 bits: x16 on the odd
+  // pairs; 3 bits: 2,1 | 16,8 | 128,64 | 1,1)
+  const half8_t b_ones = {(half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f};
+  const half8_t b_mult = (BITS == 4) ? half8_t{(half_t)1.f, (half_t)1.f, (half_t)16.f, (half_t)16.f, (half_t)1.f, (half_t)1.f, (half_t)16.f, (half_t)16.f}
+                                     : half8_t{(half_t)2.f, (half_t)1.f, (half_t)16.f, (half_t)8.f, (half_t)128.f, (half_t)64.f, (half_t)1.f, (half_t)1.f};
 
   for (int r = 0; r < rounds; ++r) {
     const int base = t0 + r * MAXS;
@@ -202,6 +226,12 @@ __global__ __launch_bounds__(NW * 64) void strip_kernel(const StripParams p) {
       zraw[j][0] = zbase[(size_t)G * zmul + zoff];
       zraw[j][1] = (CPL == 4) ? zbase[(size_t)G * zmul + zoff + zoff2] : 0u;
     }
+    // ---- 2b. RA: this round's activation fragments, raw (16 B per k-step; L2-resident, so they land before the weights)
+    uint4_t xq[RA ? MAXS : 1];
+    if constexpr (RA) {
+#pragma unroll
+      for (int s = 0; s < MAXS; ++s) xq[s] = *(const uint4_t *)(xrow_ra + 32 * min(base + s, tmax));
+    }
     // ---- 3. every weight load of this round: exactly MAXS loads, rows clamped into the matrix;
     //         address = wave-uniform row base (SALU) + one per-lane 32-bit offset -------------------------------------
     wvec_t w[MAXS];
@@ -219,17 +249,48 @@ __global__ __launch_bounds__(NW * 64) void strip_kernel(const StripParams p) {
       }
     }
 
+    // RA: pin the issue order -- without this hipcc sinks half of the activation loads below the first MFMAs and waits
+    // for them with vmcnt(0)
+    if constexpr (RA) __builtin_amdgcn_sched_barrier(0);
+
     // ---- 4. first round: activations -> LDS (needs only the OLDEST loads; the weights stay in flight).  For many rows
     //         (XL > 2) the chunk was staged before the weight loads instead, to keep its registers out of this region.
-    if (XL <= 2 && r == 0) stage_x();
+    if (!RA && XL <= 2 && r == 0) stage_x();
 
     // ---- 5. straight-line: raw-magic B fragments -> MFMA; one fp32 correction per group ----------------------------------
     const half_t *xr = xlane + 32 * (r * MAXS);
     const float2_t *sxr = sxs + (size_t)(r * NG) * 16 + 4 * g;  // (Sx, Sx') of rows 4g..4g+3
     float4_t gacc[CPL];
+    float4_t g_ones = {0.f, 0.f, 0.f, 0.f}, g_sx = {0.f, 0.f, 0.f, 0.f};  // RA: 1024-offset sum and plain sum of x, per group
 #pragma unroll
     for (int s = 0; s < MAXS; ++s) {
-      const half8_t av = *(const half8_t *)(xr + 32 * s);
+      half8_t av;
+      if constexpr (RA) {
+        // k-steps past this wave's chunk (padding of the last round) or past K contribute nothing: zero multipliers
+        const bool valid = (r * MAXS + s < p.spw) && (base + s <= tmax);
+        const half_t one = valid ? (half_t)1.f : (half_t)0.f;
+        half8_t xv;  // bf16 activations: compile-time variant (a runtime branch per k-step would split the straight-line body)
+        if constexpr (RA_BF16) xv = bf16x8_to_h8(xq[s]); else xv = __builtin_bit_cast(half8_t, xq[s]);
+        if constexpr (BITS == 4) {
+          const half8_t pv = a_perm_04152637(xv);
+          const half_t sixteenth = valid ? (half_t)0.0625f : (half_t)0.f;
+          const half2_t q0 = half2_t{pv[0], pv[1]} * half2_t{one, one}, q1 = half2_t{pv[2], pv[3]} * half2_t{sixteenth, sixteenth};
+          const half2_t q2 = half2_t{pv[4], pv[5]} * half2_t{one, one}, q3 = half2_t{pv[6], pv[7]} * half2_t{sixteenth, sixteenth};
+          av = half8_t{q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, q3.x, q3.y};
+        } else {
+          const half8_t pv = __builtin_shufflevector(xv, xv, 0, 5, 1, 6, 2, 7, 3, 4);
+          const half2_t q0 = half2_t{pv[0], pv[1]} * (half2_t{(half_t)0.5f, (half_t)1.f} * half2_t{one, one});
+          const half2_t q1 = half2_t{pv[2], pv[3]} * (half2_t{(half_t)0.0625f, (half_t)0.125f} * half2_t{one, one});
+          const half2_t q2 = half2_t{pv[4], pv[5]} * (half2_t{(half_t)0.0078125f, (half_t)0.015625f} * half2_t{one, one});
+          const half2_t q3 = half2_t{pv[6], pv[7]} * half2_t{one, one};
+          av = half8_t{q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, q3.x, q3.y};
+        }
+        const float4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+        g_ones = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, b_ones, (s % SPG == 0) ? zero4 : g_ones, 0, 0, 0);
+        g_sx = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, b_mult, (s % SPG == 0) ? zero4 : g_sx, 0, 0, 0);
+      } else {
+        av = *(const half8_t *)(xr + 32 * s);
+      }
 #pragma unroll
       for (int c = 0; c < CPL; ++c) {
         half2_t b0, b1, b2, b3;
@@ -255,10 +316,16 @@ __global__ __launch_bounds__(NW * 64) void strip_kernel(const StripParams p) {
       }
       if (s % SPG == SPG - 1) {
         const int j = s / SPG;
-        const float4_t s01 = *(const float4_t *)(sxr + j * 16);      // (Sx,Sx') rows 4g, 4g+1
-        const float4_t s23 = *(const float4_t *)(sxr + j * 16 + 2);  // rows 4g+2, 4g+3
-        const float sxv[4] = {s01[0], s01[2], s23[0], s23[2]};
-        const float big[4] = {1024.f * s01[1], 1024.f * s01[3], 1024.f * s23[1], 1024.f * s23[3]};
+        float sxv[4], big[4];
+        if constexpr (RA) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { sxv[q] = g_sx[q]; big[q] = 1024.f * g_ones[q]; }
+        } else {
+          const float4_t s01 = *(const float4_t *)(sxr + j * 16);      // (Sx,Sx') rows 4g, 4g+1
+          const float4_t s23 = *(const float4_t *)(sxr + j * 16 + 2);  // rows 4g+2, 4g+3
+          sxv[0] = s01[0]; sxv[1] = s01[2]; sxv[2] = s23[0]; sxv[3] = s23[2];
+          big[0] = 1024.f * s01[1]; big[1] = 1024.f * s01[3]; big[2] = 1024.f * s23[1]; big[3] = 1024.f * s23[3];
+        }
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
           // this group's scale / zero of column n+c, converted to fp32 here (keeps the raw 16/32-bit words live instead)
@@ -302,29 +369,42 @@ __global__ __launch_bounds__(NW * 64) void strip_kernel(const StripParams p) {
   }
 }
 
-template <int NW, int CPL, int MAXS, int SPG, int XL, int BITS = 4>
+template <int NW, int CPL, int MAXS, int SPG, int XL, int BITS = 4, bool RA = false, bool RA_BF16 = false>
 static int launch_strip_t(const StripParams &p, int grid, size_t lds, hipStream_t stream) {
   static bool attr_done = false;
   if (!attr_done) {
-    QLLM_HIP_CHECK(hipFuncSetAttribute((const void *)strip_kernel<NW, CPL, MAXS, SPG, XL, BITS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    QLLM_HIP_CHECK(hipFuncSetAttribute((const void *)strip_kernel<NW, CPL, MAXS, SPG, XL, BITS, RA, RA_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
-  hipLaunchKernelGGL((strip_kernel<NW, CPL, MAXS, SPG, XL, BITS>), dim3(grid), dim3(NW * 64), lds, stream, p);
+  hipLaunchKernelGGL((strip_kernel<NW, CPL, MAXS, SPG, XL, BITS, RA, RA_BF16>), dim3(grid), dim3(NW * 64), lds, stream, p);
   QLLM_HIP_CHECK(hipGetLastError());
   return QLLM_OK;
 }
 
 // (waves per block, weight loads per lane per round): 16 waves x 8 or 24, or 8 waves x 16
-// (64-column strips always use rounds of 8: 4 dwords per load keep the register budget of a 1024-thread block)
-static int strip_maxs(int nw, int spw, int cpl) { return cpl >= 2 ? 8 : (nw == 8 ? 16 : (spw <= 8 ? 8 : 24)); }
-static int strip_spw_pad(int nw, int spw, int cpl) { const int m = strip_maxs(nw, spw, cpl); return (spw + m - 1) / m * m; }
-static int strip_xl(int nw, int M, int spw, int cpl) { return (M * strip_spw_pad(nw, spw, cpl) * 4 + 63) / 64; }
+// (64-column strips always use rounds of 8: 4 dwords per load keep the register budget of a 1024-thread block;
+//  register-A launches always use rounds of 8: each k-step also holds 16 B of activations per lane)
+static int strip_maxs(int nw, int spw, int cpl, int ra) { return (ra || cpl >= 2) ? 8 : (nw == 8 ? 16 : (spw <= 8 ? 8 : 24)); }
+static int strip_spw_pad(int nw, int spw, int cpl, int ra) { const int m = strip_maxs(nw, spw, cpl, ra); return (spw + m - 1) / m * m; }
+static int strip_xl(int nw, int M, int spw, int cpl) { return (M * strip_spw_pad(nw, spw, cpl, 0) * 4 + 63) / 64; }
+
+template <int SPG, bool BF>
+static int launch_strip_ra(const StripParams &p, int grid, size_t lds, hipStream_t stream) {
+  if (p.bits == 3) return launch_strip_t<16, 1, 8, SPG, 1, 3, true, BF>(p, grid, lds, stream);
+  if (p.cpl == 4)
+    return p.nw == 8 ? launch_strip_t<8, 4, 8, SPG, 1, 4, true, BF>(p, grid, lds, stream)
+                     : launch_strip_t<16, 4, 8, SPG, 1, 4, true, BF>(p, grid, lds, stream);
+  if (p.cpl == 2) return launch_strip_t<16, 2, 8, SPG, 1, 4, true, BF>(p, grid, lds, stream);
+  return p.nw == 8 ? launch_strip_t<8, 1, 8, SPG, 1, 4, true, BF>(p, grid, lds, stream)
+                   : launch_strip_t<16, 1, 8, SPG, 1, 4, true, BF>(p, grid, lds, stream);
+}
 
 template <int SPG>
 static int launch_strip_s(const StripParams &p, int grid, size_t lds, hipStream_t stream) {
+  if (p.ra) return p.act_bf16 ? launch_strip_ra<SPG, true>(p, grid, lds, stream) : launch_strip_ra<SPG, false>(p, grid, lds, stream);
   const bool small_x = strip_xl(p.nw, p.M, p.spw, p.cpl) <= 2;
   if (p.bits == 3) {  // 16-column strips, 16 waves
-    if (strip_maxs(16, p.spw, 1) == 8)
+    if (strip_maxs(16, p.spw, 1, 0) == 8)
       return small_x ? launch_strip_t<16, 1, 8, SPG, 2, 3>(p, grid, lds, stream) : launch_strip_t<16, 1, 8, SPG, 8, 3>(p, grid, lds, stream);
     return small_x ? launch_strip_t<16, 1, 24, SPG, 2, 3>(p, grid, lds, stream) : launch_strip_t<16, 1, 24, SPG, 8, 3>(p, grid, lds, stream);
   }
@@ -336,7 +416,7 @@ static int launch_strip_s(const StripParams &p, int grid, size_t lds, hipStream_
     return small_x ? launch_strip_t<16, 2, 8, SPG, 2>(p, grid, lds, stream) : launch_strip_t<16, 2, 8, SPG, 8>(p, grid, lds, stream);
   if (p.nw == 8)
     return small_x ? launch_strip_t<8, 1, 16, SPG, 2>(p, grid, lds, stream) : launch_strip_t<8, 1, 16, SPG, 8>(p, grid, lds, stream);
-  if (strip_maxs(16, p.spw, 1) == 8)
+  if (strip_maxs(16, p.spw, 1, 0) == 8)
     return small_x ? launch_strip_t<16, 1, 8, SPG, 2>(p, grid, lds, stream) : launch_strip_t<16, 1, 8, SPG, 8>(p, grid, lds, stream);
   return small_x ? launch_strip_t<16, 1, 24, SPG, 2>(p, grid, lds, stream) : launch_strip_t<16, 1, 24, SPG, 8>(p, grid, lds, stream);
 }
@@ -355,10 +435,12 @@ int strip_spw(int K, int group_size, int nw) {
   return (spw + spg - 1) / spg * spg;
 }
 
-size_t strip_lds_bytes(int M, int spw, int nw, int cpl, int group_size) {
-  const int pad = strip_spw_pad(nw, spw, cpl);
+size_t strip_lds_bytes(int M, int spw, int nw, int cpl, int group_size, int ra) {
+  const size_t red = (size_t)nw * M * 16 * cpl * sizeof(float);
+  if (ra) return red;  // register-A: only the cross-wave reduction buffer
+  const int pad = strip_spw_pad(nw, spw, cpl, 0);
   const int groups = pad / (group_size / 32);  // groups per wave chunk
-  return (size_t)nw * M * 16 * cpl * sizeof(float) + (size_t)nw * M * (pad * 32 + 8) * sizeof(half_t) +
+  return red + (size_t)nw * M * (pad * 32 + 8) * sizeof(half_t) +
          (size_t)nw * groups * 16 * 8;  // (Sx, Sx') float2 per (group, row), 16 rows per group
 }
 
@@ -375,7 +457,7 @@ int strip_cpl(int cols_total, bool all_mult64, bool all_mult32) {
 bool strip_x_ok(int M, int spw, int nw, int cpl) { return strip_xl(nw, M, spw, cpl) <= 8; }
 
 int launch_strip(const StripParams &p, int grid, hipStream_t stream) {
-  const size_t lds = strip_lds_bytes(p.M, p.spw, p.nw, p.cpl, p.group_size);
+  const size_t lds = strip_lds_bytes(p.M, p.spw, p.nw, p.cpl, p.group_size, p.ra);
   if (p.group_size == 64) return launch_strip_s<2>(p, grid, lds, stream);
   return launch_strip_s<4>(p, grid, lds, stream);
 }

@@ -12,6 +12,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from qllm_amd.modeling.q_layers import QuantLinearGPTQ, QuantLinearHQQ, WQLinear_GEMM  # noqa: E402
 
 SHAPES = [(4096, 4096), (4096, 11008), (11008, 4096)]
+# total bytes of the rotating weight copies: 640 MB = beyond the 256 MB MALL (HBM-cold); ~100 MB = MALL-warm but L2-cold
+FOOTPRINT_MB = int(os.environ.get("KBENCH_FOOTPRINT_MB", "640"))
 CLS = {"GPTQ": QuantLinearGPTQ, "GEMM": WQLinear_GEMM, "HQQ": QuantLinearHQQ}
 
 
@@ -47,7 +49,7 @@ def main():
     for layout in args.layouts:
         for (K, N) in SHAPES:
             wbytes = K * N // 2
-            ncopy = max(2, min(48, (640 << 20) // wbytes))
+            ncopy = max(2, min(48, (FOOTPRINT_MB << 20) // wbytes))
             layers = [rand_layer(layout, K, N, args.g, dev, args.act and layout == "GPTQ") for _ in range(ncopy)]
             for M in args.m:
                 x = torch.randn(M, K, device=dev, dtype=torch.float16)
@@ -97,7 +99,7 @@ def grouped():
     dev = torch.device("cuda:0")
     for name, shapes in (("qkv", [(4096, 4096)] * 3), ("gate_up", [(4096, 11008)] * 2), ("o", [(4096, 4096)]), ("down", [(11008, 4096)])):
         nbytes = sum(alg_bytes(K, N, 128, 1, "GPTQ", False) for K, N in shapes)
-        ncopy = max(2, min(32, (640 << 20) // nbytes))
+        ncopy = max(2, min(32, (FOOTPRINT_MB << 20) // nbytes))
         sets = [[rand_layer("GPTQ", K, N, 128, dev) for (K, N) in shapes] for _ in range(ncopy)]
         x = torch.randn(1, shapes[0][0], device=dev, dtype=torch.float16)
         descs = [[l.decode_descriptor() for l in s] for s in sets]
