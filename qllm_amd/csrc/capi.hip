@@ -116,7 +116,11 @@ static bool strip_plan(const qllm_weight_t *w, int n, int M, StripPlan *plan) {
   // measured (graph replay, us; slab -> RA): 4096x4096 M=4 5.3 -> 6.2, M=8 9.6 -> 7.1, M=16 9.9 -> 8.5; 4096x11008 M=4 9.8 -> 9.3,
   // M=8 10.0 -> 9.7, M=16 25.7 -> 11.9; 11008x4096 M=4 13.6 -> 13.0, M=8 20.2 -> 14.6, M=16 26.4 (split-K fallback) -> 18.9
   static int ra_min = env_int("QLLM_STRIP_RA_MIN", 5);
-  const int ra = (M >= ra_min) ? 1 : 0;
+  // long K with 64-wide groups or 3 bits: the one-round slab variant (24 loads + 12 scale/zero pairs per lane) spills
+  // 17-21 registers in a 16-wave block; the register-A variant (rounds of 8 with next-round prefetch) does not
+  static int ra_longk = env_int("QLLM_STRIP_RA_LONGK", 1);
+  const bool longk = ra_longk && (w[0].group_size == 64 || bits == 3) && strip_spw(w[0].K, w[0].group_size, 16) > 8;
+  const int ra_base = (M >= ra_min) ? 1 : 0;
   int first = bits == 3 ? 1 : strip_cpl(cols, m64, m32);
   if (force_cpl == 4 && m64 && bits == 4) first = 4;
   if (force_cpl == 2 && m32 && bits == 4) first = 2;
@@ -134,6 +138,7 @@ static bool strip_plan(const qllm_weight_t *w, int n, int M, StripPlan *plan) {
     int nw = cpl == 4 ? (nw4 ? nw4 : 8) : ((cpl == 2 || bits == 3) ? 16 : strip_nw(w[0].K, strips));
     for (int tries = 0; tries < 2; ++tries) {
       const int spw = strip_spw(w[0].K, w[0].group_size, nw);
+      const int ra = (ra_base || (longk && cpl == 1 && nw == 16)) ? 1 : 0;
       if ((ra || strip_x_ok(M, spw, nw, cpl)) && strip_lds_bytes(M, spw, nw, cpl, w[0].group_size, ra) <= 156 * 1024) {
         plan->cpl = cpl;
         plan->nw = nw;

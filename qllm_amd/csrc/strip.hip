@@ -59,9 +59,12 @@ __device__ __forceinline__ float dpp_add(float v) {
 //       registers (4 v_perm + 4 v_pk_mul), and Sx / Sx' come out of the matrix core in exactly the accumulator layout
 //       the correction needs: two more MFMAs per k-step against constant B fragments (all ones -> Sx' = sum of the
 //       staged values; the per-slot multipliers -> Sx).  Rounds are 8 k-steps (8 x 16 B of x + 8 weight loads in flight
-//       per lane); LDS holds only the cross-wave reduction buffer.
+//       per lane); LDS holds only the cross-wave reduction buffer.  (Measured dead end: also requesting the NEXT round's
+//       weights before computing a round -- two register sets, loop unrolled by two -- was 8-18 % slower at K=11008.)
 template <int NW, int CPL, int MAXS, int SPG, int XL, int BITS, bool RA = false, bool RA_BF16 = false>
-__global__ __launch_bounds__(NW * 64) void strip_kernel(const StripParams p) {
+// (second launch-bound = minimum waves per SIMD: the 8-wave 64-column slab variant sits right at the 128-register edge
+//  that lets two blocks share a CU -- 130 registers halve its occupancy: gate/up 13.7 -> 15.0 us)
+__global__ __launch_bounds__(NW * 64, (NW == 8 && CPL == 4 && SPG == 4 && !RA) ? 4 : 1) void strip_kernel(const StripParams p) {
   static_assert(BITS == 4 || (BITS == 3 && CPL == 1), "3-bit strips are 16 columns wide");
   static_assert(!RA || MAXS == 8, "register-A rounds are 8 k-steps");
   constexpr int NG = MAXS / SPG;   // groups per round (MAXS is a multiple of SPG; rounds start on a group boundary)
@@ -105,7 +108,8 @@ __global__ __launch_bounds__(NW * 64) void strip_kernel(const StripParams p) {
   float2_t *sxs = (float2_t *)((half_t *)(red + NW * M * TN) + (size_t)NW * M * xrow) + (size_t)wave * ngw * 16;
   const int cpr = spw_pad * 4;  // 16-byte chunks per row
   const int xlast = M * cpr - 1;
-  half8_t xa[XL];
+  uint4_t xa[XL];
+  bool xkeep[XL];
   int xdst[XL], sdst[XL];
 #pragma unroll
   for (int u = 0; u < XL; ++u) {
@@ -115,13 +119,10 @@ __global__ __launch_bounds__(NW * 64) void strip_kernel(const StripParams p) {
     const int kc = c - row * cpr;
     const int k = 32 * t0 + 8 * kc;
     const size_t off = (size_t)row * p.K + min(k, p.K - 8);
-    half8_t v;
-    if (p.act_bf16)
-      v = bf16x8_to_h8(*(const uint4_t *)((const uint16_t *)p.x + off));
-    else
-      v = *(const half8_t *)((const half_t *)p.x + off);
-    const half8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
-    xa[u] = (k < kend) ? v : zero;
+    // raw 16 bytes now (fp16 or bf16: same size); bf16 is converted when the chunk is staged -- converting here put a
+    // vmcnt(0) between this load and every load after it
+    xa[u] = *(const uint4_t *)((const uint16_t *)p.x + off);
+    xkeep[u] = (k < kend);
     xdst[u] = (cu <= xlast) ? row * xrow + 8 * kc : -1;
     sdst[u] = (kc / GL) * 16 + row;
   }
@@ -135,13 +136,16 @@ __global__ __launch_bounds__(NW * 64) void strip_kernel(const StripParams p) {
       //   4 bits: (k0,k4 | k1,k5 | k2,k6 | k3,k7), divisors (1,1 | 16,16 | 1,1 | 16,16)
       //   3 bits: (k0,k5 | k1,k6 | k2,k7 | k3,k4), divisors (2,1 | 16,8 | 128,64 | 1,1)
       half2_t p0, p1, p2, p3, q0, q1, q2, q3;
+      const half8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+      half8_t xv = p.act_bf16 ? bf16x8_to_h8(xa[u]) : __builtin_bit_cast(half8_t, xa[u]);
+      xv = xkeep[u] ? xv : zero8;
       if constexpr (BITS == 4) {
-        const half8_t pv = a_perm_04152637(xa[u]);
+        const half8_t pv = a_perm_04152637(xv);
         p0 = half2_t{pv[0], pv[1]}; p1 = half2_t{pv[2], pv[3]}; p2 = half2_t{pv[4], pv[5]}; p3 = half2_t{pv[6], pv[7]};
         const half2_t sixteenth = {(half_t)0.0625f, (half_t)0.0625f};
         q0 = p0; q1 = p1 * sixteenth; q2 = p2; q3 = p3 * sixteenth;
       } else {
-        const half8_t pv = __builtin_shufflevector(xa[u], xa[u], 0, 5, 1, 6, 2, 7, 3, 4);
+        const half8_t pv = __builtin_shufflevector(xv, xv, 0, 5, 1, 6, 2, 7, 3, 4);
         p0 = half2_t{pv[0], pv[1]}; p1 = half2_t{pv[2], pv[3]}; p2 = half2_t{pv[4], pv[5]}; p3 = half2_t{pv[6], pv[7]};
         q0 = p0 * half2_t{(half_t)0.5f, (half_t)1.f};
         q1 = p1 * half2_t{(half_t)0.0625f, (half_t)0.125f};
@@ -197,6 +201,8 @@ __global__ __launch_bounds__(NW * 64) void strip_kernel(const StripParams p) {
   const int zmul = (zk == ZK_PACKED) ? (N >> 3) : (N >> 1);
   const int zoff = (zk == ZK_PACKED) ? (n >> 3) : (n >> 1);
   const int zoff2 = (zk == ZK_F16 && CPL == 4) ? 1 : 0;
+  const uint32_t zsel_p = (zk == ZK_PACKED) ? 0xffffffffu : 0u, zsel_h = (zk == ZK_F16) ? 0xffffffffu : 0u;
+  const uint32_t zsel_s = (zk == ZK_SYM) ? __builtin_bit_cast(uint32_t, (float)(1 << (BITS - 1))) : 0u;
   // RA: this lane's activation row (MFMA row i; rows >= M re-read row M-1, their outputs are never stored), k-slot 8g
   const uint16_t *xrow_ra = (const uint16_t *)p.x + (size_t)min(i, M - 1) * p.K + 8 * g;
   // constant B fragments: all ones, and the per-slot multipliers that undo the staged divisors (4 bits: x16 on the odd
@@ -333,7 +339,9 @@ __global__ __launch_bounds__(NW * 64) void strip_kernel(const StripParams p) {
           const uint32_t zd = (CPL >= 2) ? zraw[j][c >> 1] : zraw[j][0];
           const bool hi = (CPL >= 2) ? (c & 1) : (n & 1);
           const float zh = (float)__builtin_bit_cast(half_t, (uint16_t)(hi ? (zd >> 16) : (zd & 0xffffu)));
-          const float zfc = (zk == ZK_PACKED) ? zp : ((zk == ZK_F16) ? zh : (float)(1 << (BITS - 1)));
+          // branch-free select of the zero kind: with ?: on the wave-uniform zk hipcc may emit real branches around each
+          // conversion (a dozen extra basic blocks per round, which also breaks up the load/MFMA schedule)
+          const float zfc = __builtin_bit_cast(float, (__builtin_bit_cast(uint32_t, zp) & zsel_p) | (__builtin_bit_cast(uint32_t, zh) & zsel_h) | zsel_s);
           const float sfc = (float)sc[j][c];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
