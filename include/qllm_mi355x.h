@@ -136,6 +136,17 @@ int qllm_ort_dequant(const void *qweight, const void *scales, const void *qzeros
                      int32_t groupsize, int32_t bits, int32_t in_features, int32_t add_zero_bias, void *out_kn,
                      int32_t N, void *stream);
 
+/* ort_ops.Dequantize4Bits(qweight u8 [N, K/block, block/2], scales [N*K/block], qzeros, g_idx, block_size, in_features,
+ * out_features) -> W[N,K] f16 (ort_ops.cc:161-197; kernels dq.cu:79-245): the ORT / MatMulNBits blob layout that
+ * QuantLinearORT stores (quant_linear_onnxruntime.py:85-153).  `qzeros` is either packed u8 (two 4-bit zero points per
+ * byte, ceil(K/block / 2) bytes per row; zeros_f16 = 0) or fp16 [N, K/block] (zeros_f16 = 1); `g_idx` (NULL unless the
+ * layer is act-order) maps each input channel to its block.  Needs block_size % 16 == 0 and in_features % block_size == 0.
+ * Numerics follow the reference's Python path: fp16((q - z) * s), with the difference rounded to fp16 first when the
+ * zero points are fp16. */
+int qllm_ort_dequantize4bits(const void *qweight, const void *scales, const void *qzeros, int32_t zeros_f16,
+                             const int32_t *g_idx, int32_t block_size, int32_t in_features, int32_t out_features,
+                             void *out_nk, void *stream);
+
 /* awq_inference_engine.gemm_forward_cuda(x[M,K], qweight[K,N/8], scales[K/g,N], qzeros[K/g,N/8], split_k_iters)
  * -> y[M,N] (gemm_cuda.h:3-4).  `split_k_iters` is accepted for signature parity and ignored: the reduction
  * over K is carried in fp32, never as the reference's fp16 partial sums (gemm_cuda_gen.cu:1115,1160). */

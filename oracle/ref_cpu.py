@@ -18,6 +18,9 @@ reference's CPU path for the hot path named in BASELINE.json:
   * bit layouts (``general_pack_on_row`` / ``general_unpack_on_row``)            ...compress_weight.py:10-92
   * ``pack_qzeros`` (COMPATIBLE_WITH_AUTOGPTQ offset)                            ...compress_weight.py:156-172
   * ``handle_qzeros_for_autogptq``                                               ...quant_linear_gptq.py:119-134
+  * ORT / MatMulNBits blob layout: ``dequantize_blockwise_4bits`` / ``QuantLinearORT.pack_on_device``
+    / ``forward``                                       ...quant_linear_onnxruntime.py:52-82, 116-153, 169-174
+    (goldens: ``tests/golden/make_goldens_ort.py`` -> ``ort_*.npz``)
 
 Parity pinning: the reference ships no tests, so this oracle is pinned against
 golden vectors minted by importing the reference itself in the build container
@@ -349,6 +352,71 @@ def autogptq_fixup_qzeros(qzeros, bits: int, out_features: int) -> np.ndarray:
     z = unpack_along_cols(qzeros, bits, out_features)
     z = (z + 1) & ((1 << bits) - 1)
     return pack_along_cols(z, bits)
+
+
+# ----------------------------------------------------------------------------------------------
+# ORT / MatMulNBits blob layout (4 bits)       quant_linear_onnxruntime.py:52-82 (dequant), :116-153 (pack)
+#   qweight u8 [N, K/g, g/2]: byte b of block j of row n = q[g*j + 2b, n] | q[g*j + 2b + 1, n] << 4
+#   scales  f16 [N * K/g]   : row-major (n, j)
+#   qzeros  u8  [N * ceil(G/2)]: byte i of row n = z[2i, n] | z[2i+1, n] << 4 (odd G: last high nibble is padding)
+#           or f16 [N, G]   : un-packed, non-integer zero points
+#   W[n, k] = fp16((q - z) * s) for integer zeros (ONE rounding: int32 difference, then one fp16 multiply);
+#             fp16(fp16(q - z) * s) for fp16 zeros (the difference is rounded to fp16 first)
+#   act-order: z, s taken at block g_idx[k]
+# ----------------------------------------------------------------------------------------------
+def ort_int_weight(qweight_u8) -> np.ndarray:
+    """[N, G, g/2] u8 -> q[K, N] int32."""
+    qw = np.asarray(qweight_u8, dtype=np.uint8)
+    n = qw.shape[0]
+    lo, hi = (qw & 0x0F).astype(np.int32), (qw >> 4).astype(np.int32)
+    q_nk = np.stack([lo, hi], axis=-1).reshape(n, -1)
+    return np.ascontiguousarray(q_nk.T)
+
+
+def ort_int_zeros(qzeros_u8, out_features: int, n_blocks: int) -> np.ndarray:
+    """flat u8 nibble pairs -> z[G, N] int32."""
+    zb = np.asarray(qzeros_u8, dtype=np.uint8).reshape(out_features, -1)
+    z_ng = np.stack([(zb & 0x0F).astype(np.int32), (zb >> 4).astype(np.int32)], axis=-1).reshape(out_features, -1)
+    return np.ascontiguousarray(z_ng[:, :n_blocks].T)
+
+
+def pack_ort(q_kn, z_gn, scales_gn):
+    """(q[K,N], z[G,N] int or f16, scales[G,N]) -> (qweight u8 [N,G,g/2], qzeros, scales_flat) as pack_on_device does."""
+    q_nk = np.asarray(q_kn).T.astype(np.uint8)
+    n, k = q_nk.shape
+    g_blocks = np.asarray(scales_gn).shape[0]
+    qweight = (q_nk[:, 0::2] | (q_nk[:, 1::2] << 4)).reshape(n, g_blocks, k // g_blocks // 2)
+    z = np.asarray(z_gn)
+    if z.dtype == np.float16:
+        qzeros = np.ascontiguousarray(z.T)
+    else:
+        z_ng = z.T.astype(np.uint8)
+        if z_ng.shape[1] & 1:
+            z_ng = np.concatenate([z_ng, np.zeros((n, 1), np.uint8)], axis=1)
+        qzeros = (z_ng[:, 0::2] | (z_ng[:, 1::2] << 4)).reshape(-1)
+    return np.ascontiguousarray(qweight), qzeros, np.ascontiguousarray(np.asarray(scales_gn, np.float16).T).reshape(-1)
+
+
+def dequant_ort(qweight_u8, scales_flat, qzeros, g_idx, groupsize: int, in_features: int, out_features: int) -> np.ndarray:
+    """W[N, K] float16, exactly as dequantize_blockwise_4bits (quant_linear_onnxruntime.py:52-82)."""
+    q_kn = ort_int_weight(qweight_u8)[:in_features]
+    n_blocks = np.asarray(qweight_u8).shape[1]
+    s_gn = np.asarray(scales_flat, dtype=np.float16).reshape(out_features, n_blocks).T
+    gi = trivial_g_idx(in_features, groupsize) if g_idx is None else np.asarray(g_idx, dtype=np.int64)
+    qz = np.asarray(qzeros)
+    if qz.dtype == np.float16:
+        z_gn = qz.reshape(out_features, n_blocks).T
+        diff = (q_kn.astype(np.float32) - z_gn[gi].astype(np.float32)).astype(np.float16)  # int - half -> half
+    else:
+        z_gn = ort_int_zeros(qz, out_features, n_blocks)
+        diff = (q_kn - z_gn[gi]).astype(np.float16)                                        # exact small integers
+    w_kn = (diff.astype(np.float32) * s_gn[gi].astype(np.float32)).astype(np.float16)      # one fp16 multiply
+    return np.ascontiguousarray(w_kn.T)
+
+
+def ort_is_act_order(g_idx) -> bool:
+    """dequantize_blockwise_4bits gathers per k only if g_idx[:32] is not all zero (:70)."""
+    return g_idx is not None and int(np.asarray(g_idx)[:32].sum()) != 0
 
 
 # ----------------------------------------------------------------------------------------------

@@ -21,7 +21,7 @@ ABI_VERSION = 1
 EXPORTS = (
     "qllm_abi_version", "qllm_last_error", "qllm_device_info", "qllm_workspace_bytes", "qllm_workspace_init",
     "qllm_linear_forward", "qllm_linear_forward_grouped", "qllm_dequant", "qllm_ort_gemv", "qllm_ort_dequant",
-    "qllm_awq_gemm_forward", "qllm_unpack_qweight", "qllm_pack_qweight",
+    "qllm_awq_gemm_forward", "qllm_unpack_qweight", "qllm_pack_qweight", "qllm_ort_dequantize4bits",
 )
 
 
@@ -85,6 +85,8 @@ def _declare(lib):
     lib.qllm_unpack_qweight.argtypes = [vp, i32, i32, i32, i32, vp, vp]
     lib.qllm_pack_qweight.restype = C.c_int
     lib.qllm_pack_qweight.argtypes = [vp, i32, i32, i32, i32, vp, vp]
+    lib.qllm_ort_dequantize4bits.restype = C.c_int
+    lib.qllm_ort_dequantize4bits.argtypes = [vp, vp, vp, i32, vp, i32, i32, i32, vp, vp]
 
 
 def is_built() -> bool:

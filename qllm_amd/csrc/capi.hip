@@ -402,6 +402,17 @@ int qllm_awq_gemm_forward(const void *x, const void *qweight, const void *scales
   return qllm_linear_forward(&w, x, y, M, act_dtype, workspace, workspace_bytes, stream);
 }
 
+int qllm_ort_dequantize4bits(const void *qweight, const void *scales, const void *qzeros, int32_t zeros_f16, const int32_t *g_idx,
+                             int32_t block_size, int32_t in_features, int32_t out_features, void *out_nk, void *stream) {
+  clear_error();
+  if (!qweight || !scales || !qzeros || !out_nk) return set_error(QLLM_ERR_INVALID, "qweight / scales / qzeros / out must not be NULL");
+  if (in_features <= 0 || out_features <= 0) return set_error(QLLM_ERR_INVALID, "in_features/out_features must be >= 1 (K=%d N=%d)", in_features, out_features);
+  if (block_size < 16 || block_size % 16) return set_error(QLLM_ERR_INVALID, "block_size must be a multiple of 16 (got %d)", block_size);
+  if (in_features % block_size) return set_error(QLLM_ERR_UNSUPPORTED, "in_features must be a multiple of block_size (K=%d block=%d)", in_features, block_size);
+  if ((uintptr_t)qweight % 8 || (uintptr_t)out_nk % 16) return set_error(QLLM_ERR_INVALID, "qweight must be 8-byte and out 16-byte aligned");
+  return launch_ort_dequant(qweight, scales, qzeros, zeros_f16 ? 1 : 0, g_idx, block_size, in_features, out_features, out_nk, (hipStream_t)stream);
+}
+
 int qllm_unpack_qweight(const void *qweight, int32_t layout, int32_t bits, int32_t K, int32_t N, int32_t *q_kn, void *stream) {
   clear_error();
   if (!qweight || !q_kn) return set_error(QLLM_ERR_INVALID, "qweight / q_kn must not be NULL");

@@ -9,6 +9,10 @@ int launch_dequant(const qllm_weight_t &w, int zero_kind, void *out, int out_dty
 int launch_unpack_qweight(const void *qweight, int layout, int bits, int K, int N, int32_t *q_kn, hipStream_t stream);
 int launch_pack_qweight(const int32_t *q_kn, int layout, int bits, int K, int N, void *qweight, hipStream_t stream);
 
+// ---- ortblob.hip (ORT / MatMulNBits blob layout -> W[N,K] fp16) ---------------------------------------------------
+int launch_ort_dequant(const void *qweight, const void *scales, const void *qzeros, int zeros_f16, const int32_t *g_idx,
+                       int block, int K, int N, void *out, hipStream_t stream);
+
 // ---- skinny.hip ----------------------------------------------------------------------------------------------
 constexpr int kMaxProblems = 8;
 

@@ -2,3 +2,4 @@
 from .quant_linear_gptq import QuantLinearGPTQ  # noqa: F401
 from .quant_linear_awq import WQLinear_GEMM  # noqa: F401
 from .quant_linear_hqq import QuantLinearHQQ  # noqa: F401
+from .quant_linear_onnxruntime import QuantLinearORT  # noqa: F401

@@ -134,6 +134,28 @@ def dequant(w: QllmWeight, device: torch.device, dtype=torch.float16, transposed
     return out
 
 
+def ort_dequantize4bits(qweight: torch.Tensor, scales: torch.Tensor, qzeros: torch.Tensor, g_idx: Optional[torch.Tensor],
+                        block_size: int, in_features: int, out_features: int) -> torch.Tensor:
+    """ORT / MatMulNBits blob -> W[N,K] in the scales' dtype (ort_ops.Dequantize4Bits, ort_ops.cc:161-197)."""
+    for name, t in (("qweight", qweight), ("scales", scales), ("qzeros", qzeros)):
+        _check_input(t, name)
+    if qweight.dtype != torch.uint8:
+        raise RuntimeError("qweight must be uint8 (ORT blob layout)")
+    zf = qzeros.dtype != torch.uint8
+    s16 = scales if scales.dtype == torch.float16 else scales.to(torch.float16)
+    z = qzeros if (not zf or qzeros.dtype == torch.float16) else qzeros.to(torch.float16)
+    gi = None
+    if g_idx is not None:
+        gi = g_idx.to(device=qweight.device, dtype=torch.int32).contiguous()
+    out = torch.empty((out_features, in_features), dtype=torch.float16, device=qweight.device)
+    with torch.cuda.device(qweight.device):
+        rc = _lib.load().qllm_ort_dequantize4bits(qweight.data_ptr(), s16.data_ptr(), z.data_ptr(), 1 if zf else 0,
+                                                  gi.data_ptr() if gi is not None else None, block_size, in_features,
+                                                  out_features, out.data_ptr(), _stream_ptr())
+    _lib.check(rc)
+    return out if scales.dtype == torch.float16 else out.to(scales.dtype)
+
+
 def unpack_qweight(qweight: torch.Tensor, layout: str, bits: int, in_features: int, out_features: int) -> torch.Tensor:
     _check_input(qweight, "qweight")
     q = torch.empty((in_features, out_features), dtype=torch.int32, device=qweight.device)

@@ -50,3 +50,9 @@ def dequant(qweight: torch.Tensor, scales: torch.Tensor, qzeros: torch.Tensor, g
                               in_features, qweight.shape[1], groupsize, bits, add_zero_bias)
     out = ops.dequant(w, qweight.device, torch.float16)
     return out.to(torch.bfloat16) if scales.dtype == torch.bfloat16 else out
+
+
+def Dequantize4Bits(qweight: torch.Tensor, scales: torch.Tensor, qzeros: torch.Tensor, g_idx: Optional[torch.Tensor],
+                    block_size: int, in_features: int, out_features: int):
+    """ort_ops.Dequantize4Bits (ort_ops.cc:161-197): ORT / MatMulNBits blob -> W[out_features, in_features]."""
+    return ops.ort_dequantize4bits(qweight, scales, qzeros, g_idx, block_size, in_features, out_features)

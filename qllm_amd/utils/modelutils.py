@@ -16,17 +16,21 @@ def find_layers(module, layers=(nn.Conv2d, nn.Linear), name=""):
 
 def select_quant_linear(pack_mode: str, wbits: int, quant_method: str):
     """Same decision table as the reference (modelutils.py:44-68) restricted to the layouts this build serves:
-    hqq -> QuantLinearHQQ; GEMM, or AUTO on a 4-bit-capable engine -> WQLinear_GEMM; otherwise QuantLinearGPTQ.
-    ORT / MARLIN / vptq are outside the hot-path scope and raise."""
-    from ..modeling.q_layers import QuantLinearGPTQ, QuantLinearHQQ, WQLinear_GEMM
+    ORT -> QuantLinearORT; hqq -> QuantLinearHQQ; GEMM, or AUTO on a 4-bit-capable engine -> WQLinear_GEMM; otherwise
+    QuantLinearGPTQ.  MARLIN / vptq are outside the hot-path scope and raise."""
+    from ..modeling.q_layers import QuantLinearGPTQ, QuantLinearHQQ, QuantLinearORT, WQLinear_GEMM
     from ..modeling.q_layers.ext_package_checker import is_the_machine_support_awq_engine
 
     pack_mode = pack_mode.upper()
     quant_method = quant_method.lower()
-    if quant_method == "vptq" or pack_mode in ("ORT", "MARLIN"):
-        raise NotImplementedError(f"pack_mode={pack_mode} / quant_method={quant_method} is outside this build's scope")
+    if quant_method == "vptq":
+        raise NotImplementedError("quant_method=vptq is outside this build's scope")
+    if pack_mode == "ORT":
+        return QuantLinearORT
     if quant_method == "hqq":
         return QuantLinearHQQ
+    if pack_mode == "MARLIN":
+        raise NotImplementedError("pack_mode=MARLIN is outside this build's scope")
     if pack_mode == "GEMM" or (pack_mode == "AUTO" and is_the_machine_support_awq_engine(wbits)):
         return WQLinear_GEMM
     return QuantLinearGPTQ

@@ -17,7 +17,14 @@ def pytest_configure(config):
 
 
 def golden_names():
-    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+    """GPTQ / AWQ / HQQ fixtures (tests/golden/make_goldens.py)."""
+    return sorted(n for n in (os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+                  if not n.startswith("ort_"))
+
+
+def ort_golden_names():
+    """ORT / MatMulNBits blob-layout fixtures (tests/golden/make_goldens_ort.py)."""
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "ort_*.npz")))
 
 
 def load_golden(name):

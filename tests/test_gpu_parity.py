@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden_names, load_golden
+from conftest import golden_names, load_golden, ort_golden_names
 from oracle import ref_cpu as O
 from gpu_util import LAYER, Ref, oracle_w, oracle_y, randx, synth, to_layer
 
@@ -382,3 +382,60 @@ def test_load_and_eval_tiny_llama(tmp_path, pack_mode):
     assert O.rel_err(step.numpy(), logits_ref[:, :1].numpy()) <= 2e-2
     agree = (logits.argmax(-1) == logits_ref.argmax(-1)).float().mean().item()
     assert agree >= 0.9
+
+
+# ---- ORT / MatMulNBits blob layout ----------------------------------------------------------------
+def _ort_layer(qweight, scales_flat, qzeros, g_idx, bias, g, K, N, dtype=torch.float16):
+    from qllm_amd.modeling.q_layers import QuantLinearORT
+    layer = QuantLinearORT(4, g, K, N, bias is not None, dtype=dtype)
+    layer.qweight = torch.from_numpy(np.ascontiguousarray(qweight))
+    layer.qzeros = torch.from_numpy(np.ascontiguousarray(qzeros))
+    layer.scales = torch.from_numpy(np.ascontiguousarray(scales_flat)).to(dtype)
+    layer.g_idx = torch.from_numpy(np.ascontiguousarray(g_idx))
+    if bias is not None:
+        layer.bias = torch.from_numpy(bias).to(dtype)
+    return layer.to(DEV)
+
+
+@pytest.mark.parametrize("name", ort_golden_names())
+def test_ort_blob_dequant_bit_exact_and_forward_vs_reference(name):
+    from qllm_amd import ort_ops
+    g = load_golden(name)
+    K, N, gs = g["K"], g["N"], g["groupsize"]
+    layer = _ort_layer(g["qweight"], g["scales_flat"], g["qzeros"], g["g_idx"], g["bias"], gs, K, N)
+    act = O.ort_is_act_order(g["g_idx"])
+    w = ort_ops.Dequantize4Bits(layer.qweight, layer.scales, layer.qzeros, layer.g_idx if act else None, gs, K, N)
+    assert w.shape == (N, K) and np.array_equal(w.cpu().numpy().view(np.uint16), g["W_unpack"].view(np.uint16))
+    wu, s, z = layer.unpack()  # on-device path of the module
+    assert np.array_equal(wu.numpy().view(np.uint16), g["W_unpack"].view(np.uint16))
+    x = torch.from_numpy(g["x"]).to(DEV)
+    assert O.rel_err(layer(x).cpu().numpy(), g["y"]) <= TOL        # 33 rows: split-K / GEMM path
+    assert O.rel_err(layer(x[:1]).cpu().numpy(), g["y1"]) <= TOL   # decode path
+    assert layer(x.reshape(3, 11, K)).shape == (3, 11, N)
+
+
+@pytest.mark.parametrize("K,N,gs,zk,act,bias", [(4096, 4096, 128, "int", False, False), (4096, 11008, 128, "int", False, True),
+                                                (11008, 4096, 64, "f16", False, False), (4096, 4096, 128, "int", True, False),
+                                                (384, 256, 128, "int", False, False)])
+def test_ort_blob_forward_vs_oracle(K, N, gs, zk, act, bias):
+    rng = np.random.default_rng(K + N + gs)
+    G = K // gs
+    q = rng.integers(0, 16, (K, N), dtype=np.int32)
+    s = (rng.random((G, N)) * 0.010 + 0.002).astype(np.float16)
+    z = (rng.random((G, N)) * 15).astype(np.float16) if zk == "f16" else rng.integers(0, 16, (G, N), dtype=np.int32)
+    g_idx = O.trivial_g_idx(K, gs)
+    if act:
+        g_idx = g_idx[rng.permutation(K)].astype(np.int32)
+        g_idx[0] = G - 1
+    b = (rng.standard_normal(N) * 0.5).astype(np.float16) if bias else None
+    qw, qz, sf = O.pack_ort(q, z, s)
+    layer = _ort_layer(qw, sf, qz, g_idx, b, gs, K, N)
+    w_nk = O.dequant_ort(qw, sf, qz, g_idx if act else None, gs, K, N)
+    got = layer.unpack()[0].numpy()
+    assert np.array_equal(got.view(np.uint16), w_nk.view(np.uint16))  # bit-exact, incl. odd block counts / act-order
+    w_kn = np.ascontiguousarray(w_nk.T)
+    for m in (1, 16, 300):
+        x = randx(m, K, seed=m)
+        y = layer(torch.from_numpy(x).to(DEV)).cpu().numpy()
+        ref = O.matmul_f16(x, w_kn, b).numpy() if m <= 8 else O.matmul_f16_via_f32(x, w_kn, b).numpy()
+        assert O.rel_err(y, ref) <= TOL, (K, N, m)

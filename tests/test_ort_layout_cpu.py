@@ -1,0 +1,97 @@
+"""ORT / MatMulNBits blob layout, CPU side: the oracle against the goldens minted from the
+reference (tests/golden/make_goldens_ort.py), and the host logic of QuantLinearORT (pack / unpack / state dict /
+dispatch).  No compute goes through the HIP library here."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, ort_golden_names
+from oracle import ref_cpu as O
+
+
+def _bits(a):
+    a = np.asarray(a)
+    return a.view(np.uint16) if a.dtype == np.float16 else a
+
+
+@pytest.mark.parametrize("name", ort_golden_names())
+def test_oracle_reproduces_reference_ort_goldens(name):
+    g = load_golden(name)
+    K, N, gs = g["K"], g["N"], g["groupsize"]
+    assert np.array_equal(O.ort_int_weight(g["qweight"]), g["q"])
+    if g["qzeros"].dtype == np.uint8:
+        assert np.array_equal(O.ort_int_zeros(g["qzeros"], N, K // gs), g["zeros"])
+    qw, qz, sf = O.pack_ort(g["q"], g["zeros"], g["scales"])
+    assert np.array_equal(qw, g["qweight"]) and np.array_equal(_bits(qz), _bits(g["qzeros"]))
+    assert np.array_equal(_bits(sf), _bits(g["scales_flat"]))
+    gi = g["g_idx"] if O.ort_is_act_order(g["g_idx"]) else None
+    w_nk = O.dequant_ort(g["qweight"], g["scales_flat"], g["qzeros"], gi, gs, K, N)
+    assert np.array_equal(_bits(w_nk), _bits(g["W_unpack"]))  # bit-exact W
+    y = O.matmul_f16(g["x"], np.ascontiguousarray(w_nk.T), g["bias"])
+    assert O.rel_err(y, g["y"]) <= 1e-3
+    assert O.rel_err(O.matmul_f16(g["x"][:1], np.ascontiguousarray(w_nk.T), g["bias"]), g["y1"]) <= 1e-3
+
+
+def test_oracle_odd_block_count_padding_nibble():
+    """The reference's own CPU dequant cannot reshape an odd number of blocks; the blob format still defines it (a padding
+    high nibble per row).  Pack -> unpack round trip of the restated layout."""
+    rng = np.random.default_rng(3)
+    K, N, gs = 384, 64, 128
+    q = rng.integers(0, 16, (K, N)).astype(np.int32)
+    z = rng.integers(0, 16, (K // gs, N)).astype(np.int32)
+    s = (rng.random((K // gs, N)) * 0.01 + 0.002).astype(np.float16)
+    qw, qz, sf = O.pack_ort(q, z, s)
+    assert qz.shape == (N * 2,) and np.all((qz.reshape(N, 2)[:, 1] >> 4) == 0)
+    assert np.array_equal(O.ort_int_weight(qw), q) and np.array_equal(O.ort_int_zeros(qz, N, 3), z)
+    w = O.dequant_ort(qw, sf, qz, None, gs, K, N)
+    gi = np.arange(K) // gs
+    expect = ((q - z[gi]).astype(np.float16).astype(np.float32) * s[gi].astype(np.float32)).astype(np.float16).T
+    assert np.array_equal(_bits(w), _bits(expect))
+
+
+def _layer_from_golden(g):
+    from qllm_amd.modeling.q_layers import QuantLinearORT
+    layer = QuantLinearORT(4, g["groupsize"], g["K"], g["N"], g["bias"] is not None, dtype=torch.float16)
+    gi = torch.from_numpy(g["g_idx"]).long()
+    w_kn = torch.from_numpy(g["scales"]).double()[gi] * (torch.from_numpy(g["q"]).double() - torch.from_numpy(g["zeros"]).double()[gi])
+    lin = torch.nn.Linear(g["K"], g["N"], bias=False, dtype=torch.float64)
+    lin.weight.data = w_kn.T.contiguous()
+    zeros = torch.from_numpy(g["zeros"])
+    z_arg = zeros if zeros.dtype == torch.float16 else zeros.to(torch.float32)
+    layer.pack(lin, torch.from_numpy(g["scales"]).float().T.contiguous(), z_arg.T.contiguous(), torch.from_numpy(g["g_idx"]).clone())
+    if g["bias"] is not None:
+        layer.bias = torch.from_numpy(g["bias"]).clone()
+    return layer
+
+
+@pytest.mark.parametrize("name", ort_golden_names())
+def test_module_pack_and_unpack_match_reference(name):
+    g = load_golden(name)
+    layer = _layer_from_golden(g)
+    assert layer.qweight.dtype == torch.uint8 and np.array_equal(layer.qweight.numpy(), g["qweight"])
+    assert np.array_equal(_bits(layer.qzeros.numpy()), _bits(g["qzeros"]))
+    assert np.array_equal(_bits(layer.scales.numpy()), _bits(g["scales_flat"]))
+    assert layer.act_order == O.ort_is_act_order(g["g_idx"]) or "actorder" not in name
+    w, scales, zeros = layer.unpack()
+    assert np.array_equal(_bits(w.numpy()), _bits(g["W_unpack"]))
+    assert np.array_equal(_bits(scales.numpy()), _bits(g["scales"]))
+    assert np.array_equal(_bits(zeros.numpy().astype(g["zeros"].dtype)), _bits(g["zeros"]))
+
+
+def test_module_contract_and_dispatch():
+    from qllm_amd.modeling.q_layers import QuantLinearORT
+    from qllm_amd.utils.modelutils import select_quant_linear
+    layer = QuantLinearORT(4, 128, 512, 256, True, dtype=torch.float16)
+    sd = layer.state_dict()
+    assert sd["qweight"].shape == (256, 4, 64) and sd["qweight"].dtype == torch.uint8
+    assert sd["qzeros"].shape == (4 * 128,) and sd["qzeros"].dtype == torch.uint8
+    assert sd["scales"].shape == (4 * 256,) and sd["g_idx"].shape == (512,) and sd["bias"].shape == (256,)
+    assert layer.pack_mode == "ORT" and layer.groupsize == 128
+    assert QuantLinearORT(4, 128, 384, 64, False).qzeros.shape == (4 * 32,)  # odd block count: padded to even
+    assert QuantLinearORT(4, -1, 256, 64, False).groupsize == 256
+    assert select_quant_linear("ORT", 4, "gptq") is QuantLinearORT
+    assert select_quant_linear("ORT", 4, "hqq") is QuantLinearORT  # ORT wins over hqq, as in the reference's table
+    with pytest.raises(NotImplementedError):
+        QuantLinearORT(9, 128, 256, 64, False)
+    with pytest.raises(RuntimeError):  # no CPU forward
+        layer(torch.zeros(1, 512, dtype=torch.float16))
