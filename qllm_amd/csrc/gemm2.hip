@@ -246,8 +246,11 @@ __global__ __launch_bounds__(512) void gemm2_kernel(const GemmParams p) {
     __syncthreads();
   };
   using TagF = std::integral_constant<bool, false>;
-  // (Tried twice: running waves 4-7 with EARLY = true so that the two waves of every SIMD alternate VALU and MFMA phases --
-  //  771 vs 808 TFLOP/s, and the second body costs 17-35 VGPRs; the instantiation is left out.)
+  // (Tried three times: running waves 4-7 out of phase so that the two waves of every SIMD alternate VALU and MFMA phases.
+  //  With the plain body (EARLY = true for waves 4-7): 771 vs 808 TFLOP/s.  With the fragment-pipelined body (waves 4-7
+  //  store tile kt+2 during the second MFMA block of tile kt, loads three tiles ahead): two loop bodies in one kernel need
+  //  > 256 registers -- 42-64 spilled with two activation sets, 23-46 with one -- and ran 734/725/815 (GPTQ) and
+  //  494/452/517 (AWQ) against 862/866/977 and 806/804/882 in lockstep.  Not kept.)
   if constexpr (BN == 128) {
     // Fragment-pipelined body.  The plain body above starts every k-tile with "barrier -> 8 ds_read_b128 -> wait -> MFMA":
     // all 8 waves sit out the LDS round trip together, then the stores, then the barrier -- the MFMA pipe idles 2/3 of

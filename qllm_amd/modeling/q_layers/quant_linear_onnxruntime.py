@@ -119,7 +119,7 @@ class QuantLinearORT(nn.Module, CompressWeight, HipForwardMixin):
         from ... import ops
         key = (self.qweight.data_ptr(), self.scales.data_ptr(), self.qzeros.data_ptr(), self.g_idx.data_ptr(),
                self.bias.data_ptr() if self.bias is not None else 0)
-        if self._desc is None or key != self._desc_key:
+        if (self._desc is None and self._desc_key is None) or key != self._desc_key:
             if self.bits != 4:
                 raise NotImplementedError("the ORT blob layout is 4-bit only")
             n, k, g = self.outfeatures, self.infeatures, self.groupsize
@@ -142,7 +142,10 @@ class QuantLinearORT(nn.Module, CompressWeight, HipForwardMixin):
                 gi = self.g_idx.to(dev).long()
                 counts = torch.bincount(gi, minlength=groups)
                 if counts.numel() != groups or not bool((counts == g).all()):
-                    raise RuntimeError("QuantLinearORT act-order: blocks must each own exactly `groupsize` input channels")
+                    # blocks of unequal size cannot be laid out as contiguous groups: such a layer is served the way the
+                    # reference serves every layer -- Dequantize4Bits (per-channel gather) + a dense GEMM, on device
+                    self._desc, self._desc_keep, self._desc_key = False, None, key
+                    return None
                 perm = torch.argsort(gi, stable=True)
                 q = ops.unpack_qweight(qw, "GPTQ", 4, k, n)
                 qw = ops.pack_qweight(q.index_select(0, perm).contiguous(), "GPTQ", 4)
@@ -150,13 +153,18 @@ class QuantLinearORT(nn.Module, CompressWeight, HipForwardMixin):
             b = self._f16(self.bias).contiguous() if self.bias is not None else None
             self._desc, self._desc_keep = ops.make_weight("HQQ", qw, scales, zeros, None, b, k, n, g, 4, 0)
             self._desc_key = key
-        return self._desc
+        return self._desc if self._desc else None
 
     def decode_descriptor(self, act_order_g_idx=None, add_zero_bias: int = 0):
         return self._descriptor()
 
     def forward(self, x):
-        self._descriptor()
+        if self._descriptor() is None:  # irregular act-order: the reference's own two-step path, on device
+            from ... import ops
+            w = ops.ort_dequantize4bits(self.qweight, self.scales, self.qzeros, self.g_idx, self.groupsize,
+                                        self.infeatures, self.outfeatures)
+            y = torch.matmul(x, w.to(x.dtype).T)
+            return y + self.bias.to(y.dtype) if self.bias is not None else y
         if self._perm is not None:
             x = x.index_select(-1, self._perm)
         return self._hip_linear(x, None, 0)

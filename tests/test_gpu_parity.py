@@ -416,7 +416,7 @@ def test_ort_blob_dequant_bit_exact_and_forward_vs_reference(name):
 
 @pytest.mark.parametrize("K,N,gs,zk,act,bias", [(4096, 4096, 128, "int", False, False), (4096, 11008, 128, "int", False, True),
                                                 (11008, 4096, 64, "f16", False, False), (4096, 4096, 128, "int", True, False),
-                                                (384, 256, 128, "int", False, False)])
+                                                (384, 256, 128, "int", False, False), (1024, 512, 128, "int", "irregular", True)])
 def test_ort_blob_forward_vs_oracle(K, N, gs, zk, act, bias):
     rng = np.random.default_rng(K + N + gs)
     G = K // gs
@@ -426,7 +426,9 @@ def test_ort_blob_forward_vs_oracle(K, N, gs, zk, act, bias):
     g_idx = O.trivial_g_idx(K, gs)
     if act:
         g_idx = g_idx[rng.permutation(K)].astype(np.int32)
-        g_idx[0] = G - 1
+        if act == "irregular":  # blocks of unequal size: no row-sorted view exists -> dequant kernel + dense GEMM on device
+            g_idx[g_idx == 1] = 0
+        assert g_idx[:32].sum() != 0
     b = (rng.standard_normal(N) * 0.5).astype(np.float16) if bias else None
     qw, qz, sf = O.pack_ort(q, z, s)
     layer = _ort_layer(qw, sf, qz, g_idx, b, gs, K, N)
