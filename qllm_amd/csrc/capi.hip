@@ -86,12 +86,16 @@ static int strip_min_strips() {
   static int v = env_int("QLLM_STRIP_MIN", 192);
   return v;
 }
-// full-K strip kernel: row-stream layouts, M <= 16, enough 16-column strips to cover the 256 CUs
+// full-K strip kernel: row-stream layouts, M <= 64 (17..64: several 16-row tiles per block), enough 16-column strips to
+// cover the 256 CUs
 struct StripPlan {
   int cpl, nw, spw, ra;
 };
 static bool strip_plan(const qllm_weight_t *w, int n, int M, StripPlan *plan) {
-  if (M > 16 || strip_min_strips() <= 0) return false;
+  // measured (graph replay, us; split-K kernel -> strips with 2 / 4 row tiles): M=32: 4096x4096 28.3 -> 13.4, 4096x11008 54.9 -> 36.3,
+  // 11008x4096 50.1 -> 30.3; M=64: 33.8 -> 22.6, 52.5 -> 61.5, 48.1 -> 53.9 -- four row tiles only pay on the small shape
+  static int max_m = env_int("QLLM_STRIP_MAX_M", 32);
+  if (M > max_m || M > 64 || strip_min_strips() <= 0) return false;
   if (!strip_group_ok(w[0].group_size)) return false;
   const int bits = w[0].bits;
   if (bits != 4 && bits != 3) return false;
@@ -109,7 +113,8 @@ static bool strip_plan(const qllm_weight_t *w, int n, int M, StripPlan *plan) {
     m64 = m64 && (w[i].N % 64 == 0);
     m32 = m32 && (w[i].N % 32 == 0);
   }
-  static int force_cpl = env_int("QLLM_STRIP_CPL", 0);
+  static int force_cpl_env = env_int("QLLM_STRIP_CPL", 0);
+  int force_cpl = force_cpl_env;
   static int nw4 = env_int("QLLM_STRIP_NW4", 0);
   // rows from which the activation slab in LDS (staged once per block: M*K/8 chunk operations) loses to per-lane
   // fragment loads + two bookkeeping MFMAs per k-step (strip.hip, RA)
@@ -121,7 +126,8 @@ static bool strip_plan(const qllm_weight_t *w, int n, int M, StripPlan *plan) {
   static int ra_longk = env_int("QLLM_STRIP_RA_LONGK", 1);
   const bool longk = ra_longk && (w[0].group_size == 64 || bits == 3) && strip_spw(w[0].K, w[0].group_size, 16) > 8;
   const int ra_base = (M >= ra_min) ? 1 : 0;
-  int first = bits == 3 ? 1 : strip_cpl(cols, m64, m32);
+  int first = (bits == 3 || M > 16) ? 1 : strip_cpl(cols, m64, m32);
+  if (M > 16) force_cpl = 1;  // several row tiles per block: 16-column strips, 8-wave blocks, register-A
   if (force_cpl == 4 && m64 && bits == 4) first = 4;
   if (force_cpl == 2 && m32 && bits == 4) first = 2;
   if (force_cpl == 1) first = 1;
@@ -136,6 +142,7 @@ static bool strip_plan(const qllm_weight_t *w, int n, int M, StripPlan *plan) {
     // 64-column strips use 128 VGPRs -> 16 waves per CU: 8-wave blocks keep two strips co-resident per CU (one
     // round) instead of 16-wave blocks in two rounds (gate/up 15.6 -> 13.8 us, q/k/v 8.5 -> 8.3 us)
     int nw = cpl == 4 ? (nw4 ? nw4 : 8) : ((cpl == 2 || bits == 3) ? 16 : strip_nw(w[0].K, strips));
+    if (M > 16) nw = 8;
     for (int tries = 0; tries < 2; ++tries) {
       const int spw = strip_spw(w[0].K, w[0].group_size, nw);
       const int ra = (ra_base || (longk && cpl == 1 && nw == 16)) ? 1 : 0;
@@ -146,7 +153,7 @@ static bool strip_plan(const qllm_weight_t *w, int n, int M, StripPlan *plan) {
         plan->ra = ra;
         return true;
       }
-      if (nw == 16) break;
+      if (nw == 16 || M > 16) break;
       nw = 16;  // shorter per-wave chunks
     }
   }

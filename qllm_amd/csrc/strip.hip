@@ -61,12 +61,15 @@ __device__ __forceinline__ float dpp_add(float v) {
 //       staged values; the per-slot multipliers -> Sx).  Rounds are 8 k-steps (8 x 16 B of x + 8 weight loads in flight
 //       per lane); LDS holds only the cross-wave reduction buffer.  (Measured dead end: also requesting the NEXT round's
 //       weights before computing a round -- two register sets, loop unrolled by two -- was 8-18 % slower at K=11008.)
-template <int NW, int CPL, int MAXS, int SPG, int XL, int BITS, bool RA = false, bool RA_BF16 = false>
+// MT (RA only): 16-row MFMA tiles per block, M <= 16*MT.  Every B fragment built from a packed word is used MT times, so the
+//       per-weight VALU work is amortised over up to 64 rows; each k-step holds MT x 16 B of activations per lane.
+template <int NW, int CPL, int MAXS, int SPG, int XL, int BITS, bool RA = false, bool RA_BF16 = false, int MT = 1>
 // (second launch-bound = minimum waves per SIMD: the 8-wave 64-column slab variant sits right at the 128-register edge
 //  that lets two blocks share a CU -- 130 registers halve its occupancy: gate/up 13.7 -> 15.0 us)
 __global__ __launch_bounds__(NW * 64, (NW == 8 && CPL == 4 && SPG == 4 && !RA) ? 4 : 1) void strip_kernel(const StripParams p) {
   static_assert(BITS == 4 || (BITS == 3 && CPL == 1), "3-bit strips are 16 columns wide");
   static_assert(!RA || MAXS == 8, "register-A rounds are 8 k-steps");
+  static_assert(MT == 1 || (RA && CPL == 1), "several row tiles: register-A, 16-column strips");
   constexpr int NG = MAXS / SPG;   // groups per round (MAXS is a multiple of SPG; rounds start on a group boundary)
   constexpr int TN = 16 * CPL;     // columns per block
   constexpr int GL = 4 * SPG;      // lanes (16-byte chunks) per group in the staging pass: 8 or 16
@@ -176,9 +179,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && CPL == 4 && SPG == 4 && !RA) ?
   };
   if (!RA && XL > 2) stage_x();
 
-  float4_t yacc[CPL];
+  float4_t yacc[MT][CPL];
 #pragma unroll
-  for (int c = 0; c < CPL; ++c) yacc[c] = float4_t{0.f, 0.f, 0.f, 0.f};
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) yacc[mt][c] = float4_t{0.f, 0.f, 0.f, 0.f};
   const uint32_t mask_lo = nib_mask_vgpr();  // 0x000f000f
   const uint32_t mask_hi = mask_lo << 4;     // 0x00f000f0
   // 3-bit field masks, derived from the opaque VGPR so hipcc can fuse each (x & m) | magic into one v_and_or_b32
@@ -204,7 +209,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && CPL == 4 && SPG == 4 && !RA) ?
   const uint32_t zsel_p = (zk == ZK_PACKED) ? 0xffffffffu : 0u, zsel_h = (zk == ZK_F16) ? 0xffffffffu : 0u;
   const uint32_t zsel_s = (zk == ZK_SYM) ? __builtin_bit_cast(uint32_t, (float)(1 << (BITS - 1))) : 0u;
   // RA: this lane's activation row (MFMA row i; rows >= M re-read row M-1, their outputs are never stored), k-slot 8g
-  const uint16_t *xrow_ra = (const uint16_t *)p.x + (size_t)min(i, M - 1) * p.K + 8 * g;
+  const uint16_t *xrow_ra[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) xrow_ra[mt] = (const uint16_t *)p.x + (size_t)min(16 * mt + i, M - 1) * p.K + 8 * g;
   // constant B fragments: all ones, and the per-slot multipliers that undo the staged divisors (4 bits: x16 on the odd
   // pairs; 3 bits: 2,1 | 16,8 | 128,64 | 1,1)
   const half8_t b_ones = {(half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f};
@@ -233,10 +240,12 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && CPL == 4 && SPG == 4 && !RA) ?
       zraw[j][1] = (CPL == 4) ? zbase[(size_t)G * zmul + zoff + zoff2] : 0u;
     }
     // ---- 2b. RA: this round's activation fragments, raw (16 B per k-step; L2-resident, so they land before the weights)
-    uint4_t xq[RA ? MAXS : 1];
+    uint4_t xq[RA ? MAXS : 1][MT];
     if constexpr (RA) {
 #pragma unroll
-      for (int s = 0; s < MAXS; ++s) xq[s] = *(const uint4_t *)(xrow_ra + 32 * min(base + s, tmax));
+      for (int s = 0; s < MAXS; ++s)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) xq[s][mt] = *(const uint4_t *)(xrow_ra[mt] + 32 * min(base + s, tmax));
     }
     // ---- 3. every weight load of this round: exactly MAXS loads, rows clamped into the matrix;
     //         address = wave-uniform row base (SALU) + one per-lane 32-bit offset -------------------------------------
@@ -266,36 +275,39 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && CPL == 4 && SPG == 4 && !RA) ?
     // ---- 5. straight-line: raw-magic B fragments -> MFMA; one fp32 correction per group ----------------------------------
     const half_t *xr = xlane + 32 * (r * MAXS);
     const float2_t *sxr = sxs + (size_t)(r * NG) * 16 + 4 * g;  // (Sx, Sx') of rows 4g..4g+3
-    float4_t gacc[CPL];
-    float4_t g_ones = {0.f, 0.f, 0.f, 0.f}, g_sx = {0.f, 0.f, 0.f, 0.f};  // RA: 1024-offset sum and plain sum of x, per group
+    float4_t gacc[MT][CPL];
+    float4_t g_ones[MT], g_sx[MT];  // RA: 1024-offset sum and plain sum of x, per group
 #pragma unroll
     for (int s = 0; s < MAXS; ++s) {
-      half8_t av;
+      half8_t av[MT];
       if constexpr (RA) {
         // k-steps past this wave's chunk (padding of the last round) or past K contribute nothing: zero multipliers
         const bool valid = (r * MAXS + s < p.spw) && (base + s <= tmax);
         const half_t one = valid ? (half_t)1.f : (half_t)0.f;
-        half8_t xv;  // bf16 activations: compile-time variant (a runtime branch per k-step would split the straight-line body)
-        if constexpr (RA_BF16) xv = bf16x8_to_h8(xq[s]); else xv = __builtin_bit_cast(half8_t, xq[s]);
-        if constexpr (BITS == 4) {
-          const half8_t pv = a_perm_04152637(xv);
-          const half_t sixteenth = valid ? (half_t)0.0625f : (half_t)0.f;
-          const half2_t q0 = half2_t{pv[0], pv[1]} * half2_t{one, one}, q1 = half2_t{pv[2], pv[3]} * half2_t{sixteenth, sixteenth};
-          const half2_t q2 = half2_t{pv[4], pv[5]} * half2_t{one, one}, q3 = half2_t{pv[6], pv[7]} * half2_t{sixteenth, sixteenth};
-          av = half8_t{q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, q3.x, q3.y};
-        } else {
-          const half8_t pv = __builtin_shufflevector(xv, xv, 0, 5, 1, 6, 2, 7, 3, 4);
-          const half2_t q0 = half2_t{pv[0], pv[1]} * (half2_t{(half_t)0.5f, (half_t)1.f} * half2_t{one, one});
-          const half2_t q1 = half2_t{pv[2], pv[3]} * (half2_t{(half_t)0.0625f, (half_t)0.125f} * half2_t{one, one});
-          const half2_t q2 = half2_t{pv[4], pv[5]} * (half2_t{(half_t)0.0078125f, (half_t)0.015625f} * half2_t{one, one});
-          const half2_t q3 = half2_t{pv[6], pv[7]} * half2_t{one, one};
-          av = half8_t{q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, q3.x, q3.y};
-        }
         const float4_t zero4 = {0.f, 0.f, 0.f, 0.f};
-        g_ones = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, b_ones, (s % SPG == 0) ? zero4 : g_ones, 0, 0, 0);
-        g_sx = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, b_mult, (s % SPG == 0) ? zero4 : g_sx, 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          half8_t xv;  // bf16 activations: compile-time variant (a runtime branch per k-step would split the straight-line body)
+          if constexpr (RA_BF16) xv = bf16x8_to_h8(xq[s][mt]); else xv = __builtin_bit_cast(half8_t, xq[s][mt]);
+          if constexpr (BITS == 4) {
+            const half8_t pv = a_perm_04152637(xv);
+            const half_t sixteenth = valid ? (half_t)0.0625f : (half_t)0.f;
+            const half2_t q0 = half2_t{pv[0], pv[1]} * half2_t{one, one}, q1 = half2_t{pv[2], pv[3]} * half2_t{sixteenth, sixteenth};
+            const half2_t q2 = half2_t{pv[4], pv[5]} * half2_t{one, one}, q3 = half2_t{pv[6], pv[7]} * half2_t{sixteenth, sixteenth};
+            av[mt] = half8_t{q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, q3.x, q3.y};
+          } else {
+            const half8_t pv = __builtin_shufflevector(xv, xv, 0, 5, 1, 6, 2, 7, 3, 4);
+            const half2_t q0 = half2_t{pv[0], pv[1]} * (half2_t{(half_t)0.5f, (half_t)1.f} * half2_t{one, one});
+            const half2_t q1 = half2_t{pv[2], pv[3]} * (half2_t{(half_t)0.0625f, (half_t)0.125f} * half2_t{one, one});
+            const half2_t q2 = half2_t{pv[4], pv[5]} * (half2_t{(half_t)0.0078125f, (half_t)0.015625f} * half2_t{one, one});
+            const half2_t q3 = half2_t{pv[6], pv[7]} * half2_t{one, one};
+            av[mt] = half8_t{q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, q3.x, q3.y};
+          }
+          g_ones[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[mt], b_ones, (s % SPG == 0) ? zero4 : g_ones[mt], 0, 0, 0);
+          g_sx[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[mt], b_mult, (s % SPG == 0) ? zero4 : g_sx[mt], 0, 0, 0);
+        }
       } else {
-        av = *(const half8_t *)(xr + 32 * s);
+        av[0] = *(const half8_t *)(xr + 32 * s);
       }
 #pragma unroll
       for (int c = 0; c < CPL; ++c) {
@@ -317,20 +329,25 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && CPL == 4 && SPG == 4 && !RA) ?
           b3 = as_h2(((f << 4) & m3e) | lo34);
         }
         const half8_t bf = {b0.x, b0.y, b1.x, b1.y, b2.x, b2.y, b3.x, b3.y};
-        const float4_t cin = (s % SPG == 0) ? float4_t{0.f, 0.f, 0.f, 0.f} : gacc[c];
-        gacc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bf, cin, 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const float4_t cin = (s % SPG == 0) ? float4_t{0.f, 0.f, 0.f, 0.f} : gacc[mt][c];
+          gacc[mt][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[mt], bf, cin, 0, 0, 0);
+        }
       }
       if (s % SPG == SPG - 1) {
         const int j = s / SPG;
-        float sxv[4], big[4];
+        float sxv[MT][4], big[MT][4];
         if constexpr (RA) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) { sxv[q] = g_sx[q]; big[q] = 1024.f * g_ones[q]; }
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { sxv[mt][q] = g_sx[mt][q]; big[mt][q] = 1024.f * g_ones[mt][q]; }
         } else {
           const float4_t s01 = *(const float4_t *)(sxr + j * 16);      // (Sx,Sx') rows 4g, 4g+1
           const float4_t s23 = *(const float4_t *)(sxr + j * 16 + 2);  // rows 4g+2, 4g+3
-          sxv[0] = s01[0]; sxv[1] = s01[2]; sxv[2] = s23[0]; sxv[3] = s23[2];
-          big[0] = 1024.f * s01[1]; big[1] = 1024.f * s01[3]; big[2] = 1024.f * s23[1]; big[3] = 1024.f * s23[3];
+          sxv[0][0] = s01[0]; sxv[0][1] = s01[2]; sxv[0][2] = s23[0]; sxv[0][3] = s23[2];
+          big[0][0] = 1024.f * s01[1]; big[0][1] = 1024.f * s01[3]; big[0][2] = 1024.f * s23[1]; big[0][3] = 1024.f * s23[3];
         }
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
@@ -344,10 +361,12 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && CPL == 4 && SPG == 4 && !RA) ?
           const float zfc = __builtin_bit_cast(float, (__builtin_bit_cast(uint32_t, zp) & zsel_p) | (__builtin_bit_cast(uint32_t, zh) & zsel_h) | zsel_s);
           const float sfc = (float)sc[j][c];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const float corr = __builtin_fmaf(zfc, sxv[q], big[q]);
-            yacc[c][q] = __builtin_fmaf(sfc, gacc[c][q] - corr, yacc[c][q]);
-          }
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float corr = __builtin_fmaf(zfc, sxv[mt][q], big[mt][q]);
+              yacc[mt][c][q] = __builtin_fmaf(sfc, gacc[mt][c][q] - corr, yacc[mt][c][q]);
+            }
         }
       }
     }
@@ -355,13 +374,15 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && CPL == 4 && SPG == 4 && !RA) ?
 
   // ---- 6. reduce the NW waves' partials through LDS: red[wave][row][col] -------------------------------------------
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int row = 4 * g + r;
-    if (row < M) {
+  for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int c = 0; c < CPL; ++c) red[(wave * M + row) * TN + i * CPL + c] = yacc[c][r];
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * mt + 4 * g + r;
+      if (row < M) {
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) red[(wave * M + row) * TN + i * CPL + c] = yacc[mt][c][r];
+      }
     }
-  }
   __syncthreads();
   for (int e = threadIdx.x; e < M * TN; e += NW * 64) {
     const int row = e / TN, col = e - row * TN;
@@ -377,14 +398,14 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && CPL == 4 && SPG == 4 && !RA) ?
   }
 }
 
-template <int NW, int CPL, int MAXS, int SPG, int XL, int BITS = 4, bool RA = false, bool RA_BF16 = false>
+template <int NW, int CPL, int MAXS, int SPG, int XL, int BITS = 4, bool RA = false, bool RA_BF16 = false, int MT = 1>
 static int launch_strip_t(const StripParams &p, int grid, size_t lds, hipStream_t stream) {
   static bool attr_done = false;
   if (!attr_done) {
-    QLLM_HIP_CHECK(hipFuncSetAttribute((const void *)strip_kernel<NW, CPL, MAXS, SPG, XL, BITS, RA, RA_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    QLLM_HIP_CHECK(hipFuncSetAttribute((const void *)strip_kernel<NW, CPL, MAXS, SPG, XL, BITS, RA, RA_BF16, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
-  hipLaunchKernelGGL((strip_kernel<NW, CPL, MAXS, SPG, XL, BITS, RA, RA_BF16>), dim3(grid), dim3(NW * 64), lds, stream, p);
+  hipLaunchKernelGGL((strip_kernel<NW, CPL, MAXS, SPG, XL, BITS, RA, RA_BF16, MT>), dim3(grid), dim3(NW * 64), lds, stream, p);
   QLLM_HIP_CHECK(hipGetLastError());
   return QLLM_OK;
 }
@@ -398,6 +419,11 @@ static int strip_xl(int nw, int M, int spw, int cpl) { return (M * strip_spw_pad
 
 template <int SPG, bool BF>
 static int launch_strip_ra(const StripParams &p, int grid, size_t lds, hipStream_t stream) {
+  if (p.M > 16) {  // several 16-row tiles per block: 16-column strips, 8-wave blocks (register budget)
+    if (p.bits == 3)
+      return p.M > 32 ? launch_strip_t<8, 1, 8, SPG, 1, 3, true, BF, 4>(p, grid, lds, stream) : launch_strip_t<8, 1, 8, SPG, 1, 3, true, BF, 2>(p, grid, lds, stream);
+    return p.M > 32 ? launch_strip_t<8, 1, 8, SPG, 1, 4, true, BF, 4>(p, grid, lds, stream) : launch_strip_t<8, 1, 8, SPG, 1, 4, true, BF, 2>(p, grid, lds, stream);
+  }
   if (p.bits == 3) return launch_strip_t<16, 1, 8, SPG, 1, 3, true, BF>(p, grid, lds, stream);
   if (p.cpl == 4)
     return p.nw == 8 ? launch_strip_t<8, 4, 8, SPG, 1, 4, true, BF>(p, grid, lds, stream)

@@ -49,7 +49,7 @@ class HipForwardMixin:
         return self._desc
 
     def decode_descriptor(self, act_order_g_idx=None, add_zero_bias: int = 0):
-        """Descriptor the decode-sized (M <= 16) kernels should stream.  Default: the module's own buffers."""
+        """Descriptor the decode-sized (M <= 64) kernels should stream.  Default: the module's own buffers."""
         return self._descriptor(act_order_g_idx, add_zero_bias)
 
     def _hip_linear(self, x: torch.Tensor, act_order_g_idx=None, add_zero_bias: int = 0) -> torch.Tensor:
@@ -60,7 +60,7 @@ class HipForwardMixin:
         x2d = x.reshape(-1, x.shape[-1])
         if not x2d.is_contiguous():
             x2d = x2d.contiguous()
-        if x2d.shape[0] <= 16:
+        if x2d.shape[0] <= 64:  # the full-K strip kernels (M <= 64) stream the row-stream view
             w = self.decode_descriptor(act_order_g_idx, add_zero_bias)
         else:
             w = self._descriptor(act_order_g_idx, add_zero_bias)
