@@ -263,14 +263,14 @@ def main():
         for tag, cls, act in (("awq", WQLinear_GEMM, False), ("gptq_actorder", QuantLinearGPTQ, True)):
             ps = Stack(cls, 4, dev, seed=99, act_order=act)
             xp = torch.randn(2048, HIDDEN, device=dev, dtype=torch.float16)
-            ps.forward(xp)
-            ms = time_events(lambda: ps.forward(xp), 5)
+            gp, _ = capture(lambda: ps.forward(xp))  # graph replay, like the headline leg: kernel time, not Python / allocator time
+            ms = time_events(gp.replay, 10)
+            del gp
             tf = flops_per_pass(4, 2048) / ms / 1e9
             extra[f"prefill_m2048_{tag}"] = {"ms_per_4_layers": round(ms, 3), "TFLOPs": round(tf, 1),
                                              "frac_of_mfma_peak": round(tf / MFMA_PEAK_TFLOPS, 4)}
             del ps
-        # BASELINE configs[3]: HQQ g64 fp16 zeros, batch 16, alternating 4-bit / 3-bit layers (3-bit has no fused kernel
-        # yet: library dequant + GEMM).  Two decoder layers' 7 linears each.
+        # BASELINE configs[3]: HQQ g64 fp16 zeros, batch 16, alternating 4-bit / 3-bit layers.  Two decoder layers' 7 linears each.
         from qllm_amd.modeling.q_layers import QuantLinearHQQ
         hq = []
         for li, bits in enumerate((4, 3)):
@@ -283,9 +283,9 @@ def main():
         xs16 = {K: torch.randn(16, K, device=dev, dtype=torch.float16) for K in (HIDDEN, INTER)}
         for bits_sel, tag in ((4, "hqq_w4_g64_m16"), (3, "hqq_w3_g64_m16")):
             ls = [(l, K) for (l, K) in hq if l.bits == bits_sel]
-            for l, K in ls:
-                l(xs16[K])
-            ms = time_events(lambda: [l(xs16[K]) for l, K in ls], 10)
+            gh, _ = capture(lambda: [l(xs16[K]) for l, K in ls])
+            ms = time_events(gh.replay, 20)
+            del gh
             nbytes = sum(alg_bytes(l.infeatures, l.outfeatures, 16, 64, "f16") * bits_sel // 4 for l, _ in ls)
             extra[tag] = {"ms_per_layer": round(ms, 4), "GBps": round(nbytes / ms / 1e6, 1)}
         result["extra"] = extra
