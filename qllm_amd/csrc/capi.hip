@@ -303,7 +303,9 @@ int qllm_device_info(int device, qllm_device_info_t *out) {
 }
 
 size_t qllm_workspace_bytes(const qllm_weight_t *w, int32_t M) {
-  if (!w || M <= 0 || M > 64) return kCounterBytes;
+  if (!w || M <= 0) return kCounterBytes;
+  if (M > 64)  // prefill: fp32 partial tiles of the split-K GEMM (mid-size M only)
+    return kCounterBytes + align_up(gemm2_slab_bytes(M, w->N, gemm2_split_k(M, w->N, w->K)), 256);
   return kCounterBytes + align_up((size_t)skinny_max_split(M) * M * w->N * sizeof(float), 256);
 }
 
@@ -372,7 +374,21 @@ int qllm_linear_forward(const qllm_weight_t *w, const void *x, void *y, int32_t 
     p.n_groups = (w->K + w->group_size - 1) / w->group_size;
     p.raster = 0;
     p.stagger = 0;
-    if (gemm2_ok(p, w->layout)) return launch_gemm2(p, w->layout, (hipStream_t)stream);
+    p.split_k = 1;
+    p.slabs = nullptr;
+    p.counters = nullptr;
+    if (gemm2_ok(p, w->layout)) {
+      // split-K when the tiling leaves CUs idle and the caller's workspace can hold the partial tiles (else: no split)
+      const int S = gemm2_split_k(M, w->N, w->K);
+      const size_t need = kCounterBytes + gemm2_slab_bytes(M, w->N, S);
+      const int tiles = ((M + 255) / 256) * (w->N / 128);
+      if (S > 1 && workspace && workspace_bytes >= need && (uintptr_t)workspace % 256 == 0 && tiles <= (int)(kCounterBytes / sizeof(int))) {
+        p.split_k = S;
+        p.counters = (int *)workspace;
+        p.slabs = (float *)((char *)workspace + kCounterBytes);
+      }
+      return launch_gemm2(p, w->layout, (hipStream_t)stream);
+    }
     return launch_gemm(p, w->layout, (hipStream_t)stream);
   }
   return set_error(QLLM_ERR_UNSUPPORTED, "no fused kernel for bits=%d K=%d N=%d g=%d layout=%d act_order=%d; use qllm_dequant + GEMM",

@@ -65,12 +65,22 @@ __global__ __launch_bounds__(512) void gemm2_kernel(const GemmParams p) {
   const int wn = (BN == 256) ? (wave & 3) : (wave & 1);
 
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = p.N / BN;
-  const int nblk = tiles_m * tiles_n;
+  // split-K (p.split_k > 1, problems with fewer tiles than CUs): S consecutive block ids share an output tile and own
+  // consecutive K ranges; each writes its fp32 partial tile to a slab, the last to arrive sums them in fixed order
+  const int S = p.split_k;
+  const int nblk = tiles_m * tiles_n * S;
   int bid = blockIdx.x;
   {  // each XCD (block id % 8) walks a contiguous run of tiles, m fastest: neighbours share the weight panel
     const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, idx = bid / 8;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
+  const int ksplit = bid % S;
+  bid /= S;
+  const int tile_id = bid;
+  const int KT_all = p.K / BK;
+  const int KT_per = (KT_all + S - 1) / S;
+  const int KT0 = ksplit * KT_per;                       // first k-tile of this block
+  const int KT = max(0, min(KT_all, KT0 + KT_per) - KT0);  // its number of k-tiles (0: contributes a zero partial)
   // p.raster 0: m fastest (an XCD's run shares weight panels); 1: n fastest (an XCD's run shares activation rows:
   // 256 rows x K x 2 B = 2 MB per row block stays in its 4 MB L2 while the small packed weights stream)
   const int tm = p.raster ? (bid / tiles_n) : (bid % tiles_m);
@@ -83,7 +93,7 @@ __global__ __launch_bounds__(512) void gemm2_kernel(const GemmParams p) {
   constexpr int ASETS = (BN == 128) ? 2 : 1;
   uint4_t aset[ASETS][4];
   auto load_a = [&](int kt, uint4_t (&areg)[4]) {
-    const int ktc = min(kt, p.K / BK - 1);
+    const int ktc = min(KT0 + min(kt, max(KT, 1) - 1), KT_all - 1);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int c = tid + 512 * q, row = c >> 3, kc = c & 7;
@@ -128,9 +138,8 @@ __global__ __launch_bounds__(512) void gemm2_kernel(const GemmParams p) {
     uint32_t z;
   };
   BSet bset[2];
-  const int KT = p.K / BK;
   auto load_b = [&](int kt, BSet &bs) {
-    const int ktc = min(kt, KT - 1);  // past the end: harmless re-read, never used
+    const int ktc = min(KT0 + min(kt, max(KT, 1) - 1), KT_all - 1);  // past the end: harmless re-read, never used
 #pragma unroll
     for (int r = 0; r < WPT; ++r) {
       if constexpr (LAYOUT == 0)
@@ -316,6 +325,42 @@ __global__ __launch_bounds__(512) void gemm2_kernel(const GemmParams p) {
     }
   }
 
+  // ---- split-K: publish the fp32 partial tile; the last block to arrive sums the S partials in fixed order --------------
+  // Protocol as in skinny.hip (cdna_hip_programming.md, in-launch split-K): write-through (sc1) stores, every storing wave
+  // drains them, one relaxed agent-scope ticket per block, the last arriver reads with sc1 loads and re-arms the counter.
+  // Slab element (tile, split, wave, register r, lane): every store / load instruction of a wave covers 256 contiguous bytes.
+  if (S > 1) {
+    // (the ticket lives in the dynamic segment, past the epilogue's wave-private regions: a static __shared__ word on top of
+    //  the 160 KB dynamic maximum makes hipFuncSetAttribute fail)
+    int &s_ticket = *(int *)(smem + 8 * (16 * 72));
+    float *slab = p.slabs + ((size_t)tile_id * S + ksplit) * (size_t)(BM * BN) + (size_t)wave * (AM * 16 * 64) + lane;
+#pragma unroll
+    for (int a = 0; a < AM; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) st_sc1(slab + ((a * 4 + b) * 4 + r) * 64, acc[a][b][r]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) s_ticket = __hip_atomic_fetch_add(p.counters + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_ticket != S - 1) return;
+#pragma unroll
+    for (int a = 0; a < AM; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = float4_t{0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < S; ++s) {
+      const float *src = p.slabs + ((size_t)tile_id * S + s) * (size_t)(BM * BN) + (size_t)wave * (AM * 16 * 64) + lane;
+#pragma unroll
+      for (int a = 0; a < AM; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[a][b][r] += ld_sc1(src + ((a * 4 + b) * 4 + r) * 64);
+    }
+    if (tid == 0) __hip_atomic_store(p.counters + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+
   // ---- epilogue: + bias, round once, transpose through wave-private LDS, 16-byte row-contiguous stores ---------------
   half_t *ep = smem + wave * (16 * 72);  // 16 rows x 64 cols, row stride 72 halves (144 B: 16-byte aligned, bank-spread)
   float bv[4];
@@ -359,7 +404,7 @@ static int launch_gemm2_b(const GemmParams &p, hipStream_t stream) {
     QLLM_HIP_CHECK(hipFuncSetAttribute((const void *)gemm2_kernel<LAYOUT, BN, BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
-  const int tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
+  const int tiles = ((p.M + BM - 1) / BM) * (p.N / BN) * p.split_k;
   const size_t lds = (size_t)4 * kTile * sizeof(half_t);  // 128 KB (A 2 x 32 KB, B 2 x <= 32 KB)
   hipLaunchKernelGGL((gemm2_kernel<LAYOUT, BN, BF16>), dim3(tiles), dim3(512), lds, stream, p);
   QLLM_HIP_CHECK(hipGetLastError());
@@ -371,8 +416,23 @@ static int launch_gemm2_t(const GemmParams &p, hipStream_t stream) {
   return p.act_bf16 ? launch_gemm2_b<LAYOUT, BN, true>(p, stream) : launch_gemm2_b<LAYOUT, BN, false>(p, stream);
 }
 
+// split-K factor for a problem whose 256x128 tiling leaves CUs idle: the largest S <= 8 that still fits one round of blocks
+// (tiles * S <= CUs) and leaves every block >= 8 k-tiles; 1 otherwise.  A block's k-loop runs ~0.9 us per k-tile whatever the
+// occupancy, so M <= 1024 on 4096-wide layers is bound by the loop length, not by throughput.
+int gemm2_split_k(int M, int N, int K) {
+  static const char *e = getenv("QLLM_GEMM2_SPLITK");
+  if (e && e[0] == '0') return 1;
+  if (N % 128 != 0) return 1;
+  const int tiles = ((M + 255) / 256) * (N / 128), kt = K / 64;
+  int s = 1;
+  while (s < 8 && tiles * (s * 2) <= kNumCU && kt / (s * 2) >= 8) s *= 2;
+  return s;
+}
+size_t gemm2_slab_bytes(int M, int N, int S) { return S > 1 ? (size_t)((M + 255) / 256) * (N / 128) * S * 256 * 128 * sizeof(float) : 0; }
+
 int launch_gemm2(const GemmParams &p_in, int layout, hipStream_t stream) {
   GemmParams p = p_in;
+  if (p.split_k < 1) p.split_k = 1;
   static int raster = getenv("QLLM_GEMM2_RASTER") ? atoi(getenv("QLLM_GEMM2_RASTER")) : 1;  // measured +2-3 %
   p.raster = raster;
   static int stagger = getenv("QLLM_GEMM2_STAGGER") ? atoi(getenv("QLLM_GEMM2_STAGGER")) : 0;  // measured: 771 vs 808 TFLOP/s with it on
@@ -382,7 +442,8 @@ int launch_gemm2(const GemmParams &p_in, int layout, hipStream_t stream) {
   const int tiles256 = ((p.M + 255) / 256) * (p.N / 256);
   const int rounds = (tiles256 + kNumCU - 1) / kNumCU;
   const bool good256 = (p.N % 256 == 0) && tiles256 >= 0.85 * rounds * kNumCU;
-  const int bn = force_bn ? force_bn : (good256 ? 256 : 128);
+  int bn = force_bn ? force_bn : (good256 ? 256 : 128);
+  if (p.split_k > 1) bn = 128;  // the slab layout is the 256x128 tile's
   if (layout == QLLM_LAYOUT_AWQ_GEMM) return bn == 256 ? launch_gemm2_t<1, 256>(p, stream) : launch_gemm2_t<1, 128>(p, stream);
   return bn == 256 ? launch_gemm2_t<0, 256>(p, stream) : launch_gemm2_t<0, 128>(p, stream);
 }

@@ -94,11 +94,16 @@ struct GemmParams {
   int M, K, N, group_size, gs_shift, add_zero_bias, zero_kind, act_bf16, n_groups;
   int raster;   // gemm2 tile order: 0 = m fastest, 1 = n fastest inside an XCD's run
   int stagger;  // gemm2: waves 4-7 run their VALU phase before their MFMA phase
+  int split_k;      // gemm2: blocks per output tile along K (1 = none)
+  float *slabs;     // gemm2 split-K: [tiles][split_k][256 x 128] fp32 partial tiles
+  int *counters;    // gemm2 split-K: one arrival counter per output tile (zero before and after the launch)
 };
 int launch_gemm(const GemmParams &p, int layout, hipStream_t stream);
 
 // ---- gemm2.hip (256x256 tile; fp16 activations, trivial groups, N % 256 == 0) -------------------------------------
 bool gemm2_ok(const GemmParams &p, int layout);
+int gemm2_split_k(int M, int N, int K);
+size_t gemm2_slab_bytes(int M, int N, int S);
 int launch_gemm2(const GemmParams &p, int layout, hipStream_t stream);
 
 }  // namespace qllm

@@ -43,7 +43,9 @@ def workspace(device: torch.device, nbytes: int) -> torch.Tensor:
     key = (device.index if device.index is not None else torch.cuda.current_device(), _stream_ptr())
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
-        size = max(int(nbytes), 1 << 20)
+        # 64 MB up front covers every configuration of the Llama-class shapes (largest: 32 MB of split-K partial tiles):
+        # growing later would move the buffer under hipGraphs captured with the old pointer
+        size = max(int(nbytes), 64 << 20)
         ws = torch.zeros(size, dtype=torch.uint8, device=device)
         _workspaces[key] = ws
     return ws
