@@ -112,6 +112,25 @@ class QuantLinearORT(nn.Module, CompressWeight, HipForwardMixin):
     # ---- forward: row-stream view of the blob, cached ---------------------------------------------------------------------
     _perm = None
 
+    def row_stream_view(self):
+        """(qweight i32 [K/8, N], scales f16 [G, N], zeros f16 [G, N]): the blob re-read as a row-stream (GPTQ/HQQ-style)
+        layer.  Pure tensor views / transposes, any device; the integers are untouched."""
+        n, k, g = self.outfeatures, self.infeatures, self.groupsize
+        if self.bits != 4:
+            raise NotImplementedError("the ORT blob layout is 4-bit only")
+        if k % g != 0 or k % 8 != 0:
+            raise RuntimeError(f"QuantLinearORT needs in_features % groupsize == 0 (K={k}, g={g})")
+        groups = k // g
+        # row n of the blob as K/8 little-endian words == column n of a GPTQ row-stream qweight
+        qw = self.qweight.reshape(n, k // 2).view(torch.int32).T.contiguous()
+        scales = self._f16(self.scales).reshape(n, groups).T.contiguous()
+        if self.qzeros.dtype == torch.uint8:
+            zb = self.qzeros.reshape(n, -1)
+            zeros = torch.stack([zb & 0x0F, zb >> 4], dim=-1).reshape(n, -1)[:, :groups].T.to(torch.float16).contiguous()
+        else:
+            zeros = self._f16(self.qzeros).reshape(n, -1)[:, :groups].T.contiguous()
+        return qw, scales, zeros
+
     def _layout_name(self):
         return "HQQ"  # the cached view carries un-packed fp16 zero points [G, N]
 
@@ -123,18 +142,9 @@ class QuantLinearORT(nn.Module, CompressWeight, HipForwardMixin):
             if self.bits != 4:
                 raise NotImplementedError("the ORT blob layout is 4-bit only")
             n, k, g = self.outfeatures, self.infeatures, self.groupsize
-            if k % g != 0 or k % 8 != 0:
-                raise RuntimeError(f"QuantLinearORT needs in_features % groupsize == 0 (K={k}, g={g})")
-            groups = k // g
+            groups = k // g if g else 0
             dev = self.qweight.device
-            # row n of the blob as K/8 little-endian words == column n of a GPTQ row-stream qweight
-            qw = self.qweight.reshape(n, k // 2).view(torch.int32).T.contiguous()
-            scales = self._f16(self.scales).reshape(n, groups).T.contiguous()
-            if self.qzeros.dtype == torch.uint8:
-                zb = self.qzeros.reshape(n, -1)
-                zeros = torch.stack([zb & 0x0F, zb >> 4], dim=-1).reshape(n, -1)[:, :groups].T.to(torch.float16).contiguous()
-            else:
-                zeros = self._f16(self.qzeros).reshape(n, -1)[:, :groups].T.contiguous()
+            qw, scales, zeros = self.row_stream_view()
             self._perm = None
             if self.act_order is None:
                 self.act_order = bool(self.g_idx[:32].sum().item() != 0)

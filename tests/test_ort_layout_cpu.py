@@ -95,3 +95,27 @@ def test_module_contract_and_dispatch():
         QuantLinearORT(9, 128, 256, 64, False)
     with pytest.raises(RuntimeError):  # no CPU forward
         layer(torch.zeros(1, 512, dtype=torch.float16))
+
+
+@pytest.mark.parametrize("name", ort_golden_names())
+def test_row_stream_view_is_the_same_layer(name):
+    """The cached view the fused kernels stream (blob rows as 32-bit words, transposed) holds exactly the layer's integers,
+    scales and zero points in the GPTQ/HQQ row-stream arrangement."""
+    g = load_golden(name)
+    layer = _layer_from_golden(g)
+    qw, scales, zeros = layer.row_stream_view()
+    K, N, gs = g["K"], g["N"], g["groupsize"]
+    assert qw.dtype == torch.int32 and tuple(qw.shape) == (K // 8, N)
+    assert np.array_equal(O.gptq_int_weight(qw.numpy(), 4, K), g["q"])
+    assert np.array_equal(_bits(scales.numpy()), _bits(g["scales"]))
+    assert np.array_equal(zeros.numpy().astype(np.float32), g["zeros"].astype(np.float32))
+    # HQQ-form dequant of the view vs the reference's ORT W: same values up to the different rounding sequence
+    gi = g["g_idx"].astype(np.int64)
+    w_view = O.dequant("HQQ", qw.numpy(), scales.numpy(), zeros.numpy(), None, 4, gs, K)  # trivial groups
+    if not O.ort_is_act_order(g["g_idx"]):
+        ref = g["W_unpack"].T.astype(np.float32)
+        assert np.max(np.abs(w_view.astype(np.float32) - ref)) <= 3 * 2.0 ** -10 * np.max(np.abs(ref)) / 8 + 1e-4
+        y = O.matmul_f16(g["x"], w_view, g["bias"])
+        assert O.rel_err(y, g["y"]) <= 2e-3
+    else:
+        assert gi.max() == K // gs - 1
