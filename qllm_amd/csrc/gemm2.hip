@@ -392,7 +392,10 @@ __global__ __launch_bounds__(512) void gemm2_kernel(const GemmParams p) {
 bool gemm2_ok(const GemmParams &p, int layout) {
   static const char *e = getenv("QLLM_GEMM2");
   if (e && e[0] == '0') return false;
-  if (p.g_idx || p.K % 64 != 0 || p.N % 128 != 0 || p.M < 192) return false;
+  // below 192 rows a 256-row tile wastes > 25 % of its MFMAs -- but with split-K the k-loop length, not the MFMA count, sets
+  // the time at these sizes; QLLM_GEMM2_MIN_M=65 is the first experiment of the next round (untested default stays 192)
+  static const int min_m = getenv("QLLM_GEMM2_MIN_M") ? atoi(getenv("QLLM_GEMM2_MIN_M")) : 192;
+  if (p.g_idx || p.K % 64 != 0 || p.N % 128 != 0 || p.M < min_m) return false;
   return p.group_size % 32 == 0 && p.gs_shift >= 0;  // one group per thread per k-tile; power-of-two group size
 }
 
