@@ -24,7 +24,7 @@ class QuantConfig:
     """quant_config.json / quantize_config.json / config.json["quantization_config"] (config.py:81-119)."""
     bits: int = 4
     group_size: int = 128
-    version: str = "GPTQ"            # pack mode: GPTQ | GEMM | HQQ
+    version: str = "GPTQ"            # pack mode: GPTQ | GEMM | HQQ | ORT
     quant_method: str = "gptq"
     compatible_with_autogptq: bool = False
     by_layer: Dict[str, dict] = field(default_factory=dict)  # quant_config_by_layer.json (mixed precision)

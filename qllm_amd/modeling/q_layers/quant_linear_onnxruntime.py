@@ -103,6 +103,26 @@ class QuantLinearORT(nn.Module, CompressWeight, HipForwardMixin):
         self.scales = scales_ng.reshape(-1).contiguous()
         self._desc = None
 
+    # integer-domain accessors (used by qllm_amd.repack; same names as CompressWeight's)
+    def unpack_qweight(self, device):
+        """-> q[K, N] int32 in natural order."""
+        qw = self.qweight.to(device)
+        n = qw.shape[0]
+        return torch.stack([qw & 0x0F, qw >> 4], dim=-1).reshape(n, -1).T.contiguous().to(torch.int32)
+
+    def unpack_qzeros(self, device):
+        """-> zeros[G, N]: int32 for packed zero points, the stored floating dtype otherwise."""
+        groups = self.infeatures // self.groupsize
+        qz = self.qzeros.to(device)
+        if qz.dtype != torch.uint8:
+            return qz.reshape(self.outfeatures, -1)[:, :groups].T.contiguous()
+        zb = qz.reshape(self.outfeatures, -1)
+        return torch.stack([zb & 0x0F, zb >> 4], dim=-1).reshape(self.outfeatures, -1)[:, :groups].T.contiguous().to(torch.int32)
+
+    def scales_gn(self):
+        """scales as [G, N] (the other layers' arrangement)."""
+        return self.scales.reshape(self.outfeatures, -1).T.contiguous()
+
     def unpack(self):
         """-> (W[N,K], scales[G,N], zeros[G,N]) on CPU, like the reference (:156-167)."""
         w, zeros, scales = dequantize_blockwise_4bits(self.qweight, self.scales, self.qzeros, self.g_idx,

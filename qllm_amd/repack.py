@@ -8,11 +8,11 @@ from __future__ import annotations
 
 import torch
 
-from .modeling.q_layers import QuantLinearGPTQ, QuantLinearHQQ, WQLinear_GEMM
+from .modeling.q_layers import QuantLinearGPTQ, QuantLinearHQQ, QuantLinearORT, WQLinear_GEMM
 from .modeling.q_layers.compress_weight import pack_bitstream
 from .utils import modelutils
 
-_CLS = {"GPTQ": QuantLinearGPTQ, "GEMM": WQLinear_GEMM, "AWQ": WQLinear_GEMM, "HQQ": QuantLinearHQQ}
+_CLS = {"GPTQ": QuantLinearGPTQ, "GEMM": WQLinear_GEMM, "AWQ": WQLinear_GEMM, "HQQ": QuantLinearHQQ, "ORT": QuantLinearORT}
 
 
 def repack_layer(layer, new_pack_mode: str):
@@ -24,11 +24,23 @@ def repack_layer(layer, new_pack_mode: str):
     dev = layer.qweight.device
     if target is WQLinear_GEMM and layer.bits != 4:
         raise NotImplementedError("AWQ GEMM layout is 4-bit only")
+    if (target is QuantLinearORT or isinstance(layer, QuantLinearORT)) and layer.bits != 4:
+        raise NotImplementedError("the ORT blob layout is 4-bit only")
     q = layer.unpack_qweight(dev)          # [K, N] int32, natural order
-    z = layer.unpack_qzeros(dev)           # [G, N] int (GPTQ/AWQ) or fp16 (HQQ)
+    z = layer.unpack_qzeros(dev)           # [G, N] int (GPTQ/AWQ/ORT) or fp16 (HQQ, ORT with real-valued zeros)
+    scales_gn = layer.scales_gn() if isinstance(layer, QuantLinearORT) else layer.scales  # [G, N]
     new = target(layer.bits, layer.groupsize, layer.infeatures, layer.outfeatures, layer.bias is not None,
                  dtype=layer.scales.dtype)
     new.g_idx = layer.g_idx.clone()
+    if target is QuantLinearORT:
+        if layer.infeatures % layer.groupsize != 0:
+            raise ValueError("the ORT blob layout needs in_features % groupsize == 0")
+        new.scales = scales_gn.clone()     # pack_on_device flattens it to [N*G]
+        zt = z if z.dtype.is_floating_point else z.to(torch.int32)
+        new.pack_on_device(q, zt.to(new.scales.dtype) if z.dtype.is_floating_point else zt)
+        if layer.bias is not None:
+            new.bias = layer.bias.clone()
+        return new.to(dev)
     if target is WQLinear_GEMM:
         k = torch.arange(layer.infeatures, device=layer.g_idx.device) // layer.groupsize
         if not torch.equal(layer.g_idx.to(torch.int64), k):
@@ -47,7 +59,7 @@ def repack_layer(layer, new_pack_mode: str):
     else:  # HQQ: un-packed zeros in the layer dtype
         new.qweight = _pack_rows(q, layer.bits)
         new.qzeros = z.to(layer.scales.dtype)
-    new.scales = layer.scales.clone()
+    new.scales = scales_gn.clone()
     if layer.bias is not None:
         new.bias = layer.bias.clone()
     return new.to(dev)
@@ -67,7 +79,7 @@ def _awq_index(n, dev):
 
 def repack_to_new_mode(model: torch.nn.Module, new_pack_mode: str):
     """Model-level conversion (auto_model_quantization.py:115-147)."""
-    layers = modelutils.find_layers(model, [QuantLinearGPTQ, QuantLinearHQQ, WQLinear_GEMM])
+    layers = modelutils.find_layers(model, [QuantLinearGPTQ, QuantLinearHQQ, QuantLinearORT, WQLinear_GEMM])
     for name, layer in layers.items():
         modelutils.set_op_by_name(model, name, repack_layer(layer, new_pack_mode))
     if hasattr(model, "quant_config"):

@@ -119,3 +119,80 @@ def test_row_stream_view_is_the_same_layer(name):
         assert O.rel_err(y, g["y"]) <= 2e-3
     else:
         assert gi.max() == K // gs - 1
+
+
+def test_repack_between_ort_and_the_other_layouts_is_integer_exact():
+    from qllm_amd.repack import repack_layer
+    from qllm_amd.modeling.q_layers import QuantLinearGPTQ, QuantLinearHQQ, QuantLinearORT
+    g = load_golden("ort_w4_g128_bias")
+    ort = _layer_from_golden(g)
+    gptq = repack_layer(ort, "GPTQ")
+    assert isinstance(gptq, QuantLinearGPTQ)
+    eq, ez = O.pack_gptq(g["q"], g["zeros"], 4)
+    assert np.array_equal(gptq.qweight.numpy(), eq) and np.array_equal(gptq.qzeros.numpy(), ez)
+    assert np.array_equal(_bits(gptq.scales.numpy()), _bits(g["scales"])) and torch.equal(gptq.bias, ort.bias)
+    back = repack_layer(gptq, "ORT")
+    assert isinstance(back, QuantLinearORT)
+    assert torch.equal(back.qweight, ort.qweight) and torch.equal(back.qzeros, ort.qzeros) and torch.equal(back.scales, ort.scales)
+    awq = repack_layer(ort, "GEMM")
+    aq, az = O.pack_awq(g["q"], g["zeros"])
+    assert np.array_equal(awq.qweight.numpy(), aq) and np.array_equal(awq.qzeros.numpy(), az)
+    # real-valued zero points travel between HQQ and ORT
+    gf = load_golden("ort_w4_g64_f16zeros")
+    ortf = _layer_from_golden(gf)
+    hqq = repack_layer(ortf, "HQQ")
+    assert isinstance(hqq, QuantLinearHQQ) and np.array_equal(_bits(hqq.qzeros.numpy()), _bits(gf["zeros"]))
+    assert np.array_equal(O.gptq_int_weight(hqq.qweight.numpy(), 4, gf["K"]), gf["q"])
+    backf = repack_layer(hqq, "ORT")
+    assert torch.equal(backf.qweight, ortf.qweight) and np.array_equal(_bits(backf.qzeros.numpy()), _bits(ortf.qzeros.numpy()))
+    with pytest.raises(ValueError):
+        repack_layer(ortf, "GPTQ")  # fp16 zeros cannot be stored as packed GPTQ zeros
+
+
+def test_ort_checkpoint_round_trip_and_model_repack(tmp_path):
+    """version=ORT checkpoints load into QuantLinearORT (uint8 blobs survive safetensors) and convert to the other modes."""
+    import json
+    import os
+    import transformers
+    from qllm_amd.modeling import base
+    from qllm_amd.modeling.q_layers import QuantLinearGPTQ, QuantLinearORT
+    from qllm_amd.repack import repack_to_new_mode
+    from qllm_amd.utils import modelutils
+    cfg = transformers.LlamaConfig(hidden_size=256, intermediate_size=512, num_hidden_layers=1, num_attention_heads=4,
+                                   num_key_value_heads=4, vocab_size=128, max_position_embeddings=64, torch_dtype="float16",
+                                   tie_word_embeddings=False)
+    torch.manual_seed(0)
+    model = transformers.LlamaForCausalLM(cfg).half()
+    names = [n for n in modelutils.find_layers(model, [torch.nn.Linear]) if n != "lm_head"]
+    qcfg = base.QuantConfig(bits=4, group_size=128, version="ORT", quant_method="gptq")
+    assert base.swap_quantized_linears(model, names, qcfg) is QuantLinearORT
+    rng = np.random.default_rng(2)
+    truth = {}
+    for n, layer in modelutils.find_layers(model, [QuantLinearORT]).items():
+        K, N = layer.infeatures, layer.outfeatures
+        q = rng.integers(0, 16, size=(K, N), dtype=np.int32)
+        z = rng.integers(0, 16, size=(K // 128, N), dtype=np.int32)
+        s = (rng.random((K // 128, N)) * 0.004 + 0.001).astype(np.float16)
+        qw, qz, sf = O.pack_ort(q, z, s)
+        layer.qweight, layer.qzeros, layer.scales = torch.from_numpy(qw), torch.from_numpy(qz), torch.from_numpy(sf)
+        truth[n] = (q, z, s)
+    model.quant_config = qcfg
+    d = str(tmp_path / "ort")
+    base.save_quantized(model, d)
+    assert json.load(open(os.path.join(d, "quantize_config.json")))["version"] == "ORT"
+    loaded = base.load_quantized(d, device=None)
+    assert loaded.load_report["quantized_layers"] == len(names) == 7 and not loaded.load_report["unexpected_keys"]
+    a, b = model.state_dict(), loaded.state_dict()
+    assert set(a) == set(b) and all(torch.equal(a[k], b[k]) for k in a)
+    lay = loaded.model.layers[0].mlp.down_proj
+    assert isinstance(lay, QuantLinearORT) and lay.qweight.dtype == torch.uint8
+    w_before = lay.unpack()[0]
+    repack_to_new_mode(loaded, "GPTQ")
+    lay2 = loaded.model.layers[0].mlp.down_proj
+    assert isinstance(lay2, QuantLinearGPTQ) and loaded.quant_config.version == "GPTQ"
+    q, z, s = truth["model.layers.0.mlp.down_proj"]
+    eq, ez = O.pack_gptq(q, z, 4)
+    assert np.array_equal(lay2.qweight.numpy(), eq) and np.array_equal(lay2.qzeros.numpy(), ez)
+    # same integers, scales and zeros; the two modules' W differ only by their rounding sequences (s*q - s*z vs (q-z)*s)
+    w_after = lay2.unpack()[0]
+    assert float((w_after.float() - w_before.float()).abs().max()) <= 2.0 ** -9 * float(w_before.float().abs().max())
