@@ -1,0 +1,67 @@
+"""Build-time guard on the register budget of the kernels the default dispatch reaches (no GPU needed: hipcc
+cross-compiles gfx950 to assembly and the resource usage is read from the code-object metadata).
+
+Why: the decode kernels sit next to occupancy cliffs -- the 8-wave 64-column strip variant shares a CU between two
+blocks only up to 128 VGPRs (130 cost 8 % on gate/up this round), 16-wave blocks cannot exceed 128 at all (anything more
+spills), and a spilled register inside the prefill k-loop is a scratch load that also counts against vmcnt."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "qllm_amd", "csrc")
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def _resources(src):
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not available")
+    out = os.path.join("/tmp", f"qllm_res_{src}_{int(os.path.getmtime(os.path.join(CSRC, src)))}.s")
+    if not os.path.exists(out):
+        subprocess.run([HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-S",
+                        "--cuda-device-only", os.path.join(CSRC, src), "-o", out], check=True, capture_output=True)
+    res = {}
+    for block in open(out).read().split("\n  - ")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", block)
+        vg = re.search(r"\.vgpr_count:\s+(\d+)", block)
+        sp = re.search(r"\.vgpr_spill_count:\s+(\d+)", block)
+        if name and vg and sp:
+            res[name.group(1)] = (int(vg.group(1)), int(sp.group(1)))
+    return res
+
+
+def _strip(nw, cpl, maxs, spg, xl, bits=4, ra=False, bf=False, mt=1):
+    return (f"_ZN4qllm12strip_kernelILi{nw}ELi{cpl}ELi{maxs}ELi{spg}ELi{xl}ELi{bits}ELb{int(ra)}ELb{int(bf)}ELi{mt}EEEvNS_11StripParamsE")
+
+
+def test_decode_strip_variants_fit_their_register_budget():
+    res = _resources("strip.hip")
+    # (kernel, max VGPRs): the launches of the headline bench and of the batch-16 / batch-32 decode paths
+    budget = [
+        (_strip(8, 4, 8, 4, 2), 128),             # q/k/v and gate/up grouped launches: two 8-wave blocks per CU
+        (_strip(16, 1, 8, 4, 2), 128),            # o_proj
+        (_strip(16, 1, 24, 4, 2), 128),           # down_proj (K = 11008 in one round of 24 loads)
+        (_strip(16, 1, 8, 4, 1, ra=True), 128),   # M = 5..16, 16-column strips
+        (_strip(16, 1, 8, 2, 1, ra=True), 128),   # ... g64 (HQQ)
+        (_strip(8, 4, 8, 4, 1, ra=True), 256),    # M = 5..16, grouped 64-column strips
+        (_strip(8, 4, 8, 2, 1, ra=True), 256),
+        (_strip(16, 1, 8, 4, 1, bits=3, ra=True), 128),
+        (_strip(8, 1, 8, 4, 1, ra=True, mt=2), 256),  # M = 17..32
+        (_strip(8, 1, 8, 2, 1, ra=True, mt=2), 256),
+    ]
+    for name, cap in budget:
+        assert name in res, f"kernel variant not instantiated: {name}"
+        vgpr, spill = res[name]
+        assert spill == 0 and vgpr <= cap, (name, vgpr, spill)
+
+
+def test_prefill_kernels_do_not_spill():
+    res = _resources("gemm2.hip")
+    names = [n for n in res if "gemm2_kernel" in n]
+    assert len(names) == 8  # {GPTQ, AWQ} x {256x128, 256x256} x {fp16, bf16 activations}
+    for n in names:
+        vgpr, spill = res[n]
+        assert spill == 0 and vgpr <= 256, (n, vgpr, spill)
