@@ -154,6 +154,13 @@ int qllm_awq_gemm_forward(const void *x, const void *qweight, const void *scales
                           int32_t split_k_iters, void *y, int32_t M, int32_t K, int32_t N, int32_t group_size,
                           int32_t act_dtype, void *workspace, size_t workspace_bytes, void *stream);
 
+/* Diagnostics: which kernel a forward call with these descriptors (1 = qllm_linear_forward, > 1 = the grouped call) and M
+ * rows would run, written as text into buf ("strip ...", "skinny ...", "gemm2 ...", "gemm ...", "unsupported ...").  Pure host
+ * code -- pointers are only tested for NULL / alignment, never dereferenced -- so the dispatch table can be checked without a
+ * GPU.  No reference counterpart. */
+int qllm_plan_describe(const qllm_weight_t *w, int32_t n_weights, int32_t M, int32_t have_workspace, char *buf,
+                       size_t buflen);
+
 /* ---- layout conversion on device (repack) ----------------------------------- */
 /* Integer grid q[K,N] (i32, natural order) <-> packed qweight of `layout`/`bits`.
  * Replaces general_pack_on_row / general_unpack_on_row (+ AWQ reorder) (compress_weight.py:46-92,

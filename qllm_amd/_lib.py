@@ -22,6 +22,7 @@ EXPORTS = (
     "qllm_abi_version", "qllm_last_error", "qllm_device_info", "qllm_workspace_bytes", "qllm_workspace_init",
     "qllm_linear_forward", "qllm_linear_forward_grouped", "qllm_dequant", "qllm_ort_gemv", "qllm_ort_dequant",
     "qllm_awq_gemm_forward", "qllm_unpack_qweight", "qllm_pack_qweight", "qllm_ort_dequantize4bits",
+    "qllm_plan_describe",
 )
 
 
@@ -85,6 +86,8 @@ def _declare(lib):
     lib.qllm_unpack_qweight.argtypes = [vp, i32, i32, i32, i32, vp, vp]
     lib.qllm_pack_qweight.restype = C.c_int
     lib.qllm_pack_qweight.argtypes = [vp, i32, i32, i32, i32, vp, vp]
+    lib.qllm_plan_describe.restype = C.c_int
+    lib.qllm_plan_describe.argtypes = [wp, i32, i32, i32, C.c_char_p, sz]
     lib.qllm_ort_dequantize4bits.restype = C.c_int
     lib.qllm_ort_dequantize4bits.argtypes = [vp, vp, vp, i32, vp, i32, i32, i32, vp, vp]
 

@@ -436,6 +436,54 @@ int qllm_ort_dequantize4bits(const void *qweight, const void *scales, const void
   return launch_ort_dequant(qweight, scales, qzeros, zeros_f16 ? 1 : 0, g_idx, block_size, in_features, out_features, out_nk, (hipStream_t)stream);
 }
 
+// Which kernel a forward call with these descriptors and M rows would run, as text -- no device work.  Mirrors the order of
+// qllm_linear_forward (n_weights == 1) / qllm_linear_forward_grouped (n_weights > 1); kept next to them on purpose.
+int qllm_plan_describe(const qllm_weight_t *w, int32_t n_weights, int32_t M, int32_t have_workspace, char *buf, size_t buflen) {
+  clear_error();
+  if (!w || !buf || buflen < 64) return set_error(QLLM_ERR_INVALID, "w / buf must not be NULL (buf >= 64 bytes)");
+  if (n_weights < 1 || n_weights > kMaxProblems) return set_error(QLLM_ERR_INVALID, "n_weights must be 1..%d (got %d)", kMaxProblems, n_weights);
+  if (M <= 0) return set_error(QLLM_ERR_INVALID, "M must be >= 1 (got %d)", M);
+  for (int i = 0; i < n_weights; ++i) {
+    const int rc = validate_weight(&w[i]);
+    if (rc) return rc;
+  }
+  StripPlan pl;
+  bool decode_ok = true;
+  for (int i = 0; i < n_weights; ++i) decode_ok = decode_ok && (w[i].bits == 3 || skinny_ok(w[i], M));
+  if ((n_weights > 1 || w[0].bits == 3 || skinny_ok(w[0], M)) && decode_ok && strip_plan(w, n_weights, M, &pl)) {
+    snprintf(buf, buflen, "strip nw=%d cpl=%d spw=%d form=%s row_tiles=%d", pl.nw, pl.cpl, pl.spw, pl.ra ? "register-A" : "lds-slab",
+             M > 32 ? 4 : (M > 16 ? 2 : 1));
+    return QLLM_OK;
+  }
+  if (decode_ok && w[0].bits == 4 && skinny_ok(w[0], M)) {
+    const int awq_w = skinny_awq_w(M), tn = skinny_tile_cols(w[0].layout, awq_w);
+    int tiles_total = 0, S, spw;
+    for (int i = 0; i < n_weights; ++i) tiles_total += (w[i].N + tn - 1) / tn;
+    skinny_plan(w[0].K, M, tiles_total, skinny_target_waves(), &S, &spw);
+    snprintf(buf, buflen, "skinny tile_cols=%d split_k=%d spw=%d", tn, S, spw);
+    return QLLM_OK;
+  }
+  if (n_weights == 1 && gemm_ok(w[0])) {
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.g_idx = w[0].g_idx;
+    p.M = M;
+    p.K = w[0].K;
+    p.N = w[0].N;
+    p.group_size = w[0].group_size;
+    p.gs_shift = ((w[0].group_size & (w[0].group_size - 1)) == 0) ? __builtin_ctz((unsigned)w[0].group_size) : -1;
+    if (gemm2_ok(p, w[0].layout)) {
+      const int S = have_workspace ? gemm2_split_k(M, w[0].N, w[0].K) : 1;
+      snprintf(buf, buflen, "gemm2 tile=256x%d split_k=%d", gemm2_tile_n(M, w[0].N, S), S);
+    } else {
+      snprintf(buf, buflen, "gemm tile=128x128%s", w[0].g_idx ? " act-order-gather" : "");
+    }
+    return QLLM_OK;
+  }
+  snprintf(buf, buflen, "unsupported (dequant + GEMM)");
+  return QLLM_OK;
+}
+
 int qllm_unpack_qweight(const void *qweight, int32_t layout, int32_t bits, int32_t K, int32_t N, int32_t *q_kn, void *stream) {
   clear_error();
   if (!qweight || !q_kn) return set_error(QLLM_ERR_INVALID, "qweight / q_kn must not be NULL");

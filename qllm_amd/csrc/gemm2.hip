@@ -433,6 +433,16 @@ int gemm2_split_k(int M, int N, int K) {
 }
 size_t gemm2_slab_bytes(int M, int N, int S) { return S > 1 ? (size_t)((M + 255) / 256) * (N / 128) * S * 256 * 128 * sizeof(float) : 0; }
 
+// 256x256 tiles when they fill the chip well; else 256x128 (twice the blocks)
+int gemm2_tile_n(int M, int N, int split_k) {
+  static int force_bn = getenv("QLLM_GEMM2_BN") ? atoi(getenv("QLLM_GEMM2_BN")) : 0;
+  if (split_k > 1) return 128;  // the slab layout is the 256x128 tile's
+  const int tiles256 = ((M + 255) / 256) * (N / 256);
+  const int rounds = (tiles256 + kNumCU - 1) / kNumCU;
+  const bool good256 = (N % 256 == 0) && tiles256 >= 0.85 * rounds * kNumCU;
+  return force_bn ? force_bn : (good256 ? 256 : 128);
+}
+
 int launch_gemm2(const GemmParams &p_in, int layout, hipStream_t stream) {
   GemmParams p = p_in;
   if (p.split_k < 1) p.split_k = 1;
@@ -440,13 +450,7 @@ int launch_gemm2(const GemmParams &p_in, int layout, hipStream_t stream) {
   p.raster = raster;
   static int stagger = getenv("QLLM_GEMM2_STAGGER") ? atoi(getenv("QLLM_GEMM2_STAGGER")) : 0;  // measured: 771 vs 808 TFLOP/s with it on
   p.stagger = stagger;
-  // 256x256 tiles when they fill the chip well; else 256x128 (twice the blocks)
-  static int force_bn = getenv("QLLM_GEMM2_BN") ? atoi(getenv("QLLM_GEMM2_BN")) : 0;
-  const int tiles256 = ((p.M + 255) / 256) * (p.N / 256);
-  const int rounds = (tiles256 + kNumCU - 1) / kNumCU;
-  const bool good256 = (p.N % 256 == 0) && tiles256 >= 0.85 * rounds * kNumCU;
-  int bn = force_bn ? force_bn : (good256 ? 256 : 128);
-  if (p.split_k > 1) bn = 128;  // the slab layout is the 256x128 tile's
+  const int bn = gemm2_tile_n(p.M, p.N, p.split_k);
   if (layout == QLLM_LAYOUT_AWQ_GEMM) return bn == 256 ? launch_gemm2_t<1, 256>(p, stream) : launch_gemm2_t<1, 128>(p, stream);
   return bn == 256 ? launch_gemm2_t<0, 256>(p, stream) : launch_gemm2_t<0, 128>(p, stream);
 }

@@ -103,6 +103,7 @@ int launch_gemm(const GemmParams &p, int layout, hipStream_t stream);
 // ---- gemm2.hip (256x256 tile; fp16 activations, trivial groups, N % 256 == 0) -------------------------------------
 bool gemm2_ok(const GemmParams &p, int layout);
 int gemm2_split_k(int M, int N, int K);
+int gemm2_tile_n(int M, int N, int split_k);
 size_t gemm2_slab_bytes(int M, int N, int S);
 int launch_gemm2(const GemmParams &p, int layout, hipStream_t stream);
 

@@ -136,6 +136,14 @@ def dequant(w: QllmWeight, device: torch.device, dtype=torch.float16, transposed
     return out
 
 
+def plan_describe(ws_desc: Sequence[QllmWeight], m: int, have_workspace: bool = True) -> str:
+    """Which kernel `linear_forward` (one descriptor) / `linear_forward_grouped` (several) would run for m rows."""
+    arr = (QllmWeight * len(ws_desc))(*ws_desc)
+    buf = C.create_string_buffer(256)
+    _lib.check(_lib.load().qllm_plan_describe(arr, len(ws_desc), int(m), 1 if have_workspace else 0, buf, 256))
+    return buf.value.decode()
+
+
 def ort_dequantize4bits(qweight: torch.Tensor, scales: torch.Tensor, qzeros: torch.Tensor, g_idx: Optional[torch.Tensor],
                         block_size: int, in_features: int, out_features: int) -> torch.Tensor:
     """ORT / MatMulNBits blob -> W[N,K] in the scales' dtype (ort_ops.Dequantize4Bits, ort_ops.cc:161-197)."""

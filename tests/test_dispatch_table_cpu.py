@@ -1,0 +1,92 @@
+"""The kernel-selection table, checked without a GPU through the pure-host entry point qllm_plan_describe (descriptors carry
+fake, aligned, never-dereferenced pointers).  Guards against silent fallbacks: earlier in this round an over-estimated LDS
+size quietly sent every M=16 launch to the slower split-K kernel."""
+import ctypes as C
+
+import pytest
+
+from qllm_amd import _lib
+
+GPTQ, AWQ, HQQ = _lib.LAYOUT_GPTQ, _lib.LAYOUT_AWQ_GEMM, _lib.LAYOUT_HQQ
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not _lib.is_built():
+        pytest.skip("libqllm_mi355x.so not built")
+    return _lib.load()
+
+
+def W(K, N, g=128, bits=4, layout=GPTQ, zeros=16, g_idx=None):
+    return _lib.QllmWeight(16, 16, zeros, g_idx, None, K, N, g, bits, layout, 0)
+
+
+def plan(lib, ws, m, have_ws=1):
+    arr = (_lib.QllmWeight * len(ws))(*ws)
+    buf = C.create_string_buffer(256)
+    assert lib.qllm_plan_describe(arr, len(ws), m, have_ws, buf, 256) == 0, _lib.last_error()
+    return buf.value.decode()
+
+
+def test_llama7b_decode_routes(lib):
+    attn, up, down = W(4096, 4096), W(4096, 11008), W(11008, 4096)
+    # batch 1: every linear of the stack on the full-K strip kernel, LDS-slab form
+    assert plan(lib, [attn], 1) == "strip nw=16 cpl=1 spw=8 form=lds-slab row_tiles=1"
+    assert plan(lib, [down], 1) == "strip nw=16 cpl=1 spw=24 form=lds-slab row_tiles=1"          # one round of 24 loads
+    assert plan(lib, [attn] * 3, 1) == "strip nw=8 cpl=4 spw=16 form=lds-slab row_tiles=1"      # grouped q/k/v: 64-column strips
+    assert plan(lib, [up] * 2, 1) == "strip nw=8 cpl=4 spw=16 form=lds-slab row_tiles=1"        # grouped gate/up
+    # batch 5..16: register-A form; 17..32: two row tiles; 33..64: split-K kernel
+    for m in (5, 8, 16):
+        assert "form=register-A row_tiles=1" in plan(lib, [attn], m)
+        assert "form=register-A row_tiles=1" in plan(lib, [down], m)
+        assert plan(lib, [attn] * 3, m).startswith("strip nw=8 cpl=4")
+    assert "form=lds-slab" in plan(lib, [attn], 4)
+    for m in (17, 32):
+        assert plan(lib, [attn], m) == "strip nw=8 cpl=1 spw=16 form=register-A row_tiles=2"
+        assert plan(lib, [attn] * 3, m).endswith("row_tiles=2")
+    for m in (33, 64):
+        assert plan(lib, [attn], m).startswith("skinny tile_cols=64")
+
+
+def test_llama7b_prefill_routes(lib):
+    attn, up, down = W(4096, 4096), W(4096, 11008), W(11008, 4096)
+    assert plan(lib, [attn], 2048) == "gemm2 tile=256x128 split_k=1"      # 256 tiles: one per CU
+    assert plan(lib, [attn], 8192) == "gemm2 tile=256x256 split_k=1"
+    assert plan(lib, [attn], 512) == "gemm2 tile=256x128 split_k=4"       # 64 tiles -> 4 blocks per tile
+    assert plan(lib, [attn], 256) == "gemm2 tile=256x128 split_k=8"
+    assert plan(lib, [down], 1024) == "gemm2 tile=256x128 split_k=2"
+    assert plan(lib, [up], 512) == "gemm2 tile=256x128 split_k=1"         # 172 tiles: a split would need two rounds
+    assert plan(lib, [attn], 512, have_ws=0) == "gemm2 tile=256x128 split_k=1"  # no workspace: no split, still fused
+    assert plan(lib, [attn], 128) == "gemm tile=128x128"                  # 64 < M < 192: the older kernel (next round)
+    assert plan(lib, [W(4096, 4000)], 2048) == "gemm tile=128x128"        # ragged N
+    assert plan(lib, [W(4096, 4096, layout=AWQ)], 2048) == "gemm2 tile=256x128 split_k=1"  # AWQ layout read in place
+
+
+def test_other_layouts_and_widths(lib):
+    # AWQ in place at decode sizes: split-K kernel (the modules hand the strip kernel their row-stream view instead)
+    assert plan(lib, [W(4096, 4096, layout=AWQ)], 1).startswith("skinny tile_cols=128")
+    # HQQ g64: batch 16 on the register-A strips; long K at batch 1 too (the 24-load slab variant would spill)
+    assert "form=register-A" in plan(lib, [W(11008, 4096, 64, 4, HQQ)], 1)
+    assert "form=lds-slab" in plan(lib, [W(4096, 4096, 64, 4, HQQ)], 1)
+    assert "form=register-A" in plan(lib, [W(4096, 4096, 64, 4, HQQ)], 16)
+    # 3 bits: fused for HQQ / symmetric zeros at decode sizes only
+    assert plan(lib, [W(4096, 4096, 64, 3, HQQ)], 16).startswith("strip nw=16 cpl=1")
+    assert plan(lib, [W(4096, 4096, 128, 3, GPTQ, zeros=None)], 1).startswith("strip")
+    assert plan(lib, [W(4096, 4096, 128, 3, GPTQ)], 1).startswith("unsupported")   # packed 3-bit zeros straddle words
+    assert plan(lib, [W(4096, 4096, 64, 3, HQQ)], 300).startswith("unsupported")    # prefill: dequant + GEMM
+    assert plan(lib, [W(4096, 4096, 128, 8)], 1).startswith("unsupported")
+    # raw act-order descriptors (the modules use a row-sorted view instead): in-place gather in the 128x128 kernel
+    assert plan(lib, [W(4096, 4096, g_idx=16)], 300) == "gemm tile=128x128 act-order-gather"
+    # narrow layers: too few strips to fill the chip -> split-K kernel
+    assert plan(lib, [W(4096, 1024)], 1).startswith("skinny")
+    assert plan(lib, [W(4096, 1024)] * 3, 1).startswith("strip")                    # grouped: 192 strips together
+    # group sizes the strip kernel does not serve
+    assert plan(lib, [W(4096, 4096, 32)], 1).startswith("skinny")
+
+
+def test_plan_describe_validates(lib):
+    arr = (_lib.QllmWeight * 1)(W(4096, 4096, bits=9))
+    buf = C.create_string_buffer(256)
+    assert lib.qllm_plan_describe(arr, 1, 1, 1, buf, 256) == _lib.QLLM_ERR_INVALID and "bits" in _lib.last_error()
+    assert lib.qllm_plan_describe(arr, 0, 1, 1, buf, 256) == _lib.QLLM_ERR_INVALID
+    assert lib.qllm_plan_describe(None, 1, 1, 1, buf, 256) == _lib.QLLM_ERR_INVALID
