@@ -328,6 +328,18 @@ def test_reference_named_entry_points():
         ort_ops.gemv(torch.from_numpy(x), t["qweight"], t["scales"], t["qzeros"], None, 128, 4, 1024, 0)  # CPU input
 
 
+def test_empty_batch_returns_empty_output():
+    """Zero rows: no launch, an empty result of the right shape and dtype (every layout, 2-D and 3-D inputs)."""
+    for layout in ("GPTQ", "GEMM", "HQQ"):
+        d = synth(layout, 4, 128, 1024, 512, seed=70)
+        layer = to_layer(d, DEV)
+        y = layer(torch.empty((0, 1024), dtype=torch.float16, device=DEV))
+        assert y.shape == (0, 512) and y.dtype == torch.float16
+        y3 = layer(torch.empty((2, 0, 1024), dtype=torch.float16, device=DEV))
+        assert y3.shape == (2, 0, 512)
+    torch.cuda.synchronize()
+
+
 def test_c_abi_error_codes_on_device():
     from qllm_amd import _lib, ops
     lib = _lib.load()
