@@ -61,6 +61,11 @@ struct StripProblem {
 };
 
 struct StripParams {
+#ifdef QLLM_STRIP_HEADER
+  // next-round experiment: the words every wave needs first, in ONE 64-byte line at the head of the
+  // argument block (one s_load_dwordx8 instead of eight loads from seven lines in two dependent batches)
+  int block_begin8[kMaxProblems];
+#endif
   StripProblem prob[kMaxProblems];
   const void *x;
   int n_prob;
