@@ -5,28 +5,43 @@
 
 Workload (config.workload = "llama2-7b-awq-w4-g128-decode-b1"): BASELINE.json configs[1] -- the 32 x 7 quantized
 linears of Llama-2-7B in the AWQ "GEMM" pack mode, w4 g128 asymmetric zeros, batch 1.  ONE STEP = one decode token
-through the whole linear stack (224 fused dequant+matvec launches, chained q/k/v -> o -> gate/up -> down so every
-launch depends on the previous layer like in the model), replayed from a hipGraph.  Weights are synthetic (no
+through the whole linear stack, driven through the q_layer MODULES exactly as a loaded model drives them
+(`q_proj(h)`, `k_proj(h)`, `v_proj(h)`, `o_proj(q)`, `gate_proj(o)`, `up_proj(o)`, `down_proj(gate)` per layer; every
+launch is fed by the previous one like in the model), replayed from a hipGraph.  The modules carry the sibling groups
+the loader installs (q/k/v and gate/up -> one grouped launch each: 4 launches per layer) and the step runs inside an
+`ops.DecodeChain` (links alternate between two streams; link i+1 streams its weights while link i computes; DESIGN.md
+section 3.4).  `--chain 0` / `--fused 0` give the single-stream and the 7-launch forms.  Weights are synthetic (no
 network: random packed int4 words, random fp16 scales sized to keep activations O(1)) and RESIDENT IN HBM before the
 timed region; 3.5 GB of weights per pass means nothing is served from the 256 MB Infinity Cache.
 
 value = decode tokens/s over all ranks (rank r runs an independent replica: batch elements are independent units,
-no data-path collective -> "scaling": "weak").
+no data-path collective -> "scaling": "weak").  `--tp N` instead runs the Llama-2-70B column/row-parallel layer stack
+(BASELINE configs[4]) with one RCCL all-reduce per Megatron pair; see tp_leg().
 
 Extra objects on the JSON line:
-  roofline     dominant kernel = the decode matvec (one kernel function serves all 224 launches).
+  roofline     dominant kernel = the decode matvec (one kernel function serves every launch of the step).
                achieved = algorithmic bytes per launch (packed weights + scales + zeros + x + y,
-               3,369,484,288 B per token / 224) / average launch duration, the latter measured here with HIP events on
-               the launch stream over the K timed steps (ms_per_step / 224; it therefore includes the inter-kernel
-               gaps, which rocprofv3's per-kernel average in profiles/ does not).
-  cpu_baseline the CPU oracle (oracle/ref_cpu.py: the reference's torch dequant + fp16 matmul restated) timed on this
-               host's cores over a bounded sample (one decoder layer's 7 linears), extrapolated x32.
-  extra        per-shape decode GB/s and the M=2048 prefill TFLOP/s of the same layers (act-order GPTQ, configs[2]).
+               3,369,484,288 B per token / launches) / average launch duration, the latter measured here with HIP events
+               on the launch stream over the K timed steps (= event time / launches: inter-kernel gaps included, and with
+               the chain the links overlap pairwise, so this is the wall-clock share of a launch, not its residency).
+               traffic = HBM bytes per launch from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate passes,
+               FETCH doubled per MI355X_MICROARCH.md) that THIS run spawns on itself (`--pmc-child`, 8 layers, links
+               serialised on one stream because counter collection serialises dispatches); null if rocprofv3 is absent.
+  cpu_baseline the reference's CPU torch formulation (oracle/ref_torch.py: shift/mask dequant + fp16 torch.matmul,
+               bit-identical to the oracle) timed on this host's cores over one decoder layer (3 warm + 5 timed calls per
+               shape, thread count picked by a short sweep and stated), extrapolated x32.
+  extra        per-shape decode GB/s, the other launch forms, M=2048 prefill TFLOP/s (AWQ; act-order GPTQ = configs[2]),
+               HQQ g64 M=16 (configs[3]) and the Llama-2-70B per-rank shard shapes of configs[4].
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import torch
@@ -58,39 +73,50 @@ def make_layer(cls, K, N, dev, gen, act_order=False):
     return layer.to(dev)
 
 
-class Stack:
-    """The quantized linears of the decoder stack, driven in model order."""
+class Block(torch.nn.Module):
+    """One decoder layer's quantized linears under their Llama names (what swap_quantized_linears leaves in a model)."""
 
-    def __init__(self, cls, n_layers, dev, seed, act_order=False):
+    def __init__(self, cls, dev, gen, act_order=False, hidden=HIDDEN, inter=INTER, kv=None):
+        super().__init__()
+        kv = hidden if kv is None else kv
+        self.q_proj = make_layer(cls, hidden, hidden, dev, gen, act_order)
+        self.k_proj = make_layer(cls, hidden, kv, dev, gen, act_order)
+        self.v_proj = make_layer(cls, hidden, kv, dev, gen, act_order)
+        self.o_proj = make_layer(cls, hidden, hidden, dev, gen, act_order)
+        self.gate_proj = make_layer(cls, hidden, inter, dev, gen, act_order)
+        self.up_proj = make_layer(cls, hidden, inter, dev, gen, act_order)
+        self.down_proj = make_layer(cls, inter, hidden, dev, gen, act_order)
+
+    def forward(self, h):
+        q = self.q_proj(h)
+        k = self.k_proj(h)  # noqa: F841  (k, v feed attention in the real model)
+        v = self.v_proj(h)  # noqa: F841
+        o = self.o_proj(q)
+        gate = self.gate_proj(o)
+        up = self.up_proj(o)  # noqa: F841
+        return self.down_proj(gate)
+
+
+class Stack(torch.nn.Module):
+    """The quantized linears of the decoder stack, driven in model order through the module API."""
+
+    def __init__(self, cls, n_layers, dev, seed, act_order=False, fused=True):
+        super().__init__()
+        from qllm_amd.modeling.q_layers import install_sibling_groups
         gen = torch.Generator(device=dev).manual_seed(seed)
-        self.blocks = []
-        for _ in range(n_layers):
-            blk = dict(
-                q=make_layer(cls, HIDDEN, HIDDEN, dev, gen, act_order), k=make_layer(cls, HIDDEN, HIDDEN, dev, gen, act_order),
-                v=make_layer(cls, HIDDEN, HIDDEN, dev, gen, act_order), o=make_layer(cls, HIDDEN, HIDDEN, dev, gen, act_order),
-                gate=make_layer(cls, HIDDEN, INTER, dev, gen, act_order), up=make_layer(cls, HIDDEN, INTER, dev, gen, act_order),
-                down=make_layer(cls, INTER, HIDDEN, dev, gen, act_order))
-            self.blocks.append(blk)
+        self.blocks = torch.nn.ModuleList([Block(cls, dev, gen, act_order) for _ in range(n_layers)])
+        self.groups = install_sibling_groups(self, [cls]) if fused else 0
 
-    def forward(self, h, grouped=False):
+    def set_fused(self, on: bool):
+        for m in self.modules():
+            g = getattr(m, "_siblings", None)
+            if g is not None:
+                g.enabled = on
+
+    def forward(self, h):
         for b in self.blocks:
-            if grouped:
-                from qllm_amd import ops
-                q, k, v = ops.linear_forward_grouped([b[n].decode_descriptor() for n in ("q", "k", "v")], h)
-                o = b["o"](q)
-                gate, up = ops.linear_forward_grouped([b[n].decode_descriptor() for n in ("gate", "up")], o)
-            else:
-                q = b["q"](h)
-                k = b["k"](h)  # noqa: F841  (results feed attention in the real model)
-                v = b["v"](h)  # noqa: F841
-                o = b["o"](q)
-                gate = b["gate"](o)
-                up = b["up"](o)  # noqa: F841
-            h = b["down"](gate)
+            h = b(h)
         return h
-
-    def launches_per_pass(self, grouped=False):
-        return len(self.blocks) * (4 if grouped else 7)
 
 
 def bytes_per_token(n_layers=LAYERS, M=1):
@@ -125,36 +151,108 @@ def time_events(fn, iters):
     return e0.elapsed_time(e1) / iters  # ms
 
 
-def cpu_baseline_leg():
-    """Oracle (port of the reference's CPU torch path) on this host's cores, bounded sample: one decoder layer."""
+def decode_step_fn(stack, h0, chain):
+    """One decode token through the stack's modules; inside the chain when one is given."""
+    if chain is None:
+        return lambda: stack(h0)
+
+    def step():
+        with chain:
+            return stack(h0)
+    return step
+
+
+def cpu_baseline_leg(dev):
+    """The reference's CPU torch formulation (oracle/ref_torch.py) on this host's cores, bounded sample: one decoder layer.
+    AWQ has no CPU forward in the reference at all (WQLinear_GEMM.forward needs its CUDA engine), so the layer
+    is timed in the GPTQ layout its integers repack to: same int4 count, same scales/zeros, same ops."""
     import numpy as np
-    from oracle import ref_cpu as O
+    from oracle import ref_torch as T
 
     cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
     rng = np.random.default_rng(0)
     shapes = [(HIDDEN, HIDDEN)] * 4 + [(HIDDEN, INTER)] * 2 + [(INTER, HIDDEN)]
     layers = []
     for (K, N) in shapes:
-        qw = rng.integers(-2 ** 31, 2 ** 31 - 1, size=(K, N // 8), dtype=np.int64).astype(np.int32)
-        qz = rng.integers(-2 ** 31, 2 ** 31 - 1, size=(K // GROUP, N // 8), dtype=np.int64).astype(np.int32)
-        sc = ((rng.random((K // GROUP, N)) * 0.4 + 0.8) / (K ** 0.5 * 6.5)).astype(np.float16)
+        qw = torch.from_numpy(rng.integers(-2 ** 31, 2 ** 31 - 1, size=(K // 8, N), dtype=np.int64).astype(np.int32))
+        qz = torch.from_numpy(rng.integers(-2 ** 31, 2 ** 31 - 1, size=(K // GROUP, N // 8), dtype=np.int64).astype(np.int32))
+        sc = torch.from_numpy(((rng.random((K // GROUP, N)) * 0.4 + 0.8) / (K ** 0.5 * 6.5)).astype(np.float16))
         layers.append((K, N, qw, qz, sc))
-    xs = {K: rng.standard_normal((1, K)).astype(np.float16) for K in (HIDDEN, INTER)}
+    xs = {K: torch.from_numpy(rng.standard_normal((1, K)).astype(np.float16)) for K in (HIDDEN, INTER)}
 
-    def one_layer():
-        for (K, N, qw, qz, sc) in layers:
-            O.forward("GEMM", xs[K], qw, sc, qz, None, None, 4, GROUP, K)
+    def call(i):
+        K, N, qw, qz, sc = layers[i]
+        return T.forward_gptq_torch(xs[K], qw, sc, qz, GROUP, 4)
 
-    one_layer()  # warm
-    t0 = time.perf_counter()
-    reps = 2
-    for _ in range(reps):
-        one_layer()
-    per_layer = (time.perf_counter() - t0) / reps
-    return dict(value=1.0 / (per_layer * LAYERS), unit="tokens/s", cores=cores, kind="port",
-                sample=f"1 of {LAYERS} decoder layers (7 AWQ w4 g128 linears, M=1), {reps} timed passes after 1 warm-up, "
-                       f"extrapolated x{LAYERS}; torch threads={torch.get_num_threads()}")
+    # thread count: short sweep on the 4096x4096 shape (more threads than ~32 usually lose on these bandwidth-light ops)
+    sweep = {}
+    for t in sorted({1, 8, 16, 32, 64, cores} & set(range(1, cores + 1))):
+        torch.set_num_threads(t)
+        call(0)
+        t0 = time.perf_counter()
+        call(0)
+        call(0)
+        sweep[t] = (time.perf_counter() - t0) / 2
+    best = min(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    per_shape = []
+    for i in (0, 4, 6):  # one of each shape: 3 warm + 5 timed, median
+        for _ in range(3):
+            call(i)
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            y = call(i)
+            ts.append(time.perf_counter() - t0)
+        per_shape.append(sorted(ts)[2])
+    per_layer = 4 * per_shape[0] + 2 * per_shape[1] + per_shape[2]
+    # parity of the GPU path against this very formulation, same tensors (north_star: <= 1e-2 relative)
+    from qllm_amd.modeling.q_layers import QuantLinearGPTQ
+    K, N, qw, qz, sc = layers[6]
+    gl = QuantLinearGPTQ(4, GROUP, K, N, False, dtype=torch.float16)
+    gl.qweight, gl.qzeros, gl.scales = qw, qz, sc
+    y_gpu = gl.to(dev)(xs[K].to(dev)).float().cpu()
+    rel = float((y_gpu - y.float()).abs().max() / y.float().abs().max())
+    return dict(value=round(1.0 / (per_layer * LAYERS), 4), unit="tokens/s", cores=best, kind="port",
+                sample=f"1 of {LAYERS} decoder layers (7 w4 g128 linears, M=1; torch shift/mask dequant + fp16 torch.matmul, "
+                       f"oracle/ref_torch.py), 3 warm + 5 timed calls per shape (median), extrapolated x{LAYERS}; "
+                       f"torch threads={best} of {cores} host cores, chosen by a sweep "
+                       f"{ {k: round(v * 1e3, 1) for k, v in sweep.items()} } ms per 4096x4096 call",
+                ms_per_shape={"4096x4096": round(per_shape[0] * 1e3, 2), "4096x11008": round(per_shape[1] * 1e3, 2),
+                              "11008x4096": round(per_shape[2] * 1e3, 2)},
+                gpu_vs_cpu_rel_err_11008x4096=round(rel, 6))
+
+
+def pmc_traffic(args):
+    """HBM bytes per launch of the decode kernel: two rocprofv3 PMC passes over a child run of this file."""
+    rocprof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if rocprof is None:
+        return None, "rocprofv3 not found"
+    per = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="qllm_pmc_", dir="/tmp")
+        env = dict(os.environ, TMPDIR="/tmp", QLLM_CHAIN_SERIAL="1")
+        cmd = [rocprof, "--kernel-trace", "--pmc", ctr, "-d", d, "-o", "p", "--output-format", "csv", "--",
+               sys.executable, os.path.abspath(__file__), "--pmc-child", "--steps", "2", "--warmup", "1", "--no-extra",
+               "--chain", str(args.chain), "--fused", str(args.fused)]
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
+            f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            tot, n = 0.0, 0
+            for r in csv.DictReader(open(f[0])):
+                if "qllm::strip_kernel" in r["Kernel_Name"] and r["Counter_Name"] == ctr:
+                    tot += float(r["Counter_Value"])
+                    n += 1
+            per[ctr] = tot / max(n, 1)
+        except Exception as e:  # noqa: BLE001
+            shutil.rmtree(d, ignore_errors=True)
+            return None, f"rocprofv3 --pmc {ctr} pass failed: {type(e).__name__}"
+        shutil.rmtree(d, ignore_errors=True)
+    # FETCH_SIZE / WRITE_SIZE are in KB; FETCH counts 64 B per 128-B request on gfx950 for wide coalesced reads (x2)
+    return int((2.0 * per["FETCH_SIZE"] + per["WRITE_SIZE"]) * 1024), (
+        "this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `bench.py --pmc-child` "
+        "(8 layers, same kernels, links serialised on one stream); bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024, averaged over "
+        "the decode-kernel dispatches")
 
 
 def main():
@@ -162,9 +260,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--grouped", type=int, default=int(os.environ.get("QLLM_BENCH_GROUPED", "1")),
-                    help="1: q/k/v and gate/up as single grouped launches (4 launches per layer instead of 7)")
+    ap.add_argument("--chain", type=int, default=int(os.environ.get("QLLM_BENCH_CHAIN", "1")),
+                    help="1: the step runs inside ops.DecodeChain (links alternate between two streams)")
+    ap.add_argument("--fused", type=int, default=int(os.environ.get("QLLM_BENCH_FUSED", "1")),
+                    help="1: sibling groups (q/k/v and gate/up as one grouped launch each: 4 launches per layer instead of 7)")
+    ap.add_argument("--tp", type=int, default=0, help="Llama-2-70B tensor-parallel leg (BASELINE configs[4]); 1 = shard shapes on one GPU")
     ap.add_argument("--no-extra", action="store_true", help="skip the per-shape / prefill / CPU legs")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 PMC passes behind roofline.traffic")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -180,16 +283,29 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from qllm_amd import _lib
+    from qllm_amd import _lib, ops
     from qllm_amd.modeling.q_layers import QuantLinearGPTQ, WQLinear_GEMM
 
     info = _lib.device_info(local_rank)  # raises unless gfx950 + library present: no fallback is ever benchmarked
 
-    grouped = bool(args.grouped)
-    stack = Stack(WQLinear_GEMM, LAYERS, dev, seed=1234 + rank)
+    if args.tp:
+        from tools import tp_bench
+        return tp_bench.run(args, world, rank, dev, info)
+
+    n_layers = 8 if args.pmc_child else LAYERS
+    fused = bool(args.fused)
+    stack = Stack(WQLinear_GEMM, n_layers, dev, seed=1234 + rank, fused=fused)
     h0 = torch.randn(1, HIDDEN, device=dev, dtype=torch.float16)
-    graph, out = capture(lambda: stack.forward(h0, grouped))
+    chain = ops.DecodeChain(dev) if args.chain else None
+    graph, out = capture(decode_step_fn(stack, h0, chain))
+    torch.cuda.synchronize()
     assert torch.isfinite(out.float()).all(), "synthetic stack diverged"
+    launches = n_layers * (4 if fused else 7)
+    if chain is not None:
+        chain.check()
+        assert chain.links == launches and chain.fallbacks == 0, (chain.links, chain.fallbacks)
+    if fused:
+        assert stack.groups == 2 * n_layers
 
     def barrier():
         torch.cuda.synchronize()
@@ -209,24 +325,25 @@ def main():
     barrier()
     wall = time.perf_counter() - t0
     ev_ms = e0.elapsed_time(e1)
+    if chain is not None:
+        chain.check()  # no link timed out during the timed region
     if world > 1:
         t = torch.tensor([wall, ev_ms], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall, ev_ms = float(t[0]), float(t[1])
+    if args.pmc_child:
+        return
 
     ms_per_step = wall * 1e3 / args.steps
     tokens_per_s = world * args.steps / wall
-    launches = stack.launches_per_pass(grouped)
     bpt = bytes_per_token()
     avg_launch_us = ev_ms * 1e3 / (args.steps * launches)
     achieved = (bpt / launches) / (avg_launch_us * 1e-6) / 1e9
 
-    traffic = None
-    try:  # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command (profiles/)
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc.json")))
-        traffic = pmc["bytes_per_launch_avg_over_step"] if grouped else None
-    except Exception:  # noqa: BLE001
-        pass
+    traffic, traffic_source = None, "skipped (--no-pmc)"
+    if rank == 0 and world == 1 and not args.no_pmc and not args.no_extra:
+        del graph
+        traffic, traffic_source = pmc_traffic(args)
 
     result = {
         "metric": "decode_tokens_per_s_llama2_7b_w4a16_g128_linear_stack", "value": round(tokens_per_s, 2),
@@ -235,35 +352,46 @@ def main():
         "dtype": "f16", "data": "synthetic",
         "config": {"workload": "llama2-7b-awq-w4-g128-decode-b1", "pack_mode": "GEMM", "bits": 4, "group_size": GROUP,
                    "layers": LAYERS, "linears_per_layer": 7, "batch": 1, "launches_per_step": launches,
-                   "grouped_qkv_gateup": grouped, "graph": True, "parallelism": f"replicas x{world}",
+                   "driven_through": "q_layer modules (sibling groups installed by the loader)", "grouped_qkv_gateup": fused,
+                   "decode_chain": bool(args.chain), "graph": True, "parallelism": f"replicas x{world}",
                    "device": info["arch"], "compute_units": info["compute_units"]},
         "roofline": {"bound": "hbm", "kernel": "qllm::strip_kernel (decode matvec; serves every launch of the step)",
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                     "traffic_source": "profiles/r01_pmc.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)",
+                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_source,
                      "bytes_per_launch": bpt // launches, "avg_launch_us": round(avg_launch_us, 3)},
     }
 
     if rank == 0 and world == 1 and not args.no_extra:
         extra = {}
-        # per-shape decode bandwidth (32 distinct weight sets per shape => HBM resident, not cache resident)
-        for name, key, (K, N) in (("attn_4096x4096", "q", (HIDDEN, HIDDEN)), ("mlp_4096x11008", "gate", (HIDDEN, INTER)),
-                                  ("mlp_11008x4096", "down", (INTER, HIDDEN))):
+        # per-shape decode bandwidth (32 distinct weight sets per shape => HBM resident, not cache resident), ordinary launches
+        stack.set_fused(False)
+        for name, key, (K, N) in (("attn_4096x4096", "q_proj", (HIDDEN, HIDDEN)), ("mlp_4096x11008", "gate_proj", (HIDDEN, INTER)),
+                                  ("mlp_11008x4096", "down_proj", (INTER, HIDDEN))):
             x = torch.randn(1, K, device=dev, dtype=torch.float16)
-            ls = [b[key] for b in stack.blocks]
+            ls = [getattr(b, key) for b in stack.blocks]
             g, _ = capture(lambda: [l(x) for l in ls])
             ms = time_events(g.replay, 20) / len(ls)
             extra[f"decode_{name}"] = {"us": round(ms * 1e3, 2), "GBps": round(alg_bytes(K, N, 1) / ms / 1e6, 1)}
-        # the other launch granularity (grouped: q/k/v and gate/up as single launches; ungrouped: one per linear)
-        gg, _ = capture(lambda: stack.forward(h0, not grouped))
-        ms = time_events(gg.replay, 20)
-        extra["decode_stack_" + ("ungrouped" if grouped else "grouped")] = {
-            "ms_per_token": round(ms, 4), "tokens_per_s": round(1e3 / ms, 1), "GBps": round(bpt / ms / 1e6, 1)}
+        # the other launch forms of the same step (all through the modules)
+        for tag, fz, ch in (("fused_single_stream", True, None), ("ungrouped_single_stream", False, None),
+                            ("ungrouped_chain", False, chain if chain is not None else ops.DecodeChain(dev)),
+                            ("fused_chain", True, chain if chain is not None else ops.DecodeChain(dev))):
+            if fz == fused and (ch is not None) == bool(args.chain):
+                continue  # the headline form
+            stack.set_fused(fz)
+            gg, _ = capture(decode_step_fn(stack, h0, ch))
+            ms = time_events(gg.replay, 20)
+            del gg
+            extra["decode_stack_" + tag] = {"ms_per_token": round(ms, 4), "tokens_per_s": round(1e3 / ms, 1),
+                                            "GBps": round(bpt / ms / 1e6, 1), "frac_of_hbm_peak": round(bpt / ms / 1e6 / HBM_PEAK_GBPS, 4)}
+        stack.set_fused(fused)
+        del stack
+        torch.cuda.empty_cache()
         # prefill M=2048 (BASELINE configs[2]: GPTQ act-order) and AWQ, one layer's 7 linears x 4 layers
         for tag, cls, act in (("awq", WQLinear_GEMM, False), ("gptq_actorder", QuantLinearGPTQ, True)):
             ps = Stack(cls, 4, dev, seed=99, act_order=act)
             xp = torch.randn(2048, HIDDEN, device=dev, dtype=torch.float16)
-            gp, _ = capture(lambda: ps.forward(xp))  # graph replay, like the headline leg: kernel time, not Python / allocator time
+            gp, _ = capture(lambda: ps(xp))  # graph replay, like the headline leg: kernel time, not Python / allocator time
             ms = time_events(gp.replay, 10)
             del gp
             tf = flops_per_pass(4, 2048) / ms / 1e9
@@ -288,8 +416,15 @@ def main():
             del gh
             nbytes = sum(alg_bytes(l.infeatures, l.outfeatures, 16, 64, "f16") * bits_sel // 4 for l, _ in ls)
             extra[tag] = {"ms_per_layer": round(ms, 4), "GBps": round(nbytes / ms / 1e6, 1)}
+        del hq
+        torch.cuda.empty_cache()
+        try:  # BASELINE configs[4] on one GPU: the per-rank shard shapes of Llama-2-70B at TP = 8
+            from tools import tp_bench
+            extra.update(tp_bench.shard_shapes_leg(dev))
+        except Exception as e:  # noqa: BLE001
+            extra["tp_shard_error"] = f"{type(e).__name__}: {e}"
         result["extra"] = extra
-        result["cpu_baseline"] = cpu_baseline_leg()
+        result["cpu_baseline"] = cpu_baseline_leg(dev)
     elif rank == 0:
         result["cpu_baseline"] = None
 

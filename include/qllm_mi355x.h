@@ -27,9 +27,16 @@
  *       AWQ_GEMM qweight i32 [K, N/8], nibble i of word (k,j) = q[k, 8j+{0,2,4,6,1,3,5,7}[i]]; qzeros i32 [K/g, N/8]
  *                same interleave; scales f16 [K/g, N]; 4-bit only; no g_idx
  *       HQQ      qweight as GPTQ; qzeros f16 [ceil(K/g), N] (un-packed, non-integer); no g_idx
- *   - numerics: W[k,n] = fp16( fp16(s*q) - fp16(z*s) ) exactly as DequantizeLinearBlockWise
- *     (quant_linear_gptq.py:38-48) -- one IEEE rounding per op, bit-identical to the CPU path -- then
- *     y = x.W accumulated in fp32 and rounded once to the activation dtype; bias added in fp32 before rounding.
+ *   - numerics, by kernel path (qllm_plan_describe() names the path a call takes):
+ *       qllm_dequant / qllm_ort_dequant, the prefill GEMMs ("gemm2", "gemm") and the split-K decode kernel ("skinny"):
+ *         W[k,n] = fp16( fp16(s*q) - fp16(z*s) ) exactly as DequantizeLinearBlockWise (quant_linear_gptq.py:38-48) -- one IEEE
+ *         rounding per op, bit-identical to the CPU path -- then y = x.W accumulated in fp32, bias added in fp32, one
+ *         rounding to the activation dtype.
+ *       the full-K decode kernel ("strip", M <= 32 on row-stream layouts -- the default decode path):
+ *         y = sum_G s_G * ( sum_{k in G} x_k q_k  -  z_G * sum_{k in G} x_k ) evaluated in fp32, i.e. x.W for the UNROUNDED
+ *         W = s*(q - z); it differs from the path above by the fp16 rounding noise of W (<= 3e-4 relative measured; the
+ *         tests bound every decode case at 2e-3 against float64 of the reference's W and at 1e-2 against the CPU path).
+ *     The bit-exactness guarantee therefore holds for the dequant entry points and the paths of the first group only.
  */
 #ifndef QLLM_MI355X_H_
 #define QLLM_MI355X_H_
@@ -41,7 +48,7 @@
 extern "C" {
 #endif
 
-#define QLLM_ABI_VERSION 1
+#define QLLM_ABI_VERSION 2
 
 typedef enum qllm_status {
   QLLM_OK = 0,
@@ -115,6 +122,26 @@ int qllm_linear_forward(const qllm_weight_t *w, const void *x, void *y, int32_t 
 int qllm_linear_forward_grouped(const qllm_weight_t *w, void *const *y, int32_t n_weights, const void *x,
                                 int32_t M, int32_t act_dtype, void *workspace, size_t workspace_bytes,
                                 void *stream);
+
+/* Chained decode link (no reference counterpart).  Same arithmetic as qllm_linear_forward_grouped at
+ * M <= 4 on row-stream layouts, but the launch is one link of a chain whose links the caller issues ALTERNATELY on two
+ * streams: link i+1 is then resident and has its weight loads in flight while link i still computes, and the small activation
+ * vector is handed over in-band:
+ *   QLLM_CHAIN_PUBLISH_Y  y[i] are written write-through; the caller must have filled them with 0xFF bytes (every half = 0xFFFF,
+ *                         "not written yet") before the link's CONSUMER can start -- e.g. one memset of the activation arena at
+ *                         the head of every decode step; a result that is exactly 0xFFFF is stored as another NaN pattern;
+ *   QLLM_CHAIN_POLL_X     x is such a buffer, produced by a link on the OTHER stream (or earlier on this one): every wave
+ *                         re-reads its slice of x until no 0xFFFF half is left, then computes.
+ * Deadlock rule, enforced here: a link's blocks are at most half a CU and its grid <= 448 blocks, so two adjacent links are
+ * always co-resident; at most two streams may carry links of one chain.  Every poll loop is bounded (~10 ms): on expiry the
+ * kernel raises bit 0 of *err_word (device memory, zeroed by the caller) and finishes with whatever x held.
+ * QLLM_ERR_UNSUPPORTED when the shape has no chained plan (run it as an ordinary launch ordered after both streams). */
+#define QLLM_CHAIN_POLL_X 1
+#define QLLM_CHAIN_PUBLISH_Y 2
+int qllm_linear_forward_chained(const qllm_weight_t *w, void *const *y, int32_t n_weights, const void *x, int32_t M,
+                                int32_t act_dtype, int32_t chain_flags, void *err_word, void *stream);
+/* Text description of the chained plan ("chained strip nw=.. cpl=.. spw=.. round=.. blocks=..") or "not chainable"; pure host. */
+int qllm_chain_plan_describe(const qllm_weight_t *w, int32_t n_weights, int32_t M, char *buf, size_t buflen);
 
 /* W[K,N] (out_transposed = 0) or W[N,K] (out_transposed = 1) in `out_dtype`, bit-identical to
  * DequantizeLinearBlockWise / DequantAndUnpack / unpack().  All bits 2..8, all layouts, optional g_idx.

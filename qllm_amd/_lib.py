@@ -16,14 +16,15 @@ LIB_PATH = os.environ.get("QLLM_MI355X_LIB") or os.path.join(_HERE, LIB_NAME)  #
 QLLM_OK, QLLM_ERR_INVALID, QLLM_ERR_UNSUPPORTED, QLLM_ERR_WORKSPACE, QLLM_ERR_LAUNCH, QLLM_ERR_DEVICE = range(6)
 LAYOUT_GPTQ, LAYOUT_AWQ_GEMM, LAYOUT_HQQ = 0, 1, 2
 DT_F16, DT_BF16 = 0, 1
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 EXPORTS = (
     "qllm_abi_version", "qllm_last_error", "qllm_device_info", "qllm_workspace_bytes", "qllm_workspace_init",
     "qllm_linear_forward", "qllm_linear_forward_grouped", "qllm_dequant", "qllm_ort_gemv", "qllm_ort_dequant",
     "qllm_awq_gemm_forward", "qllm_unpack_qweight", "qllm_pack_qweight", "qllm_ort_dequantize4bits",
-    "qllm_plan_describe",
+    "qllm_plan_describe", "qllm_linear_forward_chained", "qllm_chain_plan_describe",
 )
+CHAIN_POLL_X, CHAIN_PUBLISH_Y = 1, 2
 
 
 class QllmWeight(C.Structure):
@@ -88,6 +89,10 @@ def _declare(lib):
     lib.qllm_pack_qweight.argtypes = [vp, i32, i32, i32, i32, vp, vp]
     lib.qllm_plan_describe.restype = C.c_int
     lib.qllm_plan_describe.argtypes = [wp, i32, i32, i32, C.c_char_p, sz]
+    lib.qllm_linear_forward_chained.restype = C.c_int
+    lib.qllm_linear_forward_chained.argtypes = [wp, C.POINTER(vp), i32, vp, i32, i32, i32, vp, vp]
+    lib.qllm_chain_plan_describe.restype = C.c_int
+    lib.qllm_chain_plan_describe.argtypes = [wp, i32, i32, C.c_char_p, sz]
     lib.qllm_ort_dequantize4bits.restype = C.c_int
     lib.qllm_ort_dequantize4bits.argtypes = [vp, vp, vp, i32, vp, i32, i32, i32, vp, vp]
 

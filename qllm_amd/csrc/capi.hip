@@ -91,7 +91,16 @@ static int strip_min_strips() {
 struct StripPlan {
   int cpl, nw, spw, ra;
 };
-static bool strip_plan(const qllm_weight_t *w, int n, int M, StripPlan *plan) {
+constexpr int kChainMaxGrid = 448;          // blocks of a chained link: all co-resident beside the neighbouring link's
+constexpr int kChainMinGrid = 120;          // fewer blocks than about half the CUs: not worth a link (ordinary launch instead)
+constexpr size_t kChainMaxLds = 80 * 1024;  // half a CU
+static int chain_max_m() {
+  static int v = env_int("QLLM_CHAIN_MAX_M", 4);
+  return v;
+}
+// chain != 0: plan for a chained decode link (strip.hip, CH): lds-slab form, 4 bits, at most half a CU per block, grid <= 448
+static bool strip_plan(const qllm_weight_t *w, int n, int M, StripPlan *plan, int chain = 0) {
+  if (chain && (M > chain_max_m() || w[0].bits != 4)) return false;
   // measured (graph replay, us; split-K kernel -> strips with 2 / 4 row tiles): M=32: 4096x4096 28.3 -> 13.4, 4096x11008 54.9 -> 36.3,
   // 11008x4096 50.1 -> 30.3; M=64: 33.8 -> 22.6, 52.5 -> 61.5, 48.1 -> 53.9 -- four row tiles only pay on the small shape
   static int max_m = env_int("QLLM_STRIP_MAX_M", 32);
@@ -133,20 +142,29 @@ static bool strip_plan(const qllm_weight_t *w, int n, int M, StripPlan *plan) {
   if (force_cpl == 1) first = 1;
   // candidates: the measured-best strip width first; if its activation slab does not fit in LDS (many rows), narrower
   // strips with 16 waves (each wave stages a shorter K chunk)
-  const int cand_cpl[2] = {first, 1};
-  for (int ci = 0; ci < 2; ++ci) {
+  const int chain_arg = chain ? 1 : 0;
+  const int cand_cpl[3] = {first, 1, (chain && m64) ? 4 : 1};
+  for (int ci = 0; ci < 3; ++ci) {
     const int cpl = cand_cpl[ci];
-    if (ci == 1 && cpl == first) break;
+    if (ci >= 1 && cpl == cand_cpl[ci - 1]) continue;
+    if (ci == 2 && cpl == first) break;
     const int strips = cols / (16 * cpl);
     if (cpl == 1 && strips < strip_min_strips()) continue;
+    if (chain && (strips > kChainMaxGrid || strips < kChainMinGrid)) continue;
     // 64-column strips use 128 VGPRs -> 16 waves per CU: 8-wave blocks keep two strips co-resident per CU (one
     // round) instead of 16-wave blocks in two rounds (gate/up 15.6 -> 13.8 us, q/k/v 8.5 -> 8.3 us)
-    int nw = cpl == 4 ? (nw4 ? nw4 : 8) : ((cpl == 2 || bits == 3) ? 16 : strip_nw(w[0].K, strips));
+    int nw = cpl == 4 ? ((nw4 && !chain) ? nw4 : 8) : ((cpl == 2 || bits == 3) ? 16 : strip_nw(w[0].K, strips));
     if (M > 16) nw = 8;
+    if (chain) {  // half a CU per block: 64-column strips (g128) as 8-wave blocks; 16-column strips as 16 waves x one round of 8
+      if (cpl == 2 || (cpl == 4 && w[0].group_size != 128)) continue;  // k-steps when K is short, else 8 waves x rounds of <= 24
+      if (cpl == 1) nw = strip_spw(w[0].K, w[0].group_size, 16) <= 8 ? 16 : 8;
+    }
     for (int tries = 0; tries < 2; ++tries) {
       const int spw = strip_spw(w[0].K, w[0].group_size, nw);
-      const int ra = (ra_base || (longk && cpl == 1 && nw == 16)) ? 1 : 0;
-      if ((ra || strip_x_ok(M, spw, nw, cpl)) && strip_lds_bytes(M, spw, nw, cpl, w[0].group_size, ra) <= 156 * 1024) {
+      const int ra = (ra_base || (!chain && longk && cpl == 1 && nw == 16)) ? 1 : 0;
+      if (chain && (ra || tries > 0)) break;
+      if ((ra || strip_x_ok(M, spw, nw, cpl, chain_arg)) &&
+          strip_lds_bytes(M, spw, nw, cpl, w[0].group_size, ra, chain_arg) <= (chain ? kChainMaxLds : 156 * 1024)) {
         plan->cpl = cpl;
         plan->nw = nw;
         plan->spw = spw;
@@ -164,9 +182,10 @@ static bool strip_ok(const qllm_weight_t *w, int n, int M) {
   return strip_plan(w, n, M, &pl);
 }
 
-static int run_strip(const qllm_weight_t *w, void *const *y, int n, const void *x, int M, int act_dtype, hipStream_t stream) {
+static int run_strip(const qllm_weight_t *w, void *const *y, int n, const void *x, int M, int act_dtype, hipStream_t stream,
+                     int chain = 0, uint32_t *err = nullptr) {
   StripPlan pl;
-  if (!strip_plan(w, n, M, &pl)) return set_error(QLLM_ERR_INVALID, "internal: strip plan");
+  if (!strip_plan(w, n, M, &pl, chain != 0)) return set_error(QLLM_ERR_INVALID, "internal: strip plan");
   StripParams p;
   memset(&p, 0, sizeof(p));
   p.x = x;
@@ -182,6 +201,8 @@ static int run_strip(const qllm_weight_t *w, void *const *y, int n, const void *
   p.group_size = w[0].group_size;
   p.add_zero_bias = w[0].add_zero_bias;
   p.act_bf16 = (act_dtype == QLLM_BF16);
+  p.chain = chain;
+  p.err = err;
   int block = 0;
   for (int i = 0; i < n; ++i) {
     StripProblem &q = p.prob[i];
@@ -339,6 +360,54 @@ int qllm_linear_forward_grouped(const qllm_weight_t *w, void *const *y, int32_t 
   if (strip_ok(w, n_weights, M)) return run_strip(w, y, n_weights, x, M, act_dtype, (hipStream_t)stream);
   if (w[0].bits != 4) return set_error(QLLM_ERR_UNSUPPORTED, "grouped forward: no fused kernel for %d-bit weights in this shape", w[0].bits);
   return run_skinny(w, y, n_weights, x, M, act_dtype, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int qllm_linear_forward_chained(const qllm_weight_t *w, void *const *y, int32_t n_weights, const void *x, int32_t M,
+                                int32_t act_dtype, int32_t chain_flags, void *err_word, void *stream) {
+  clear_error();
+  if (!w || !y) return set_error(QLLM_ERR_INVALID, "w / y arrays must not be NULL");
+  if (n_weights < 1 || n_weights > kMaxProblems) return set_error(QLLM_ERR_INVALID, "n_weights must be 1..%d (got %d)", kMaxProblems, n_weights);
+  if (chain_flags < 1 || chain_flags > 3) return set_error(QLLM_ERR_INVALID, "chain_flags must be POLL_X | PUBLISH_Y (1..3), got %d", chain_flags);
+  if (!err_word || (uintptr_t)err_word % 4) return set_error(QLLM_ERR_INVALID, "err_word must be a 4-byte aligned device word");
+  for (int i = 0; i < n_weights; ++i) {
+    int rc = validate_weight(&w[i]);
+    if (rc) return rc;
+    rc = check_io(x, y[i], M, act_dtype);
+    if (rc) return rc;
+    if ((uintptr_t)y[i] % 4 || w[i].N % 2) return set_error(QLLM_ERR_INVALID, "chained links store y in 4-byte pairs: y must be 4-byte aligned, N even");
+    const bool rows0 = w[0].layout != QLLM_LAYOUT_AWQ_GEMM, rowsi = w[i].layout != QLLM_LAYOUT_AWQ_GEMM;
+    if (w[i].K != w[0].K || w[i].group_size != w[0].group_size || w[i].bits != w[0].bits || rows0 != rowsi ||
+        w[i].add_zero_bias != w[0].add_zero_bias)
+      return set_error(QLLM_ERR_INVALID, "grouped weights must agree on K, group_size, bits, layout family and add_zero_bias");
+    if (!skinny_ok(w[i], M)) return set_error(QLLM_ERR_UNSUPPORTED, "chained link needs the decode kernel (4-bit, K%%32==0, no act-order)");
+  }
+  StripPlan pl;
+  if (!strip_plan(w, n_weights, M, &pl, 1))
+    return set_error(QLLM_ERR_UNSUPPORTED, "no chained-link plan for this shape (M=%d): run it as an ordinary launch", M);
+  return run_strip(w, y, n_weights, x, M, act_dtype, (hipStream_t)stream, chain_flags, (uint32_t *)err_word);
+}
+
+int qllm_chain_plan_describe(const qllm_weight_t *w, int32_t n_weights, int32_t M, char *buf, size_t buflen) {
+  clear_error();
+  if (!w || !buf || buflen < 64) return set_error(QLLM_ERR_INVALID, "w / buf must not be NULL (buf >= 64 bytes)");
+  if (n_weights < 1 || n_weights > kMaxProblems) return set_error(QLLM_ERR_INVALID, "n_weights must be 1..%d (got %d)", kMaxProblems, n_weights);
+  if (M <= 0) return set_error(QLLM_ERR_INVALID, "M must be >= 1 (got %d)", M);
+  bool ok = true;
+  for (int i = 0; i < n_weights; ++i) {
+    const int rc = validate_weight(&w[i]);
+    if (rc) return rc;
+    ok = ok && skinny_ok(w[i], M) && w[i].N % 2 == 0;
+  }
+  StripPlan pl;
+  if (ok && strip_plan(w, n_weights, M, &pl, 1)) {
+    int cols = 0;
+    for (int i = 0; i < n_weights; ++i) cols += w[i].N;
+    snprintf(buf, buflen, "chained strip nw=%d cpl=%d spw=%d round=%d blocks=%d", pl.nw, pl.cpl, pl.spw,
+             strip_maxs(pl.nw, pl.spw, pl.cpl, 0, 1), cols / (16 * pl.cpl));
+  } else {
+    snprintf(buf, buflen, "not chainable");
+  }
+  return QLLM_OK;
 }
 
 int qllm_linear_forward(const qllm_weight_t *w, const void *x, void *y, int32_t M, int32_t act_dtype, void *workspace,

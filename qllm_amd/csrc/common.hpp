@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/qllm_mi355x.h"
 
 namespace qllm {
@@ -31,6 +33,25 @@ void clear_error();
     if (_e != hipSuccess)                                                                             \
       return ::qllm::set_error(QLLM_ERR_LAUNCH, "%s failed: %s", #expr, hipGetErrorString(_e));       \
   } while (0)
+
+// Per-device once-flag for per-device function attributes (hipFuncSetAttribute): a lock-free bitmask, one bit per HIP
+// device ordinal (<= 64 devices per process).  A racing second caller at worst repeats the (idempotent) attribute call.
+struct DeviceLatch {
+  std::atomic<uint64_t> bits{0};
+  bool test(int dev) const { return dev >= 0 && dev < 64 && (bits.load(std::memory_order_acquire) >> dev) & 1u; }
+  void set(int dev) { if (dev >= 0 && dev < 64) bits.fetch_or(1ull << dev, std::memory_order_release); }
+};
+
+// opt a kernel into > 64 KB of dynamic LDS on the CURRENT device, once per (kernel, device)
+inline int lds_optin(DeviceLatch &latch, const void *kernel_fn) {
+  int dev = 0;
+  QLLM_HIP_CHECK(hipGetDevice(&dev));
+  if (!latch.test(dev)) {
+    QLLM_HIP_CHECK(hipFuncSetAttribute(kernel_fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    latch.set(dev);
+  }
+  return QLLM_OK;
+}
 
 // ---- device helpers ---------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t as_u32(half2_t v) { return __builtin_bit_cast(uint32_t, v); }

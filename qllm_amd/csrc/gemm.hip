@@ -260,12 +260,8 @@ int launch_gemm(const GemmParams &p, int layout, hipStream_t stream) {
   if (lds > 160 * 1024) return set_error(QLLM_ERR_UNSUPPORTED, "act-order table (%d groups) exceeds LDS", p.n_groups);
 #define QLLM_LAUNCH_GEMM(L, A)                                                                         \
   do {                                                                                                 \
-    static bool attr_done = false;                                                                     \
-    if (!attr_done) {                                                                                  \
-      QLLM_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_kernel<L, A>,                              \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));     \
-      attr_done = true;                                                                                \
-    }                                                                                                  \
+    static DeviceLatch attr_done; /* per (kernel, device): the LDS opt-in is a per-device attribute */   \
+    if (int rc = lds_optin(attr_done, (const void *)gemm_kernel<L, A>)) return rc;                     \
     hipLaunchKernelGGL((gemm_kernel<L, A>), dim3(tiles), dim3(256), lds, stream, p);                   \
   } while (0)
   if (layout == QLLM_LAYOUT_AWQ_GEMM) {

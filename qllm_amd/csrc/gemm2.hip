@@ -402,11 +402,8 @@ bool gemm2_ok(const GemmParams &p, int layout) {
 template <int LAYOUT, int BN, bool BF16>
 static int launch_gemm2_b(const GemmParams &p, hipStream_t stream) {
   using namespace g2;
-  static bool attr_done = false;
-  if (!attr_done) {
-    QLLM_HIP_CHECK(hipFuncSetAttribute((const void *)gemm2_kernel<LAYOUT, BN, BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done = true;
-  }
+  static DeviceLatch attr_done;  // per (kernel, device): the LDS opt-in is a per-device attribute
+  if (int rc = lds_optin(attr_done, (const void *)gemm2_kernel<LAYOUT, BN, BF16>)) return rc;
   const int tiles = ((p.M + BM - 1) / BM) * (p.N / BN) * p.split_k;
   const size_t lds = (size_t)4 * kTile * sizeof(half_t);  // 128 KB (A 2 x 32 KB, B 2 x <= 32 KB)
   hipLaunchKernelGGL((gemm2_kernel<LAYOUT, BN, BF16>), dim3(tiles), dim3(512), lds, stream, p);

@@ -78,13 +78,17 @@ struct StripParams {
   int group_size;
   int add_zero_bias;
   int act_bf16;
+  int chain;        // chained decode link (strip.hip, CH): bit 0 = x is a 0xFFFF-armed buffer (poll), bit 1 = publish y
+  uint32_t *err;    // chained links: device word, bit 0 raised when a poll loop gives up
 };
 bool strip_group_ok(int group_size);
 int strip_nw(int K, int strips_total);
 int strip_spw(int K, int group_size, int nw);
-size_t strip_lds_bytes(int M, int spw, int nw, int cpl, int group_size, int ra);
+// `chain`: 0 = ordinary launch, 1 = chained link
+int strip_maxs(int nw, int spw, int cpl, int ra, int chain);
+size_t strip_lds_bytes(int M, int spw, int nw, int cpl, int group_size, int ra, int chain);
 int strip_cpl(int cols_total, bool all_mult64, bool all_mult32);
-bool strip_x_ok(int M, int spw, int nw, int cpl);
+bool strip_x_ok(int M, int spw, int nw, int cpl, int chain);
 int launch_strip(const StripParams &p, int grid, hipStream_t stream);
 
 // ---- gemm.hip ------------------------------------------------------------------------------------------------

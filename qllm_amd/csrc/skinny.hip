@@ -349,12 +349,8 @@ template <int LAYOUT, int W, bool XLDS>
 static int launch_mt(const SkinnyParams &p, int mt, int grid, size_t lds, hipStream_t stream) {
 #define QLLM_SK(MT_)                                                                                              \
   do {                                                                                                            \
-    static bool attr_done = false;                                                                                \
-    if (!attr_done) {                                                                                             \
-      QLLM_HIP_CHECK(hipFuncSetAttribute((const void *)skinny_kernel<LAYOUT, W, MT_, XLDS>,                       \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                \
-      attr_done = true;                                                                                           \
-    }                                                                                                             \
+    static DeviceLatch attr_done; /* per (kernel, device): the LDS opt-in is a per-device attribute */              \
+    if (int rc = lds_optin(attr_done, (const void *)skinny_kernel<LAYOUT, W, MT_, XLDS>)) return rc;              \
     hipLaunchKernelGGL((skinny_kernel<LAYOUT, W, MT_, XLDS>), dim3(grid), dim3(256), lds, stream, p);             \
   } while (0)
   if constexpr (W == 2) {  // the 16-columns-per-lane AWQ variant only exists for one M-tile (register budget)

@@ -31,6 +31,13 @@ __device__ __forceinline__ float dpp_add(float v) {
   return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
 
+// any 16-bit field of v equal to 0xFFFF?  (zero-field test on ~v)
+__device__ __forceinline__ bool has_ffff16(uint64_t v) {
+  const uint64_t t = ~v;
+  return ((t - 0x0001000100010001ull) & ~t & 0x8000800080008000ull) != 0;
+}
+constexpr uint32_t kChainSpinLimit = 8192;  // polls of ~1 us each before a chained link gives up (never hang the device)
+
 // NW: waves per block; CPL: columns per lane (1 -> 16-column strip, 64-byte row segments; 4 -> 64-column strip,
 // 256-byte row segments, 4 MFMAs per k-step); MAXS: k-steps (weight loads) per lane per round; SPG: k-steps per
 // quantisation group (group_size / 32); XL: 16-byte activation chunks staged per lane.
@@ -63,11 +70,22 @@ __device__ __forceinline__ float dpp_add(float v) {
 //       weights before computing a round -- two register sets, loop unrolled by two -- was 8-18 % slower at K=11008.)
 // MT (RA only): 16-row MFMA tiles per block, M <= 16*MT.  Every B fragment built from a packed word is used MT times, so the
 //       per-weight VALU work is amortised over up to 64 rows; each k-step holds MT x 16 B of activations per lane.
-template <int NW, int CPL, int MAXS, int SPG, int XL, int BITS, bool RA = false, bool RA_BF16 = false, int MT = 1>
+// CH ("chained", lds-slab form only): the launch is one link of a decode chain whose links alternate between two streams, so
+//       that link i+1 is already resident and has ALL of its weight loads in flight while link i still computes (weights never
+//       depend on activations).  The hand-off of the small activation vector is in-band: the producer's
+//       y buffer is pre-filled with 0xFFFF halves (a NaN no finite result can equal), the producer writes its outputs
+//       write-through (sc1, agent scope), and every consumer wave re-reads ITS OWN K chunk of x with L1-bypassing loads until no
+//       0xFFFF half is left -- every 16-bit value is its own "ready" tag: no flag, no fence, no atomics, no block barrier
+//       (cdna_hip_programming.md Guideline 16, recipe R2 with 2-byte granules).  p.chain bit 0: x is such a buffer (poll);
+//       bit 1: publish y that way.  A block is at most half a CU (16 waves x <= 64 registers or 8 waves x <= 128) and the host
+//       keeps the grid <= 448, so two adjacent links are always co-resident and a polling link can never keep its producer's
+//       blocks off the chip; every poll loop is bounded (gives up after ~10 ms and raises bit 0 of *p.err).
+template <int NW, int CPL, int MAXS, int SPG, int XL, int BITS, bool RA = false, bool RA_BF16 = false, int MT = 1, bool CH = false>
 // (second launch-bound = minimum waves per SIMD: the 8-wave 64-column slab variant sits right at the 128-register edge
 //  that lets two blocks share a CU -- 130 registers halve its occupancy: gate/up 13.7 -> 15.0 us)
-__global__ __launch_bounds__(NW * 64, (NW == 8 && CPL == 4 && SPG == 4 && !RA) ? 4 : 1) void strip_kernel(const StripParams p) {
+__global__ __launch_bounds__(NW * 64, CH ? (NW == 8 ? 4 : 8) : ((NW == 8 && CPL == 4 && SPG == 4 && !RA) ? 4 : 1)) void strip_kernel(const StripParams p) {
   static_assert(BITS == 4 || (BITS == 3 && CPL == 1), "3-bit strips are 16 columns wide");
+  static_assert(!CH || (!RA && XL <= 4 && BITS == 4 && MT == 1), "chained links: lds-slab form, 4 bits, at most 4 activation chunks per lane");
   static_assert(!RA || MAXS == 8, "register-A rounds are 8 k-steps");
   static_assert(MT == 1 || (RA && CPL == 1), "several row tiles: register-A, 16-column strips");
   constexpr int NG = MAXS / SPG;   // groups per round (MAXS is a multiple of SPG; rounds start on a group boundary)
@@ -127,23 +145,62 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && CPL == 4 && SPG == 4 && !RA) ?
   uint4_t xa[XL];
   bool xkeep[XL];
   int xdst[XL], sdst[XL];
-#pragma unroll
-  for (int u = 0; u < XL; ++u) {
+  // chunk u of this lane: element offset in x, "k is inside the wave's chunk", LDS destination (-1: surplus lane), (Sx,Sx') slot
+  auto x_index = [&](int u, uint32_t &off, bool &keep, int &dst, int &sd) {
     const int cu = lane + 64 * u;
     const int c = min(cu, xlast);  // surplus lanes re-read the last chunk and are masked out below
     const int row = (M == 1) ? 0 : c / cpr;
     const int kc = c - row * cpr;
     const int k = 32 * t0 + 8 * kc;
-    const size_t off = (size_t)row * p.K + min(k, p.K - 8);
-    // raw 16 bytes now (fp16 or bf16: same size); bf16 is converted when the chunk is staged -- converting here put a
-    // vmcnt(0) between this load and every load after it
-    xa[u] = *(const uint4_t *)((const uint16_t *)p.x + off);
-    xkeep[u] = (k < kend);
-    xdst[u] = (cu <= xlast) ? row * xrow + 8 * kc : -1;
-    sdst[u] = (kc / GL) * 16 + row;
+    off = (uint32_t)(row * p.K + min(k, p.K - 8));
+    keep = (k < kend);
+    dst = (cu <= xlast) ? row * xrow + 8 * kc : -1;
+    sd = (kc / GL) * 16 + row;
+  };
+  if constexpr (!CH) {
+#pragma unroll
+    for (int u = 0; u < XL; ++u) {
+      uint32_t off;
+      x_index(u, off, xkeep[u], xdst[u], sdst[u]);
+      // raw 16 bytes now (fp16 or bf16: same size); bf16 is converted when the chunk is staged -- converting here put a
+      // vmcnt(0) between this load and every load after it
+      xa[u] = *(const uint4_t *)((const uint16_t *)p.x + off);
+    }
   }
   // lanes whose MFMA row is >= M read a valid row: their products only reach output rows that are never stored
   const half_t *xlane = xs + min(i, M - 1) * xrow + 8 * g;
+
+  // CH: this wave's activation chunk, issued AFTER its weight loads.  Chained input: L1-bypassing 8-byte loads, repeated
+  // until no half of the chunk is the 0xFFFF "not written yet" pattern (the wave decides as a whole; vmcnt is in-order, so the
+  // first pass also waits for the wave's weights -- by then they are needed anyway).
+  auto chain_load_x = [&]() {
+    uint16_t *xb = (uint16_t *)p.x;
+    uint32_t xoff[XL];  // (the index arithmetic sits here, after the weight loads, so it holds no registers while they are issued)
+#pragma unroll
+    for (int u = 0; u < XL; ++u) x_index(u, xoff[u], xkeep[u], xdst[u], sdst[u]);
+    if (p.chain & 1) {
+      for (uint32_t spin = 0;; ++spin) {
+        bool bad = false;
+#pragma unroll
+        for (int u = 0; u < XL; ++u) {
+          uint64_t *a = (uint64_t *)(xb + xoff[u]);
+          const uint64_t lo = __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const uint64_t hi = __hip_atomic_load(a + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          xa[u] = uint4_t{(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
+          bad = bad || has_ffff16(lo) || has_ffff16(hi);
+        }
+        if (__builtin_amdgcn_ballot_w64(bad) == 0) break;
+        if (spin >= kChainSpinLimit) {
+          if (lane == 0) atomicOr(p.err, 1u);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < XL; ++u) xa[u] = *(const uint4_t *)(xb + xoff[u]);
+    }
+  };
 
   auto stage_x = [&]() {
 #pragma unroll
@@ -190,7 +247,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && CPL == 4 && SPG == 4 && !RA) ?
       }
     }
   };
-  if (!RA && XL > 2) stage_x();
+  if (!RA && !CH && XL > 2) stage_x();
 
   float4_t yacc[MT][CPL];
 #pragma unroll
@@ -283,7 +340,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && CPL == 4 && SPG == 4 && !RA) ?
 
     // ---- 4. first round: activations -> LDS (needs only the OLDEST loads; the weights stay in flight).  For many rows
     //         (XL > 2) the chunk was staged before the weight loads instead, to keep its registers out of this region.
-    if (!RA && XL <= 2 && r == 0) stage_x();
+    if constexpr (CH) {
+      if (r == 0) { chain_load_x(); stage_x(); }
+    }
+    if (!RA && !CH && XL <= 2 && r == 0) stage_x();
 
     // ---- 5. straight-line: raw-magic B fragments -> MFMA; one fp32 correction per group ----------------------------------
     const half_t *xr = xlane + 32 * (r * MAXS);
@@ -397,6 +457,33 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && CPL == 4 && SPG == 4 && !RA) ?
       }
     }
   __syncthreads();
+  if constexpr (CH) {
+    if (p.chain & 2) {
+      // publish: two adjacent columns per thread as ONE 4-byte write-through (sc1) store; a result that happens to be the
+      // 0xFFFF NaN pattern is rewritten to another NaN (0xFE00 / bf16 0xFFC0) so it cannot be mistaken for "not written"
+      for (int e = threadIdx.x; e < M * (TN / 2); e += NW * 64) {
+        const int row = e / (TN / 2), col = 2 * (e - row * (TN / 2));
+        float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < NW; ++wv) {
+          v0 += red[(wv * M + row) * TN + col];
+          v1 += red[(wv * M + row) * TN + col + 1];
+        }
+        const int nn = b * TN + col;
+        if (pr.bias) { v0 += (float)pr.bias[nn]; v1 += (float)pr.bias[nn + 1]; }
+        uint32_t h0, h1;
+        if (p.act_bf16) {
+          h0 = f32_to_bf16(v0); h1 = f32_to_bf16(v1);
+          h0 = (h0 == 0xffffu) ? 0xffc0u : h0; h1 = (h1 == 0xffffu) ? 0xffc0u : h1;
+        } else {
+          h0 = __builtin_bit_cast(uint16_t, (half_t)v0); h1 = __builtin_bit_cast(uint16_t, (half_t)v1);
+          h0 = (h0 == 0xffffu) ? 0xfe00u : h0; h1 = (h1 == 0xffffu) ? 0xfe00u : h1;
+        }
+        __hip_atomic_store((uint32_t *)((uint16_t *)pr.y + (size_t)row * N + nn), h0 | (h1 << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      return;
+    }
+  }
   for (int e = threadIdx.x; e < M * TN; e += NW * 64) {
     const int row = e / TN, col = e - row * TN;
     float v = 0.f;
@@ -411,14 +498,12 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && CPL == 4 && SPG == 4 && !RA) ?
   }
 }
 
-template <int NW, int CPL, int MAXS, int SPG, int XL, int BITS = 4, bool RA = false, bool RA_BF16 = false, int MT = 1>
+template <int NW, int CPL, int MAXS, int SPG, int XL, int BITS = 4, bool RA = false, bool RA_BF16 = false, int MT = 1, bool CH = false>
 static int launch_strip_t(const StripParams &p, int grid, size_t lds, hipStream_t stream) {
-  static bool attr_done = false;
-  if (!attr_done) {
-    QLLM_HIP_CHECK(hipFuncSetAttribute((const void *)strip_kernel<NW, CPL, MAXS, SPG, XL, BITS, RA, RA_BF16, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done = true;
-  }
-  hipLaunchKernelGGL((strip_kernel<NW, CPL, MAXS, SPG, XL, BITS, RA, RA_BF16, MT>), dim3(grid), dim3(NW * 64), lds, stream, p);
+  // the >64 KB dynamic-LDS opt-in is a per-DEVICE function attribute: latch it per (kernel instantiation, device)
+  static DeviceLatch attr_done;
+  if (int rc = lds_optin(attr_done, (const void *)strip_kernel<NW, CPL, MAXS, SPG, XL, BITS, RA, RA_BF16, MT, CH>)) return rc;
+  hipLaunchKernelGGL((strip_kernel<NW, CPL, MAXS, SPG, XL, BITS, RA, RA_BF16, MT, CH>), dim3(grid), dim3(NW * 64), lds, stream, p);
   QLLM_HIP_CHECK(hipGetLastError());
   return QLLM_OK;
 }
@@ -426,9 +511,23 @@ static int launch_strip_t(const StripParams &p, int grid, size_t lds, hipStream_
 // (waves per block, weight loads per lane per round): 16 waves x 8 or 24, or 8 waves x 16
 // (64-column strips always use rounds of 8: 4 dwords per load keep the register budget of a 1024-thread block;
 //  register-A launches always use rounds of 8: each k-step also holds 16 B of activations per lane)
-static int strip_maxs(int nw, int spw, int cpl, int ra) { return (ra || cpl >= 2) ? 8 : (nw == 8 ? 16 : (spw <= 8 ? 8 : 24)); }
-static int strip_spw_pad(int nw, int spw, int cpl, int ra) { const int m = strip_maxs(nw, spw, cpl, ra); return (spw + m - 1) / m * m; }
-static int strip_xl(int nw, int M, int spw, int cpl) { return (M * strip_spw_pad(nw, spw, cpl, 0) * 4 + 63) / 64; }
+// chained links (chain != 0): 16-wave blocks must fit 64 registers -> one round of 8 (short K only); 8-wave blocks (128
+// registers): the largest round of {24, 16, 8} k-steps that pads the wave's chunk least
+int strip_maxs(int nw, int spw, int cpl, int ra, int chain) {
+  if (ra || cpl >= 2) return 8;
+  if (chain) {
+    if (nw == 16) return 8;
+    int best = 8, best_pad = (spw + 7) / 8 * 8;
+    for (int m = 16; m <= 24; m += 8) {
+      const int pad = (spw + m - 1) / m * m;
+      if (pad <= best_pad) { best = m; best_pad = pad; }
+    }
+    return best;
+  }
+  return nw == 8 ? 16 : (spw <= 8 ? 8 : 24);
+}
+static int strip_spw_pad(int nw, int spw, int cpl, int ra, int chain) { const int m = strip_maxs(nw, spw, cpl, ra, chain); return (spw + m - 1) / m * m; }
+static int strip_xl(int nw, int M, int spw, int cpl, int chain) { return (M * strip_spw_pad(nw, spw, cpl, 0, chain) * 4 + 63) / 64; }
 
 template <int SPG, bool BF>
 static int launch_strip_ra(const StripParams &p, int grid, size_t lds, hipStream_t stream) {
@@ -449,9 +548,24 @@ static int launch_strip_ra(const StripParams &p, int grid, size_t lds, hipStream
 template <int SPG>
 static int launch_strip_s(const StripParams &p, int grid, size_t lds, hipStream_t stream) {
   if (p.ra) return p.act_bf16 ? launch_strip_ra<SPG, true>(p, grid, lds, stream) : launch_strip_ra<SPG, false>(p, grid, lds, stream);
-  const bool small_x = strip_xl(p.nw, p.M, p.spw, p.cpl) <= 2;
+  if (p.chain) {  // chained links: 4 bits, <= 4 activation chunks per lane, g128 for the 64-column strips (host planner)
+    const bool x2 = strip_xl(p.nw, p.M, p.spw, p.cpl, 1) <= 2;
+#define QLLM_CH(NW_, CPL_, MAXS_) \
+  return x2 ? launch_strip_t<NW_, CPL_, MAXS_, SPG, 2, 4, false, false, 1, true>(p, grid, lds, stream) \
+            : launch_strip_t<NW_, CPL_, MAXS_, SPG, 4, 4, false, false, 1, true>(p, grid, lds, stream)
+    if (p.cpl == 4) {
+      if constexpr (SPG == 4) { QLLM_CH(8, 4, 8); } else return set_error(QLLM_ERR_UNSUPPORTED, "chained 64-column strips: group size 128 only");
+    }
+    if (p.nw == 16) { QLLM_CH(16, 1, 8); }
+    const int m = strip_maxs(8, p.spw, 1, 0, 1);
+    if (m == 24) { QLLM_CH(8, 1, 24); }
+    if (m == 16) { QLLM_CH(8, 1, 16); }
+    QLLM_CH(8, 1, 8);
+#undef QLLM_CH
+  }
+  const bool small_x = strip_xl(p.nw, p.M, p.spw, p.cpl, 0) <= 2;
   if (p.bits == 3) {  // 16-column strips, 16 waves
-    if (strip_maxs(16, p.spw, 1, 0) == 8)
+    if (strip_maxs(16, p.spw, 1, 0, 0) == 8)
       return small_x ? launch_strip_t<16, 1, 8, SPG, 2, 3>(p, grid, lds, stream) : launch_strip_t<16, 1, 8, SPG, 8, 3>(p, grid, lds, stream);
     return small_x ? launch_strip_t<16, 1, 24, SPG, 2, 3>(p, grid, lds, stream) : launch_strip_t<16, 1, 24, SPG, 8, 3>(p, grid, lds, stream);
   }
@@ -463,7 +577,7 @@ static int launch_strip_s(const StripParams &p, int grid, size_t lds, hipStream_
     return small_x ? launch_strip_t<16, 2, 8, SPG, 2>(p, grid, lds, stream) : launch_strip_t<16, 2, 8, SPG, 8>(p, grid, lds, stream);
   if (p.nw == 8)
     return small_x ? launch_strip_t<8, 1, 16, SPG, 2>(p, grid, lds, stream) : launch_strip_t<8, 1, 16, SPG, 8>(p, grid, lds, stream);
-  if (strip_maxs(16, p.spw, 1, 0) == 8)
+  if (strip_maxs(16, p.spw, 1, 0, 0) == 8)
     return small_x ? launch_strip_t<16, 1, 8, SPG, 2>(p, grid, lds, stream) : launch_strip_t<16, 1, 8, SPG, 8>(p, grid, lds, stream);
   return small_x ? launch_strip_t<16, 1, 24, SPG, 2>(p, grid, lds, stream) : launch_strip_t<16, 1, 24, SPG, 8>(p, grid, lds, stream);
 }
@@ -482,10 +596,10 @@ int strip_spw(int K, int group_size, int nw) {
   return (spw + spg - 1) / spg * spg;
 }
 
-size_t strip_lds_bytes(int M, int spw, int nw, int cpl, int group_size, int ra) {
+size_t strip_lds_bytes(int M, int spw, int nw, int cpl, int group_size, int ra, int chain) {
   const size_t red = (size_t)nw * M * 16 * cpl * sizeof(float);
   if (ra) return red;  // register-A: only the cross-wave reduction buffer
-  const int pad = strip_spw_pad(nw, spw, cpl, 0);
+  const int pad = strip_spw_pad(nw, spw, cpl, 0, chain);
   const int groups = pad / (group_size / 32);  // groups per wave chunk
   return red + (size_t)nw * M * (pad * 32 + 8) * sizeof(half_t) +
          (size_t)nw * groups * 16 * 8;  // (Sx, Sx') float2 per (group, row), 16 rows per group
@@ -501,10 +615,10 @@ int strip_cpl(int cols_total, bool all_mult64, bool all_mult32) {
 }
 
 // activation staging budget: at most 8 sixteen-byte chunks per lane
-bool strip_x_ok(int M, int spw, int nw, int cpl) { return strip_xl(nw, M, spw, cpl) <= 8; }
+bool strip_x_ok(int M, int spw, int nw, int cpl, int chain) { return strip_xl(nw, M, spw, cpl, chain) <= (chain ? 4 : 8); }
 
 int launch_strip(const StripParams &p, int grid, hipStream_t stream) {
-  const size_t lds = strip_lds_bytes(p.M, p.spw, p.nw, p.cpl, p.group_size, p.ra);
+  const size_t lds = strip_lds_bytes(p.M, p.spw, p.nw, p.cpl, p.group_size, p.ra, p.chain ? 1 : 0);
   if (p.group_size == 64) return launch_strip_s<2>(p, grid, lds, stream);
   return launch_strip_s<4>(p, grid, lds, stream);
 }

@@ -109,6 +109,10 @@ def swap_quantized_linears(model: torch.nn.Module, quantized_names, cfg: QuantCo
     target = modelutils.select_quant_linear(cfg.version, cfg.bits, cfg.quant_method)
     info = {n: cfg.by_layer.get(n, {"wbits": cfg.bits, "groupsize": cfg.group_size}) for n in quantized_names}
     modelutils.make_mixbits_quant_linear(model, set(quantized_names), info, target_layer=target)
+    # q/k/v and gate/up read the same tensor: one grouped launch per group at decode sizes (q_layers/fused.py); the modules,
+    # their names and their state-dict buffers are untouched
+    from .q_layers import install_sibling_groups
+    model.sibling_groups = install_sibling_groups(model, [target])
     return target
 
 

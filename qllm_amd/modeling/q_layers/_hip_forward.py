@@ -10,10 +10,33 @@ import torch
 from ... import ops
 
 
+def _tkey(t):
+    """Cache key of one buffer: storage address AND in-place version (load_state_dict / .copy_ bump `_version`)."""
+    return (0, 0) if t is None else (t.data_ptr(), t._version)
+
+
+# derived, pointer-holding state (ctypes descriptors, shadows, sibling groups): rebuilt on demand, never copied or pickled
+_DERIVED = ("_desc", "_desc_key", "_desc_keep", "_shadow", "_shadow_key", "_ao", "_ao_key", "_rs", "_rs_key", "_siblings")
+
+
 class HipForwardMixin:
     _desc = None
     _desc_key = None
     _desc_keep = None
+    _siblings = None  # SiblingGroup (fused.py) when the layer shares its input with q/k/v or gate/up siblings
+
+    def __getstate__(self):
+        # nn.Module pickles / deep-copies its __dict__: drop the caches that hold raw device pointers into THIS module's
+        # buffers (a copy must build its own), like the reference's modules, which carry no such state.  nn.Module defines
+        # __getstate__ itself and comes first in the q_layers' MRO, so each q_layer class re-exports this one explicitly.
+        state = torch.nn.Module.__getstate__(self)
+        for k in _DERIVED:
+            state.pop(k, None)
+        return state
+
+    def _invalidate(self):
+        for k in _DERIVED[:-1]:
+            self.__dict__.pop(k, None)
 
     def _layout_name(self) -> str:
         raise NotImplementedError
@@ -28,9 +51,7 @@ class HipForwardMixin:
     def _descriptor(self, act_order_g_idx, add_zero_bias: int):
         qzeros = self.qzeros
         bias = self.bias
-        key = (self.qweight.data_ptr(), self.scales.data_ptr(), qzeros.data_ptr() if qzeros is not None else 0,
-               bias.data_ptr() if bias is not None else 0,
-               act_order_g_idx.data_ptr() if act_order_g_idx is not None else 0, add_zero_bias)
+        key = (_tkey(self.qweight), _tkey(self.scales), _tkey(qzeros), _tkey(bias), _tkey(act_order_g_idx), add_zero_bias)
         if self._desc is None or key != self._desc_key:
             lay = self._layout_name()
             scales = self._f16(self.scales).contiguous()
@@ -57,6 +78,10 @@ class HipForwardMixin:
             raise RuntimeError(
                 f"{type(self).__name__}.forward needs HIP tensors on an MI355X: qllm_amd ships no CPU / eager fallback "
                 f"(x on {x.device}, qweight on {self.qweight.device})")
+        if self._siblings is not None and act_order_g_idx is None:
+            y = self._siblings.forward_for(self, x)  # q/k/v, gate/up: one grouped launch for the whole group (fused.py)
+            if y is not None:
+                return y
         x2d = x.reshape(-1, x.shape[-1])
         if not x2d.is_contiguous():
             x2d = x2d.contiguous()

@@ -1,0 +1,104 @@
+"""Sibling groups: quantized linears that read the SAME activation tensor (q/k/v, gate/up) served by ONE grouped launch at
+decode sizes, without touching the model code or the state dict.
+
+The reference swaps one module per nn.Linear (qllm/utils/modelutils.py:161-181) and the HF model code calls
+`q_proj(x)`, `k_proj(x)`, `v_proj(x)` one after the other.  Here the modules stay in place (same names, same buffers); they
+additionally share a `SiblingGroup`.  The first sibling called with a tensor `x` launches the grouped kernel for ALL
+siblings (`qllm_linear_forward_grouped`: one launch, x read once, 2-3x more bytes in flight per launch) and parks the others'
+outputs; when the model then calls the next sibling with the very same tensor object (and the tensor was not modified in
+between: `x._version`), it gets the parked output.  Anything else -- another tensor, a larger M, act-order, a shape the
+grouped kernel does not take -- falls back to the module's own single launch, so results never depend on call patterns.
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional, Sequence
+
+import torch
+
+from ... import ops
+
+GROUP_MAX_M = 64  # the grouped entry point serves decode sizes only (include/qllm_mi355x.h)
+
+# attribute names of siblings inside one parent module (Llama / Mistral / Qwen2, OPT, Falcon-style MLPs, ...)
+SIBLING_PATTERNS = (("q_proj", "k_proj", "v_proj"), ("gate_proj", "up_proj"), ("w1", "w3"))
+
+
+class SiblingGroup:
+    def __init__(self, layers: Sequence[torch.nn.Module]):
+        self.layers = list(layers)
+        self.enabled = True
+        self._x: Optional[torch.Tensor] = None
+        self._ver = -1
+        self._parked: dict = {}
+        self.grouped_launches = 0  # diagnostics / tests
+
+    def describe(self, m: int = 1) -> str:
+        return ops.plan_describe([l.decode_descriptor() for l in self.layers], m)
+
+    def compatible(self) -> bool:
+        a = self.layers[0]
+        for l in self.layers:
+            if type(l) is not type(a) or l.infeatures != a.infeatures or l.bits != a.bits or l.groupsize != a.groupsize:
+                return False
+            if getattr(l, "act_order", None):  # every sibling would need its own permutation of x
+                return False
+        return True
+
+    def forward_for(self, layer, x: torch.Tensor) -> Optional[torch.Tensor]:
+        """Output of `layer` for x, or None when the caller must run its own launch."""
+        if not self.enabled:
+            return None
+        key = id(layer)
+        if self._x is x and x._version == self._ver and key in self._parked:
+            out = self._parked.pop(key)
+            if not self._parked:
+                self._x = None
+            return out
+        self._x, self._parked = None, {}
+        x2d = x.reshape(-1, x.shape[-1])
+        if x2d.shape[0] > GROUP_MAX_M or x2d.shape[0] == 0 or not x2d.is_contiguous() or not self.compatible():
+            return None
+        try:
+            outs = ops.linear_forward_grouped([l.decode_descriptor() for l in self.layers], x2d)
+        except ops.QllmUnsupported:
+            self.enabled = False  # this group's shape has no grouped kernel: never ask again
+            return None
+        self.grouped_launches += 1
+        shape = x.shape[:-1]
+        mine = None
+        for l, o in zip(self.layers, outs):
+            o = o.reshape(shape + (l.outfeatures,))
+            if l is layer:
+                mine = o
+            else:
+                self._parked[id(l)] = o
+        self._x, self._ver = x, x._version
+        return mine
+
+
+def fuse_siblings(layers: Sequence[torch.nn.Module]) -> SiblingGroup:
+    """Make `layers` (q_layers with equal in_features / bits / groupsize) one sibling group."""
+    g = SiblingGroup(layers)
+    for l in layers:
+        l._siblings = g
+    return g
+
+
+def install_sibling_groups(model: torch.nn.Module, q_layer_types) -> int:
+    """Group the q_layers of every parent module that match one of SIBLING_PATTERNS.  Returns the number of groups.
+    QLLM_FUSE_SIBLINGS=0 disables it."""
+    if os.environ.get("QLLM_FUSE_SIBLINGS", "1") == "0":
+        return 0
+    n = 0
+    types = tuple(q_layer_types)
+    for parent in model.modules():
+        for names in SIBLING_PATTERNS:
+            subs = [getattr(parent, nm, None) for nm in names]
+            if all(isinstance(s, types) for s in subs):
+                g = SiblingGroup(subs)
+                if g.compatible():
+                    for s in subs:
+                        s._siblings = g
+                    n += 1
+    return n

@@ -9,7 +9,7 @@ import os
 import torch
 import torch.nn as nn
 
-from ._hip_forward import HipForwardMixin
+from ._hip_forward import HipForwardMixin, _tkey
 from .compress_weight import CompressWeight, pack_bitstream, unpack_bitstream
 
 AWQ_ORDER = (0, 2, 4, 6, 1, 3, 5, 7)
@@ -22,6 +22,8 @@ def _awq_col_index(n: int, device) -> torch.Tensor:
 
 
 class WQLinear_GEMM(nn.Module, CompressWeight, HipForwardMixin):
+    __getstate__ = HipForwardMixin.__getstate__  # nn.Module precedes the mixin in the MRO
+
     def __init__(self, w_bit, group_size, in_features, out_features, bias, dtype=None):
         super().__init__()
         self.dtype = torch.get_default_dtype() if dtype is None else dtype
@@ -102,8 +104,7 @@ class WQLinear_GEMM(nn.Module, CompressWeight, HipForwardMixin):
         if os.environ.get("QLLM_AWQ_DECODE_SHADOW", "1") == "0" or self.outfeatures % 16 != 0:
             return self._descriptor(None, 0)
         from ... import ops
-        key = (self.qweight.data_ptr(), self.qzeros.data_ptr(), self.scales.data_ptr(),
-               self.bias.data_ptr() if self.bias is not None else 0)
+        key = (_tkey(self.qweight), _tkey(self.qzeros), _tkey(self.scales), _tkey(self.bias))
         if self._shadow is None or key != self._shadow_key:
             dev = self.qweight.device
             q = ops.unpack_qweight(self.qweight.contiguous(), "GEMM", 4, self.infeatures, self.outfeatures)

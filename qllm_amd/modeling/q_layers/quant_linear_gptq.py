@@ -8,7 +8,7 @@ import os
 import torch
 import torch.nn as nn
 
-from ._hip_forward import HipForwardMixin, autogptq_compat
+from ._hip_forward import HipForwardMixin, _tkey, autogptq_compat
 from .compress_weight import CompressWeight, general_pack_on_row, general_unpack_on_row
 
 
@@ -20,6 +20,9 @@ class QuantLinearGPTQ(nn.Module, CompressWeight, HipForwardMixin):
         g_idx   i32 [K] (registered buffer; default k // g)
         bias    dtype [N] or None
     """
+
+    __getstate__ = HipForwardMixin.__getstate__  # nn.Module precedes the mixin in the MRO
+
 
     def __init__(self, bits, groupsize, infeatures, outfeatures, bias, dtype=None):
         super().__init__()
@@ -75,8 +78,7 @@ class QuantLinearGPTQ(nn.Module, CompressWeight, HipForwardMixin):
         if os.environ.get("QLLM_ACTORDER_SHADOW", "1") == "0" or self.bits != 4 or not self.qweight.is_cuda:
             return None
         from ... import ops
-        key = (self.qweight.data_ptr(), self.scales.data_ptr(), self.qzeros.data_ptr(), self.g_idx.data_ptr(),
-               self.bias.data_ptr() if self.bias is not None else 0, add_zero_bias)
+        key = (_tkey(self.qweight), _tkey(self.scales), _tkey(self.qzeros), _tkey(self.g_idx), _tkey(self.bias), add_zero_bias)
         if self._ao is None or key != self._ao_key:
             dev = self.qweight.device
             g = self.g_idx.to(dev).long()

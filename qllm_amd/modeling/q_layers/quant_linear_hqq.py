@@ -17,6 +17,9 @@ class QuantLinearHQQ(nn.Module, CompressWeight, HipForwardMixin):
     [ceil(K/g), N] each (the zeros are real numbers: HQQ does not round them); bias [N] or None.  g_idx is a plain
     attribute (never act-order), exactly as in the reference."""
 
+    __getstate__ = HipForwardMixin.__getstate__  # nn.Module precedes the mixin in the MRO
+
+
     SUPPORTED_BITS = (2, 3, 4, 5, 6, 7, 8)
 
     def __init__(self, bits, groupsize, infeatures, outfeatures, bias, dtype=None):

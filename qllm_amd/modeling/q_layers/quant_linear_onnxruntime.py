@@ -24,7 +24,7 @@ import math
 import torch
 import torch.nn as nn
 
-from ._hip_forward import HipForwardMixin
+from ._hip_forward import HipForwardMixin, _tkey
 from .compress_weight import CompressWeight
 
 
@@ -57,6 +57,8 @@ def dequantize_blockwise_4bits(quant_values, scale, zero_point, g_idx, rows, col
 
 
 class QuantLinearORT(nn.Module, CompressWeight, HipForwardMixin):
+    __getstate__ = HipForwardMixin.__getstate__  # nn.Module precedes the mixin in the MRO
+
     def __init__(self, bits, groupsize, infeatures, outfeatures, bias, dtype=None):
         super().__init__()
         self.dtype = torch.get_default_dtype() if dtype is None else dtype
@@ -156,8 +158,7 @@ class QuantLinearORT(nn.Module, CompressWeight, HipForwardMixin):
 
     def _descriptor(self, act_order_g_idx=None, add_zero_bias: int = 0):
         from ... import ops
-        key = (self.qweight.data_ptr(), self.scales.data_ptr(), self.qzeros.data_ptr(), self.g_idx.data_ptr(),
-               self.bias.data_ptr() if self.bias is not None else 0)
+        key = (_tkey(self.qweight), _tkey(self.scales), _tkey(self.qzeros), _tkey(self.g_idx), _tkey(self.bias))
         if (self._desc is None and self._desc_key is None) or key != self._desc_key:
             if self.bits != 4:
                 raise NotImplementedError("the ORT blob layout is 4-bit only")

@@ -114,3 +114,24 @@ def test_pack_unpack_roundtrip_random(bits):
     assert np.array_equal(O.unpack_along_rows(O.pack_along_rows(q, bits), bits, 96), q)
     z = rng.integers(0, 2 ** bits, size=(5, 64), dtype=np.int32)
     assert np.array_equal(O.unpack_along_cols(O.pack_along_cols(z, bits), bits, 64), z)
+
+
+# ---- the torch formulation that bench.py times as cpu_baseline (oracle/ref_torch.py) ------------------------------------
+@pytest.mark.parametrize("name", [n for n in golden_names() if n.startswith("gptq_w") and any(f"_w{b}_" in n for b in (2, 4, 8))])
+def test_torch_formulation_is_bit_identical_to_the_oracle_and_the_reference(name):
+    import torch
+    from oracle import ref_torch as T
+    g = load_golden(name)
+    act = O.is_act_order(g["g_idx"], g["groupsize"])
+    t = {k: torch.from_numpy(np.ascontiguousarray(g[k])) for k in ("qweight", "scales", "qzeros", "g_idx", "x")}
+    gi = t["g_idx"] if act else None
+    w = T.dequant_gptq_torch(t["qweight"], t["scales"], t["qzeros"], g["groupsize"], g["bits"], gi, g["compat"])
+    assert w.dtype == torch.float16
+    w_oracle = O.dequant("GPTQ", g["qweight"], g["scales"], g["qzeros"], g["g_idx"] if act else None, g["bits"], g["groupsize"],
+                         g["K"], g["compat"])
+    assert np.array_equal(w.numpy().view(np.uint16), w_oracle.view(np.uint16))
+    if "W_fwd" in g:
+        assert np.array_equal(w.numpy().view(np.uint16), g["W_fwd"].view(np.uint16))      # the reference's own W, bit for bit
+    bias = torch.from_numpy(g["bias"]) if g["bias"] is not None else None
+    y = T.forward_gptq_torch(t["x"], t["qweight"], t["scales"], t["qzeros"], g["groupsize"], g["bits"], gi, bias, g["compat"])
+    assert O.rel_err(y.numpy(), g["y"]) <= 1e-3

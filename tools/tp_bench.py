@@ -1,0 +1,223 @@
+"""BASELINE configs[4]: Llama-2-70B AWQ w4 g128, per-layer matmuls sharded column-parallel over 8 GPUs with one RCCL
+all-reduce per Megatron pair.  Used by bench.py:
+
+    python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8 --tp 8     the real thing (one rank per GPU)
+    python bench.py --tp 1                                                            the per-rank shard shapes, no collective
+    bench.py (default run)                                                            extra.tp_shard_* via shard_shapes_leg()
+
+Per rank and layer at TP = P (hidden 8192, 64 heads / 8 KV heads, intermediate 28672, 80 layers):
+    q/k/v   column-parallel, 8192 -> (8192 + 2 x 1024) / P, one grouped launch (sibling group), output stays sharded
+    o       row-parallel,    8192 / P -> 8192, partial sums -> ONE all-reduce of [M, 8192]
+    gate/up column-parallel, 8192 -> 2 x 28672 / P, one grouped launch, output stays sharded
+    down    row-parallel,    28672 / P -> 8192, ONE all-reduce
+so a layer costs four kernel launches and two all-reduces on the compute stream (qllm_amd/parallel.py wrappers; the
+attention / activation glue between the linears is not part of the hot path and is stood in for by feeding the q and gate
+shards forward, which have exactly the row-parallel layers' input widths).  The reference has no distributed code at all
+(qllm/modeling/base.py:294-295 asserts the sharded branch away).
+"""
+import json
+import os
+import time
+
+import torch
+
+H70, KV70, I70, L70, G = 8192, 1024, 28672, 80, 128
+HBM_PEAK_GBPS = 8000.0
+MFMA_PEAK_TFLOPS = 2500.0
+
+
+def _alg_bytes(K, N, M, g=G):
+    Gn = (K + g - 1) // g
+    return K * N // 2 + Gn * N * 2 + Gn * N // 2 + 2 * M * K + 2 * M * N
+
+
+def _layer(cls, K, N, dev, gen):
+    layer = cls(4, G, K, N, False, dtype=torch.float16)
+    layer.qweight = torch.randint(-2 ** 31, 2 ** 31 - 1, layer.qweight.shape, dtype=torch.int32, device=dev, generator=gen)
+    layer.qzeros = torch.randint(-2 ** 31, 2 ** 31 - 1, layer.qzeros.shape, dtype=torch.int32, device=dev, generator=gen)
+    layer.scales = ((torch.rand(layer.scales.shape, device=dev, generator=gen) * 0.4 + 0.8) / (K ** 0.5 * 6.5)).to(torch.float16)
+    return layer.to(dev)
+
+
+class ShardBlock(torch.nn.Module):
+    """One decoder layer's shards on this rank, as the Megatron pairing leaves them (built directly at shard shapes: the
+    synthetic integers of a shard are as good as a slice of synthetic full-size integers; tests/ cover slicing)."""
+
+    def __init__(self, cls, P, dev, gen, group=None):
+        super().__init__()
+        from qllm_amd import parallel as TP
+        self.q_proj = _layer(cls, H70, H70 // P, dev, gen)
+        self.k_proj = _layer(cls, H70, KV70 // P, dev, gen)
+        self.v_proj = _layer(cls, H70, KV70 // P, dev, gen)
+        self.o_proj = TP.RowParallelQuantLinear(_layer(cls, H70 // P, H70, dev, gen), group)
+        self.gate_proj = _layer(cls, H70, I70 // P, dev, gen)
+        self.up_proj = _layer(cls, H70, I70 // P, dev, gen)
+        self.down_proj = TP.RowParallelQuantLinear(_layer(cls, I70 // P, H70, dev, gen), group)
+
+    def forward(self, h):
+        q = self.q_proj(h)
+        self.k_proj(h)
+        self.v_proj(h)
+        o = self.o_proj(q)          # row-parallel: all-reduce inside (world > 1)
+        gate = self.gate_proj(o)
+        self.up_proj(o)
+        return self.down_proj(gate)  # all-reduce inside
+
+
+def shard_bytes_per_token(P, n_layers, M=1):
+    per = (_alg_bytes(H70, H70 // P, M) + 2 * _alg_bytes(H70, KV70 // P, M) + _alg_bytes(H70 // P, H70, M) +
+           2 * _alg_bytes(H70, I70 // P, M) + _alg_bytes(I70 // P, H70, M))
+    return n_layers * per
+
+
+def shard_flops(P, n_layers, M):
+    return n_layers * 2.0 * M * (2 * H70 * H70 // P + 2 * H70 * KV70 // P + 3 * H70 * I70 // P)
+
+
+def _capture(fn, warm=2):
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(warm):
+            fn()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = fn()
+    return g, out
+
+
+def _time(fn, iters):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def build_stack(P, n_layers, dev, seed, group=None):
+    from qllm_amd.modeling.q_layers import WQLinear_GEMM, install_sibling_groups
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    blocks = torch.nn.ModuleList([ShardBlock(WQLinear_GEMM, P, dev, gen, group) for _ in range(n_layers)])
+    install_sibling_groups(blocks, [WQLinear_GEMM])
+    return blocks
+
+
+def shard_shapes_leg(dev, n_layers=16):
+    """1 GPU: what one rank of an 8-way tensor-parallel Llama-2-70B executes (no collective), decode M=1 and prefill M=2048."""
+    from qllm_amd import ops
+    P = 8
+    blocks = build_stack(P, n_layers, dev, seed=77)
+
+    def fwd(h):
+        for b in blocks:
+            h = b(h)
+        return h
+
+    out = {}
+    h1 = torch.randn(1, H70, device=dev, dtype=torch.float16)
+    g, y = _capture(lambda: fwd(h1))
+    ms = _time(g.replay, 20)
+    del g
+    nbytes = shard_bytes_per_token(P, n_layers, 1)
+    b0 = blocks[0]
+    out["tp_shard_decode_m1"] = {
+        "what": f"per-rank shards of Llama-2-70B at TP=8 ({n_layers} layers, 4 launches per layer, no collective)",
+        "us_per_layer": round(ms * 1e3 / n_layers, 2), "GBps": round(nbytes / ms / 1e6, 1),
+        "frac_of_hbm_peak": round(nbytes / ms / 1e6 / HBM_PEAK_GBPS, 4),
+        "plans": {"qkv 8192->1024+128+128": b0.q_proj._siblings.describe(1),
+                  "o 1024->8192": ops.plan_describe([b0.o_proj.shard.decode_descriptor()], 1),
+                  "gate/up 8192->2x3584": b0.gate_proj._siblings.describe(1),
+                  "down 3584->8192": ops.plan_describe([b0.down_proj.shard.decode_descriptor()], 1)}}
+    xp = torch.randn(2048, H70, device=dev, dtype=torch.float16)
+    few = torch.nn.ModuleList(list(blocks)[:4])
+
+    def fwd_p():
+        h = xp
+        for b in few:
+            h = b(h)
+        return h
+    g, _ = _capture(fwd_p)
+    ms = _time(g.replay, 10)
+    del g
+    tf = shard_flops(P, 4, 2048) / ms / 1e9
+    out["tp_shard_prefill_m2048"] = {"ms_per_4_layers": round(ms, 3), "TFLOPs": round(tf, 1),
+                                     "frac_of_mfma_peak": round(tf / MFMA_PEAK_TFLOPS, 4)}
+    return out
+
+
+def run(args, world, rank, dev, info):
+    """bench.py --tp N: N ranks (or 1 rank running the TP=8 shard shapes without a collective)."""
+    import torch.distributed as dist
+    P = world if world > 1 else 8
+    if world > 1 and args.tp != world:
+        raise SystemExit(f"--tp {args.tp} needs --gpus {args.tp} (one rank per GPU)")
+    blocks = build_stack(P, L70, dev, seed=4321 + rank)  # every rank: its own shard of every layer
+    M = 1
+    h0 = torch.randn(M, H70, device=dev, dtype=torch.float16)
+    if world > 1:
+        dist.broadcast(h0, 0)
+
+    def step():
+        h = h0
+        for b in blocks:
+            h = b(h)
+        return h
+
+    graph = None
+    try:  # RCCL collectives are graph-capturable on the compute stream; fall back to eager launches if this build refuses
+        graph, out = _capture(step)
+        run_step = graph.replay
+    except Exception as e:  # noqa: BLE001
+        torch.cuda.synchronize()
+        out = step()
+        run_step = step
+        graph = f"eager ({type(e).__name__})"
+    assert torch.isfinite(out.float()).all()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        run_step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run_step()
+    barrier()
+    wall = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([wall], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t[0])
+    ms_per_step = wall * 1e3 / args.steps
+    ar_us = None
+    if world > 1:  # the decode-sized all-reduce on its own ([1, 8192] fp16 = 16 KB: latency-bound over xGMI)
+        buf = torch.zeros(M, H70, device=dev, dtype=torch.float16)
+        for _ in range(10):
+            dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        ar_us = _time(lambda: dist.all_reduce(buf), 200) * 1e3
+    nbytes = shard_bytes_per_token(P, L70, M)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "decode_tokens_per_s_llama2_70b_w4a16_g128_linear_stack_tp", "value": round(M * args.steps / wall, 2),
+            "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": "llama2-70b-awq-w4-g128-decode-b1-tp", "tp_degree": P, "ranks": world,
+                       "layers": L70, "launches_per_layer": 4, "all_reduces_per_layer": 2 if world > 1 else 0,
+                       "graph": graph if isinstance(graph, str) else True, "parallelism": f"tp{P}" + ("" if world > 1 else " (1 rank, no collective)"),
+                       "device": info["arch"]},
+            "roofline": {"bound": "hbm", "kernel": "qllm::strip_kernel", "achieved": round(nbytes / ms_per_step / 1e6, 1),
+                         "peak": HBM_PEAK_GBPS, "unit": "GB/s (per rank)", "frac": round(nbytes / ms_per_step / 1e6 / HBM_PEAK_GBPS, 4),
+                         "traffic": None},
+            "all_reduce_us_16KB": None if ar_us is None else round(ar_us, 2),
+            "cpu_baseline": None}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
