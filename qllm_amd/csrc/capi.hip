@@ -450,6 +450,8 @@ int qllm_linear_forward(const qllm_weight_t *w, const void *x, void *y, int32_t 
     p.slabs = nullptr;
     p.counters = nullptr;
     if (gemm2_ok(p, w->layout)) {
+      // large M: the wave-specialised 256x128 kernel (no split-K needed: every CU has at least one tile)
+      if (gemm3_ok(p, w->layout) && gemm2_split_k(M, w->N, w->K) == 1) return launch_gemm3(p, w->layout, (hipStream_t)stream);
       // split-K when the tiling leaves CUs idle and the caller's workspace can hold the partial tiles (else: no split)
       const int S = gemm2_split_k(M, w->N, w->K);
       const size_t need = kCounterBytes + gemm2_slab_bytes(M, w->N, S);
@@ -544,7 +546,9 @@ int qllm_plan_describe(const qllm_weight_t *w, int32_t n_weights, int32_t M, int
     p.N = w[0].N;
     p.group_size = w[0].group_size;
     p.gs_shift = ((w[0].group_size & (w[0].group_size - 1)) == 0) ? __builtin_ctz((unsigned)w[0].group_size) : -1;
-    if (gemm2_ok(p, w[0].layout)) {
+    if (gemm2_ok(p, w[0].layout) && gemm3_ok(p, w[0].layout) && gemm2_split_k(M, w[0].N, w[0].K) == 1) {
+      snprintf(buf, buflen, "gemm3 tile=256x128 matrix-waves=4 staging-waves=4");
+    } else if (gemm2_ok(p, w[0].layout)) {
       const int S = have_workspace ? gemm2_split_k(M, w[0].N, w[0].K) : 1;
       snprintf(buf, buflen, "gemm2 tile=256x%d split_k=%d", gemm2_tile_n(M, w[0].N, S), S);
     } else {

@@ -116,4 +116,8 @@ int gemm2_tile_n(int M, int N, int split_k);
 size_t gemm2_slab_bytes(int M, int N, int S);
 int launch_gemm2(const GemmParams &p, int layout, hipStream_t stream);
 
+// ---- gemm3.hip (256x128 tile, 4 matrix waves + 4 staging waves; no split-K) ---------------------------------------------
+bool gemm3_ok(const GemmParams &p, int layout);
+int launch_gemm3(const GemmParams &p, int layout, hipStream_t stream);
+
 }  // namespace qllm

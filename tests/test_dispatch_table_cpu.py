@@ -50,8 +50,11 @@ def test_llama7b_decode_routes(lib):
 
 def test_llama7b_prefill_routes(lib):
     attn, up, down = W(4096, 4096), W(4096, 11008), W(11008, 4096)
-    assert plan(lib, [attn], 2048) == "gemm2 tile=256x128 split_k=1"      # 256 tiles: one per CU
-    assert plan(lib, [attn], 8192) == "gemm2 tile=256x256 split_k=1"
+    g3 = "gemm3 tile=256x128 matrix-waves=4 staging-waves=4"
+    assert plan(lib, [attn], 2048) == g3                                   # 256 tiles, one per CU: the wave-specialised kernel
+    assert plan(lib, [attn], 8192) == g3
+    assert plan(lib, [down], 2048) == g3 and plan(lib, [up], 2048) == g3
+    assert plan(lib, [W(4096 + 64, 4096)], 2048) == "gemm2 tile=256x128 split_k=1"   # odd number of k-tiles: gemm2
     assert plan(lib, [attn], 512) == "gemm2 tile=256x128 split_k=4"       # 64 tiles -> 4 blocks per tile
     assert plan(lib, [attn], 256) == "gemm2 tile=256x128 split_k=8"
     assert plan(lib, [down], 1024) == "gemm2 tile=256x128 split_k=2"
@@ -59,7 +62,8 @@ def test_llama7b_prefill_routes(lib):
     assert plan(lib, [attn], 512, have_ws=0) == "gemm2 tile=256x128 split_k=1"  # no workspace: no split, still fused
     assert plan(lib, [attn], 128) == "gemm tile=128x128"                  # 64 < M < 192: the older kernel (next round)
     assert plan(lib, [W(4096, 4000)], 2048) == "gemm tile=128x128"        # ragged N
-    assert plan(lib, [W(4096, 4096, layout=AWQ)], 2048) == "gemm2 tile=256x128 split_k=1"  # AWQ layout read in place
+    assert plan(lib, [W(4096, 4096, layout=AWQ)], 2048) == g3               # AWQ layout read in place
+    assert plan(lib, [W(4096, 4096, layout=AWQ)], 512) == "gemm2 tile=256x128 split_k=4"
 
 
 def test_other_layouts_and_widths(lib):

@@ -453,3 +453,41 @@ def test_ort_blob_forward_vs_oracle(K, N, gs, zk, act, bias):
         y = layer(torch.from_numpy(x).to(DEV)).cpu().numpy()
         ref = O.matmul_f16(x, w_kn, b).numpy() if m <= 8 else O.matmul_f16_via_f32(x, w_kn, b).numpy()
         assert O.rel_err(y, ref) <= TOL, (K, N, m)
+
+
+# ---- wave-specialised prefill kernel (gemm3.hip): M >= 1024, N % 128 == 0, K % 128 == 0 -----------------------------------
+GEMM3_CASES = [
+    ("GPTQ", 128, 4096, 4096, "asym", False),
+    ("GEMM", 128, 4096, 4096, "asym", False),
+    ("GEMM", 128, 4096, 11008, "asym", True),      # 86 column tiles: ragged rounds of blocks, bias
+    ("GPTQ", 128, 11008, 4096, "asym", False),     # 172 k-tiles
+    ("HQQ", 64, 4096, 4096, "f16", False),
+    ("GPTQ", 128, 1024, 1280, "sym", True),        # small: every k-tile boundary case within a few tiles
+    ("GPTQ", 32, 256, 128, "asym", True),          # 4 k-tiles, a new group every half k-tile, one column tile
+]
+
+
+@pytest.mark.parametrize("layout,g,K,N,zk,bias", GEMM3_CASES)
+def test_wave_specialised_prefill_kernel_vs_oracle(layout, g, K, N, zk, bias):
+    from qllm_amd import ops
+    d = synth(layout, 4, g, K, N, zk, False, bias, seed=K + N + 7)
+    layer = to_layer(d, DEV)
+    ref = Ref(d)
+    big = K * N >= 4096 * 4096
+    for m in ((1024, 2048, 2049) if big else (1024, 1100, 1537)):   # whole tiles, and rows that end inside a 256-row tile
+        assert ops.plan_describe([layer._descriptor(None, 0)], m).startswith("gemm3"), (layout, K, N, m)
+        x = randx(m, K, seed=m)
+        y = layer(torch.from_numpy(x).to(DEV)).cpu().numpy()
+        assert y.shape == (m, N)
+        assert O.rel_err(y, ref.y16(x)) <= TOL, (layout, K, N, m)
+        assert O.rel_err(y, ref.y64(x)) <= 2e-3, (layout, K, N, m)
+    if big:
+        return
+    # bf16 activations through the same kernel (converted to fp16 at staging, like x.to(float16) in the reference's shim)
+    xb = torch.from_numpy(randx(1024, K, seed=3)).to(torch.bfloat16)
+    yb = layer(xb.to(DEV))
+    assert yb.dtype == torch.bfloat16
+    assert O.rel_err(yb.float().cpu().numpy(), ref.y64(xb.to(torch.float16).numpy())) <= TOL
+    # determinism: same launch twice -> same bits
+    x = torch.from_numpy(randx(1024, K, seed=9)).to(DEV)
+    assert torch.equal(layer(x), layer(x))
