@@ -143,6 +143,11 @@ int qllm_linear_forward_chained(const qllm_weight_t *w, void *const *y, int32_t 
 /* Text description of the chained plan ("chained strip nw=.. cpl=.. spw=.. round=.. blocks=..") or "not chainable"; pure host. */
 int qllm_chain_plan_describe(const qllm_weight_t *w, int32_t n_weights, int32_t M, char *buf, size_t buflen);
 
+/* Diagnostics (process-global, not thread-safe; NULL switches it off): the next chained launches each take one 64-byte slot
+ * of `buf` (device memory, n_slots x 8 x u64, in launch order) and record 100 MHz device timestamps of their first and last
+ * block: [entry, weight loads issued, input complete, exit] x 2.  A launch captured into a hipGraph keeps its slot. */
+int qllm_debug_timeline(void *buf, int32_t n_slots);
+
 /* W[K,N] (out_transposed = 0) or W[N,K] (out_transposed = 1) in `out_dtype`, bit-identical to
  * DequantizeLinearBlockWise / DequantAndUnpack / unpack().  All bits 2..8, all layouts, optional g_idx.
  * Replaces ort_ops.dequant (ort_ops.cc:58-92). */

@@ -23,6 +23,7 @@ EXPORTS = (
     "qllm_linear_forward", "qllm_linear_forward_grouped", "qllm_dequant", "qllm_ort_gemv", "qllm_ort_dequant",
     "qllm_awq_gemm_forward", "qllm_unpack_qweight", "qllm_pack_qweight", "qllm_ort_dequantize4bits",
     "qllm_plan_describe", "qllm_linear_forward_chained", "qllm_chain_plan_describe",
+    "qllm_debug_timeline",
 )
 CHAIN_POLL_X, CHAIN_PUBLISH_Y = 1, 2
 
@@ -93,6 +94,8 @@ def _declare(lib):
     lib.qllm_linear_forward_chained.argtypes = [wp, C.POINTER(vp), i32, vp, i32, i32, i32, vp, vp]
     lib.qllm_chain_plan_describe.restype = C.c_int
     lib.qllm_chain_plan_describe.argtypes = [wp, i32, i32, C.c_char_p, sz]
+    lib.qllm_debug_timeline.restype = C.c_int
+    lib.qllm_debug_timeline.argtypes = [vp, i32]
     lib.qllm_ort_dequantize4bits.restype = C.c_int
     lib.qllm_ort_dequantize4bits.argtypes = [vp, vp, vp, i32, vp, i32, i32, i32, vp, vp]
 

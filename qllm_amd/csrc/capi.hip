@@ -91,6 +91,10 @@ static int strip_min_strips() {
 struct StripPlan {
   int cpl, nw, spw, ra;
 };
+// diagnostics: timeline buffer handed to chained launches (8 x u64 per launch), see qllm_debug_timeline()
+static uint64_t *g_timeline = nullptr;
+static int g_timeline_slots = 0, g_timeline_next = 0;
+
 constexpr int kChainMaxGrid = 448;          // blocks of a chained link: all co-resident beside the neighbouring link's
 constexpr int kChainMinGrid = 120;          // fewer blocks than about half the CUs: not worth a link (ordinary launch instead)
 constexpr size_t kChainMaxLds = 80 * 1024;  // half a CU
@@ -203,6 +207,7 @@ static int run_strip(const qllm_weight_t *w, void *const *y, int n, const void *
   p.act_bf16 = (act_dtype == QLLM_BF16);
   p.chain = chain;
   p.err = err;
+  p.dbg = (chain && g_timeline && g_timeline_next < g_timeline_slots) ? g_timeline + 8 * (g_timeline_next++) : nullptr;
   int block = 0;
   for (int i = 0; i < n; ++i) {
     StripProblem &q = p.prob[i];
@@ -385,6 +390,14 @@ int qllm_linear_forward_chained(const qllm_weight_t *w, void *const *y, int32_t 
   if (!strip_plan(w, n_weights, M, &pl, 1))
     return set_error(QLLM_ERR_UNSUPPORTED, "no chained-link plan for this shape (M=%d): run it as an ordinary launch", M);
   return run_strip(w, y, n_weights, x, M, act_dtype, (hipStream_t)stream, chain_flags, (uint32_t *)err_word);
+}
+
+int qllm_debug_timeline(void *buf, int32_t n_slots) {
+  clear_error();
+  g_timeline = (uint64_t *)buf;
+  g_timeline_slots = buf ? n_slots : 0;
+  g_timeline_next = 0;
+  return QLLM_OK;
 }
 
 int qllm_chain_plan_describe(const qllm_weight_t *w, int32_t n_weights, int32_t M, char *buf, size_t buflen) {

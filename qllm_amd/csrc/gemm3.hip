@@ -1,29 +1,33 @@
-// Prefill GEMM v3: y[M,N] = x[M,K] . dequant(W4), 256x128x64 block tile, WAVE-SPECIALISED: 4 matrix waves + 4 staging waves.
+// Prefill GEMM v3: y[M,N] = x[M,K] . dequant(W4), 256x128x64 block tile, WAVE-SPECIALISED: 4 matrix waves + 4 dequant waves.
 //
 // Why: gemm2's eight waves all run the same body -- dequantise, stage, read fragments, MFMA -- and the two waves that share
 // a SIMD move through those phases in lockstep between barriers, so the VALU / LDS-store work of one never hides under the
 // MFMAs of the other; the matrix pipe is ~40 % busy (profiles/r01_prefill_summary.md).  Here the roles are split per SIMD
 // (waves w and w+4 share one):
 //   * waves 0-3, "matrix": each owns a 128x64 output tile = 4x2 tiles of v_mfma_f32_32x32x16_f16 (128 accumulator
-//     registers).  Their instruction stream is ds_read_b128 + MFMA only: 6 fragment reads per 8 MFMAs (the 64x64-per-wave
-//     16x16x32 form needs 8 per 8 MFMA-equivalents), fragments double-buffered one k16 sub-step ahead, the k-tile barrier
-//     placed in front of the LAST sub-step's MFMAs so the next tile's first fragment reads are covered too.  One matrix wave
-//     per SIMD keeps the pipe fed as long as its fragments arrive: 32 MFMAs x 32 cycles per k-tile against ~30 other issues.
-//   * waves 4-7, "staging": activations (plain 16-byte loads -> registers -> ds_write_b128, two register sets, requested two
-//     k-tiles ahead) and weights (packed words + raw scale/zero words, two sets; bit-exact 3-op fp16 dequant as everywhere
-//     else, common.hpp) into the OTHER LDS stage.  Their VALU and LDS-store work issues beside the matrix wave's MFMAs
-//     (separate pipes; the matrix waves run at raised priority).
-//   * two LDS stages of (256x64 A + 128x64 B) halves = 96 KB, one workgroup barrier per k-tile:
-//         staging, iteration t:  [request tile t+2] [write tile t+1 -> stage (t+1)%2]            barrier #t
-//         matrix,  iteration t:  sub-steps 0..2 of tile t (stage t%2), fragments of 3 in registers  barrier #t  [read tile
-//                                t+1's first fragments] [MFMAs of sub-step 3]
-//     after barrier #t nobody reads stage t%2 any more (the staging waves overwrite it in iteration t+1) and stage (t+1)%2 is
-//     complete.  __syncthreads() waits for the issuing wave's LDS operations (lgkmcnt(0)) before the barrier; plain global
-//     loads stay in flight across it (counted vmcnt).
+//     registers).  Instruction stream: ds_read_b128 + MFMA (6 fragment reads per 8 MFMAs; fragments double-buffered one k16
+//     sub-step ahead; the k-tile barrier sits in front of the LAST sub-step's MFMAs so the next tile's first fragment reads
+//     are covered too) plus the ACTIVATION tile, which needs no arithmetic: 8 LDS-DMA pieces per wave and k-tile
+//     (buffer_load_dwordx4 ... lds: 1 KB = 8 rows x 128 B each, no registers, no ds_write), requested THREE k-tiles ahead
+//     into a 3-deep ring and retired with a counted vmcnt(8) in front of the barrier.  These waves issue no other vector
+//     memory operation, so the hand-placed vmcnt counts exactly the DMA pieces.
+//   * waves 4-7, "dequant": packed weight words + raw scale/zero words through buffer loads (per-lane offsets fixed, the
+//     k-tile advance is a scalar offset: no address VALU), two register sets requested ~1.5 k-tiles ahead, the bit-exact
+//     3-op fp16 dequant (common.hpp) and ds_write_b128 into the other B stage.  (First version: these waves also staged the
+//     activations through registers -- 12 ds_write_b128 + ~130 VALU per k-tile in ONE wave per SIMD -- and were the
+//     bottleneck: 748 TFLOP/s against gemm2's 846 on 2048x4096x4096.)
+//   * LDS: A 3 x 32 KB + B 2 x 16 KB = 128 KB, one workgroup barrier per k-tile:
+//         dequant, iteration t:  [write B tile t+1 -> stage (t+1)%2]                                      barrier #t
+//         matrix,  iteration t:  sub-steps 0..2 of tile t, fragments of 3 in registers, vmcnt(8)          barrier #t
+//                                [request A tile t+3 -> ring slot t%3] [read tile t+1's first fragments] [MFMAs of sub-step 3]
+//     after barrier #t nobody reads B stage t%2 / A slot t%3 any more, and B stage (t+1)%2 / A slot (t+1)%3 are complete
+//     (every matrix wave waited for its own DMA pieces of tile t+1 before arriving).  The matrix waves use the raw
+//     s_barrier with explicit lgkmcnt(0) / vmcnt(8): __syncthreads() would drain the DMA ring (vmcnt(0)).
 //   * LDS rows are 64 halves (128 B) with the eight 16-byte slots XORed by (row >> 1) & 7: conflict-free for the 32x32x16
 //     fragment reads (lane l -> row l % 32, slot 2*ks + l / 32: each 16-lane service group of ds_read_b128 sees 8 even and
-//     8 odd rows with 8 distinct row>>1 values mod 8), for the activation stores (8 lanes = the 8 slots of one row) and for
-//     the GPTQ weight stores (8 consecutive rows at one slot).
+//     8 odd rows with 8 distinct row>>1 values mod 8) and for the GPTQ weight stores (8 consecutive rows at one slot).  An
+//     LDS-DMA piece lands lane-linear (lane l -> row l / 8, physical slot l % 8), so the swizzle is applied to the SOURCE:
+//     lane l fetches logical chunk (l % 8) ^ ((row >> 1) & 7) of its row (cdna_hip_programming.md rule 21).
 //   * epilogue: + bias, one rounding, transposed through wave-private LDS into 16-byte row-contiguous stores.
 // Serves what gemm2's 256x128 form serves when no split-K is wanted (M >= 1024 on the Llama shapes); gemm2 keeps the rest.
 // Replaces gemm_forward_4bit_cuda_m16n128k32 (/root/reference/csrc/awq_cuda/quantization/gemm_cuda_gen.cu:31-353).
@@ -37,17 +41,18 @@ namespace g3 {
 constexpr int BM = 256, BN = 128, BK = 64;
 constexpr int kATile = BM * BK, kBTile = BN * BK;  // halves per stage
 typedef float float16_t __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void lds_void_t;
 
 __device__ __forceinline__ int tile_off(int row, int slot) { return row * BK + ((slot ^ (row >> 1)) & 7) * 8; }  // in halves
 }  // namespace g3
 
-// LAYOUT 0 = GPTQ/HQQ row stream, 1 = AWQ GEMM.  Requires K % 128 == 0 (even number of k-tiles), N % 128 == 0, power-of-two group size >= 32, no g_idx.
-template <int LAYOUT, bool BF16>
+// LAYOUT 0 = GPTQ/HQQ row stream, 1 = AWQ GEMM.  fp16 activations.  Requires K % 128 == 0 (even number of k-tiles), N % 128 == 0, power-of-two group size >= 32, no g_idx.
+template <int LAYOUT>
 __global__ __launch_bounds__(512) void gemm3_kernel(const GemmParams p) {
   using namespace g3;
   extern __shared__ __attribute__((aligned(16))) half_t smem[];
-  half_t *As = smem;               // [2][256][64]
-  half_t *Bs = smem + 2 * kATile;  // [2][128 n][64 k]
+  half_t *As = smem;               // [3][256][64]  (LDS-DMA ring)
+  half_t *Bs = smem + 3 * kATile;  // [2][128 n][64 k]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -66,30 +71,8 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const GemmParams p) {
   const int KT = p.K / BK;
 
   if (wave >= 4) {
-    // ================================================= staging waves ==================================================
+    // ================================================= dequant waves ==================================================
     const int t = tid - 256;  // 0..255
-    // ---- A: chunk c = t + 256 q: row c / 8, 16-byte k-chunk c % 8 (8 lanes cover one 128-byte row segment) ------------
-    uint4_t aset[2][8];
-    auto load_a = [&](int kt, uint4_t (&areg)[8]) {
-      const int ktc = min(kt, KT - 1);  // past the end: harmless re-read
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int c = t + 256 * q, row = c >> 3, kc = c & 7;
-        const int grow = min(m0 + row, p.M - 1);  // rows past M re-read the last row; their outputs are never stored
-        areg[q] = *(const uint4_t *)((const half_t *)p.x + (size_t)grow * p.K + ktc * BK + 8 * kc);
-      }
-    };
-    auto store_a = [&](int stage, const uint4_t (&areg)[8]) {
-      half_t *Ab = As + stage * kATile;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int c = t + 256 * q, row = c >> 3, kc = c & 7;
-        if constexpr (BF16)
-          *(half8_t *)(Ab + tile_off(row, kc)) = bf16x8_to_h8(areg[q]);
-        else
-          *(uint4_t *)(Ab + tile_off(row, kc)) = areg[q];
-      }
-    };
     // ---- B -------------------------------------------------------------------------------------------------------------
     // GPTQ: thread = column t % 128, word rows 4 (t / 128) .. +3 of the 8 in a k-tile -> 4 x b128 stores
     // AWQ : thread = word column t % 16 (8 columns), k rows 4 (t / 16) .. +3 -> per column one 8-byte store of 4 k
@@ -108,21 +91,29 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const GemmParams p) {
       uint32_t z;
     };
     BSet bset[2];
+    // buffer loads: per-lane byte offsets are loop constants, the k-tile / group advance is a scalar offset (SALU only)
+    const int Gn = (p.K + (1 << p.gs_shift) - 1) >> p.gs_shift;
+    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc((void *)p.qweight, 0, (int)((size_t)p.K * p.N / 2), 0x00020000);
+    const auto rs_s = __builtin_amdgcn_make_buffer_rsrc((void *)p.scales, 0, Gn * p.N * 2, 0x00020000);
+    const auto rs_z = __builtin_amdgcn_make_buffer_rsrc((void *)zbase, 0, Gn * zmul * 4, 0x00020000);
+    const int wrow_bytes = (LAYOUT == 0) ? p.N * 4 : (p.N >> 3) * 4;        // bytes per packed row
+    const int ktile_bytes = ((LAYOUT == 0) ? 8 : BK) * wrow_bytes;         // packed rows per k-tile: 8 (GPTQ) / 64 (AWQ)
+    const int voff_w = brow * wrow_bytes + ((LAYOUT == 0) ? nB * 4 : (nB >> 3) * 4);
+    const int voff_s = nB * 2, voff_z = zoff * 4;
+    const int krow0 = (LAYOUT == 0) ? 8 * brow : brow;                     // this thread's first k inside a k-tile
     auto load_b = [&](int kt, BSet &bs) {
       const int ktc = min(kt, KT - 1);
+      const int so = ktc * ktile_bytes;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if constexpr (LAYOUT == 0)
-          bs.w[r] = p.qweight[(size_t)(ktc * 8 + brow + r) * p.N + nB];
-        else
-          bs.w[r] = p.qweight[(size_t)(ktc * BK + brow + r) * (p.N >> 3) + (nB >> 3)];
-      }
-      const int G = (ktc * BK + ((LAYOUT == 0) ? 8 * brow : brow)) >> p.gs_shift;  // one group per thread per k-tile
+      for (int r = 0; r < 4; ++r) bs.w[r] = __builtin_amdgcn_raw_buffer_load_b32(rs_w, voff_w + r * wrow_bytes, so, 0);
+      // one group per thread per k-tile (group_size >= 32); krow0 is per-lane only through brow (0 or 32 k for GPTQ)
+      const int G0 = (ktc * BK) >> p.gs_shift, G1 = (ktc * BK + 32) >> p.gs_shift;
+      const int G = (LAYOUT == 0) ? ((krow0 >= 32) ? G1 : G0) : ((ktc * BK + krow0) >> p.gs_shift);
       if constexpr (LAYOUT == 0)
-        bs.sraw = ((const uint16_t *)p.scales)[(size_t)G * p.N + nB];
+        bs.sraw = __builtin_amdgcn_raw_buffer_load_b16(rs_s, voff_s + G * p.N * 2, 0, 0);
       else
-        bs.s8 = *(const half8_t *)(p.scales + (size_t)G * p.N + nB);
-      bs.z = zbase[(size_t)G * zmul + zoff];
+        bs.s8 = __builtin_bit_cast(half8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_s, voff_s + G * p.N * 2, 0, 0));
+      bs.z = __builtin_amdgcn_raw_buffer_load_b32(rs_z, voff_z + G * zmul * 4, 0, 0);
     };
     auto store_b = [&](int stage, const BSet &bs) {
       half_t *Bb = Bs + stage * kBTile;
@@ -150,36 +141,29 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const GemmParams p) {
       }
     };
 
-    // Order of one iteration: [write tile kt+1 from its register set] barrier [request tile kt+3 into that set].  A set is
+    // Order of one iteration: [write B tile kt+1 from its register set] barrier [request tile kt+3 into that set].  A set is
     // requested right after the barrier that frees it and consumed two barriers later (~1.5 k-tiles of flight), and the only
-    // vmcnt wait in the loop is the counted one in front of the stores (the younger set's 14 loads stay in flight).  Nothing
-    // is conditional around a load (a branch there makes hipcc's counted vmcnt collapse to vmcnt(0)): past the last tile the
+    // vmcnt wait in the loop is the counted one in front of the stores (the younger set's loads stay in flight).  Nothing is
+    // conditional around a load (a branch there makes hipcc's counted vmcnt collapse to vmcnt(0)): past the last tile the
     // loads re-read it and the stores fill a stage nobody reads again.
     load_b(0, bset[0]);
-    load_a(0, aset[0]);
     load_b(1, bset[1]);
-    load_a(1, aset[1]);
     __builtin_amdgcn_sched_barrier(0);
     store_b(0, bset[0]);
-    store_a(0, aset[0]);
     __builtin_amdgcn_sched_barrier(0);
     load_b(2, bset[0]);
-    load_a(2, aset[0]);
-    __syncthreads();  // prologue barrier: stage 0 holds tile 0
+    __syncthreads();  // prologue barrier: B stage 0 holds tile 0
     for (int kt = 0; kt < KT; kt += 2) {
       store_b(1, bset[1]);
-      store_a(1, aset[1]);
       __syncthreads();  // barrier #kt
       load_b(kt + 3, bset[1]);
-      load_a(kt + 3, aset[1]);
       __builtin_amdgcn_sched_barrier(0);
       store_b(0, bset[0]);  // (KT is even -- gemm3_ok -- so the two halves need no branch between them)
-      store_a(0, aset[0]);
       __syncthreads();  // barrier #kt+1
       load_b(kt + 4, bset[0]);
-      load_a(kt + 4, aset[0]);
       __builtin_amdgcn_sched_barrier(0);
     }
+    __syncthreads();  // matches the matrix waves' barrier in front of their epilogue
     return;
   }
 
@@ -195,8 +179,8 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const GemmParams p) {
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
   half8_t fa0[4], fb0[2], fa1[4], fb1[2];
-  auto read_frags = [&](int stage, int ks, half8_t (&fa)[4], half8_t (&fb)[2]) {
-    const half_t *Ab = As + stage * kATile, *Bb = Bs + stage * kBTile;
+  auto read_frags = [&](int sa, int sb, int ks, half8_t (&fa)[4], half8_t (&fb)[2]) {
+    const half_t *Ab = As + sa * kATile, *Bb = Bs + sb * kBTile;
 #pragma unroll
     for (int b = 0; b < 2; ++b) fb[b] = *(const half8_t *)(Bb + tile_off(wn * 64 + b * 32 + fr, ks * 2 + fs));
 #pragma unroll
@@ -208,35 +192,67 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const GemmParams p) {
 #pragma unroll
       for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[a], fb[b], acc[a][b], 0, 0, 0);
   };
+  // ---- activation tile by LDS-DMA: this wave owns rows wave*64 .. +63 of the 256-row tile = 8 pieces of 8 rows x 128 B.
+  // Piece q: lane l -> LDS row r = wave*64 + 8q + l/8, physical slot l%8, which holds logical 16-byte chunk (l%8) ^ ((r>>1)&7).
+  // Per-lane byte offsets into x are loop constants; the k-tile advance (128 B) is the scalar offset.
+  const auto rs_x = __builtin_amdgcn_make_buffer_rsrc((void *)p.x, 0, (int)min((size_t)p.M * p.K * 2, (size_t)0x7fffffff), 0x00020000);
+  int voff_x[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int r = wave * 64 + 8 * q + (lane >> 3);
+    const int grow = min(m0 + r, p.M - 1);  // rows past M re-read the last row; their outputs are never stored
+    voff_x[q] = grow * p.K * 2 + (((lane & 7) ^ ((r >> 1) & 7)) << 4);
+  }
+  auto dma_a = [&](int kt, int slot) {
+    const int so = min(kt, KT - 1) * (BK * 2);
+    lds_void_t *dst = (lds_void_t *)(As + slot * kATile + (wave * 64) * BK);
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_t *)((half_t *)dst + q * 8 * BK), 16, voff_x[q], so, 0, 0);
+  };
 
-  __builtin_amdgcn_s_setprio(2);  // the matrix wave outranks its SIMD's staging wave for issue slots
-  __syncthreads();                // prologue barrier
-  read_frags(0, 0, fa0, fb0);
+  __builtin_amdgcn_s_setprio(2);  // the matrix wave outranks its SIMD's dequant wave for issue slots
+  dma_a(0, 0);
+  dma_a(1, 1);
+  dma_a(2, 2);
+  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // tile 0's pieces have landed (tiles 1, 2 still in flight)
+  __builtin_amdgcn_s_barrier();                       // prologue barrier (the dequant waves' __syncthreads)
+  read_frags(0, 0, 0, fa0, fb0);
   // The issue order is pinned (sched_barrier): left alone, hipcc sinks every fragment read to just above its first use
   // (fewest live registers) and the lone matrix wave of the SIMD then sits out each LDS round trip with an idle matrix pipe.
 #define G3_SB() __builtin_amdgcn_sched_barrier(0)
+  int sa = 0;  // A ring slot of tile kt (kt % 3)
   for (int kt = 0; kt < KT; ++kt) {
-    const int st = kt & 1;
-    read_frags(st, 1, fa1, fb1);
+    const int sb = kt & 1;
+    const int sa1 = (sa == 2) ? 0 : sa + 1;
+    read_frags(sa, sb, 1, fa1, fb1);
     G3_SB();
     mfma_all(fa0, fb0);  // sub-step 0
     G3_SB();
-    read_frags(st, 2, fa0, fb0);
+    read_frags(sa, sb, 2, fa0, fb0);
     G3_SB();
     mfma_all(fa1, fb1);  // sub-step 1
     G3_SB();
-    read_frags(st, 3, fa1, fb1);
+    read_frags(sa, sb, 3, fa1, fb1);
     G3_SB();
     mfma_all(fa0, fb0);  // sub-step 2
     G3_SB();
-    __syncthreads();     // barrier #kt: stage st^1 complete, stage st free (its last fragments are in registers)
-    read_frags(st ^ 1, 0, fa0, fb0);  // past the last tile: a stage nobody uses
+    // barrier #kt: my fragment reads of tile kt are complete (lgkmcnt(0)) and my DMA pieces of tile kt+1 have landed
+    // (vmcnt(8): only tile kt+2's are still in flight).  After it: B stage sb and A slot sa are free, tile kt+1 is complete.
+    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    G3_SB();
+    dma_a(kt + 3, sa);  // tile kt+3 takes the slot tile kt just left
+    read_frags(sa1, sb ^ 1, 0, fa0, fb0);  // past the last tile: stages nobody uses
     G3_SB();
     mfma_all(fa1, fb1);  // sub-step 3
     G3_SB();
+    sa = sa1;
   }
 #undef G3_SB
   __builtin_amdgcn_s_setprio(0);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // stray DMA pieces past the last tile: land before the LDS is reused
+  __builtin_amdgcn_s_barrier();                                // (matched by the dequant waves' final barrier)
 
   // ---- epilogue: + bias, round once, transpose through wave-private LDS, 16-byte row-contiguous stores ---------------------
   // C/D layout of 32x32 tiles: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).  (All fragment reads that
@@ -253,10 +269,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const GemmParams p) {
       for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * fs;
         const float v = acc[a][b][r] + bv[b];
-        if constexpr (BF16)
-          ((uint16_t *)ep)[row * 72 + b * 32 + fr] = f32_to_bf16(v);
-        else
-          ep[row * 72 + b * 32 + fr] = (half_t)v;
+        ep[row * 72 + b * 32 + fr] = (half_t)v;
       }
     // 32 rows x 128 B = 256 chunks of 16 B: 4 per lane (wave-private region: no barrier, the wave's own LDS ops are ordered)
 #pragma unroll
@@ -274,17 +287,20 @@ bool gemm3_ok(const GemmParams &p, int layout) {
   static const int on = getenv("QLLM_GEMM3") ? atoi(getenv("QLLM_GEMM3")) : 1;
   static const int min_m = getenv("QLLM_GEMM3_MIN_M") ? atoi(getenv("QLLM_GEMM3_MIN_M")) : 1024;
   if (!on || p.g_idx || p.K % 128 != 0 || p.N % 128 != 0 || p.M < min_m) return false;  // K % 128: an even number of k-tiles
+  // fp16 activations only: the activation tile goes to LDS by DMA, which cannot convert bf16 on the way (gemm2 does);
+  // 32-bit byte offsets into x and the packed weights
+  if (p.act_bf16 || (size_t)p.M * p.K * 2 >= 0x7fffffffull || (size_t)p.K * p.N / 2 >= 0x7fffffffull) return false;
   return p.group_size % 32 == 0 && p.gs_shift >= 5;
 }
 
-template <int LAYOUT, bool BF16>
+template <int LAYOUT>
 static int launch_gemm3_b(const GemmParams &p, hipStream_t stream) {
   using namespace g3;
   static DeviceLatch attr_done;
-  if (int rc = lds_optin(attr_done, (const void *)gemm3_kernel<LAYOUT, BF16>)) return rc;
+  if (int rc = lds_optin(attr_done, (const void *)gemm3_kernel<LAYOUT>)) return rc;
   const int tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
-  const size_t lds = (size_t)2 * (kATile + kBTile) * sizeof(half_t);  // 96 KB
-  hipLaunchKernelGGL((gemm3_kernel<LAYOUT, BF16>), dim3(tiles), dim3(512), lds, stream, p);
+  const size_t lds = (size_t)(3 * kATile + 2 * kBTile) * sizeof(half_t);  // 128 KB
+  hipLaunchKernelGGL((gemm3_kernel<LAYOUT>), dim3(tiles), dim3(512), lds, stream, p);
   QLLM_HIP_CHECK(hipGetLastError());
   return QLLM_OK;
 }
@@ -293,8 +309,7 @@ int launch_gemm3(const GemmParams &p_in, int layout, hipStream_t stream) {
   GemmParams p = p_in;
   static int raster = getenv("QLLM_GEMM2_RASTER") ? atoi(getenv("QLLM_GEMM2_RASTER")) : 1;
   p.raster = raster;
-  if (layout == QLLM_LAYOUT_AWQ_GEMM) return p.act_bf16 ? launch_gemm3_b<1, true>(p, stream) : launch_gemm3_b<1, false>(p, stream);
-  return p.act_bf16 ? launch_gemm3_b<0, true>(p, stream) : launch_gemm3_b<0, false>(p, stream);
+  return layout == QLLM_LAYOUT_AWQ_GEMM ? launch_gemm3_b<1>(p, stream) : launch_gemm3_b<0>(p, stream);
 }
 
 }  // namespace qllm

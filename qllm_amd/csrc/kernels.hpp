@@ -80,6 +80,7 @@ struct StripParams {
   int act_bf16;
   int chain;        // chained decode link (strip.hip, CH): bit 0 = x is a 0xFFFF-armed buffer (poll), bit 1 = publish y
   uint32_t *err;    // chained links: device word, bit 0 raised when a poll loop gives up
+  uint64_t *dbg;    // chained links, diagnostics (qllm_debug_timeline): 8 timestamps for this launch, or NULL
 };
 bool strip_group_ok(int group_size);
 int strip_nw(int K, int strips_total);

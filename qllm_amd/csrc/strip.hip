@@ -100,6 +100,13 @@ __global__ __launch_bounds__(NW * 64, CH ? (NW == 8 ? 4 : 8) : ((NW == 8 && CPL 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, i = lane & 15;
+  // diagnostics (CH only, p.dbg != NULL): 100 MHz timestamps of the first and the last block's wave 0 --
+  // [entry, weight loads issued, x complete, exit] -- written by lane 0; qllm_debug_timeline() hands out the slots
+  uint64_t *dbg_slot = nullptr;
+  if constexpr (CH) {
+    if (p.dbg && wave == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1)) dbg_slot = p.dbg + (blockIdx.x == 0 ? 0 : 4);
+    if (dbg_slot && lane == 0) dbg_slot[0] = __builtin_amdgcn_s_memrealtime();
+  }
 
   int pi = 0;
 #pragma unroll
@@ -341,7 +348,12 @@ __global__ __launch_bounds__(NW * 64, CH ? (NW == 8 ? 4 : 8) : ((NW == 8 && CPL 
     // ---- 4. first round: activations -> LDS (needs only the OLDEST loads; the weights stay in flight).  For many rows
     //         (XL > 2) the chunk was staged before the weight loads instead, to keep its registers out of this region.
     if constexpr (CH) {
-      if (r == 0) { chain_load_x(); stage_x(); }
+      if (r == 0) {
+        if (dbg_slot && lane == 0) dbg_slot[1] = __builtin_amdgcn_s_memrealtime();
+        chain_load_x();
+        if (dbg_slot && lane == 0) dbg_slot[2] = __builtin_amdgcn_s_memrealtime();
+        stage_x();
+      }
     }
     if (!RA && !CH && XL <= 2 && r == 0) stage_x();
 
@@ -481,6 +493,7 @@ __global__ __launch_bounds__(NW * 64, CH ? (NW == 8 ? 4 : 8) : ((NW == 8 && CPL 
         }
         __hip_atomic_store((uint32_t *)((uint16_t *)pr.y + (size_t)row * N + nn), h0 | (h1 << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
+      if (dbg_slot && lane == 0) dbg_slot[3] = __builtin_amdgcn_s_memrealtime();
       return;
     }
   }
