@@ -8,8 +8,8 @@
 //     registers).  Instruction stream: ds_read_b128 + MFMA (6 fragment reads per 8 MFMAs; fragments double-buffered one k16
 //     sub-step ahead; the k-tile barrier sits in front of the LAST sub-step's MFMAs so the next tile's first fragment reads
 //     are covered too) plus the ACTIVATION tile, which needs no arithmetic: 8 LDS-DMA pieces per wave and k-tile
-//     (buffer_load_dwordx4 ... lds: 1 KB = 8 rows x 128 B each, no registers, no ds_write), requested THREE k-tiles ahead
-//     into a 3-deep ring and retired with a counted vmcnt(8) in front of the barrier.  These waves issue no other vector
+//     (buffer_load_dwordx4 ... lds: 1 KB = 8 rows x 128 B each, no registers, no ds_write), one behind every four MFMAs,
+//     requested two k-tiles ahead into a 3-deep ring and retired with a counted vmcnt(8) in front of the barrier.  These waves issue no other vector
 //     memory operation, so the hand-placed vmcnt counts exactly the DMA pieces.
 //   * waves 4-7, "dequant": packed weight words + raw scale/zero words through buffer loads (per-lane offsets fixed, the
 //     k-tile advance is a scalar offset: no address VALU), two register sets requested ~1.5 k-tiles ahead, the bit-exact
@@ -186,12 +186,6 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const GemmParams p) {
 #pragma unroll
     for (int a = 0; a < 4; ++a) fa[a] = *(const half8_t *)(Ab + tile_off(wm * 128 + a * 32 + fr, ks * 2 + fs));
   };
-  auto mfma_all = [&](const half8_t (&fa)[4], const half8_t (&fb)[2]) {
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[a], fb[b], acc[a][b], 0, 0, 0);
-  };
   // ---- activation tile by LDS-DMA: this wave owns rows wave*64 .. +63 of the 256-row tile = 8 pieces of 8 rows x 128 B.
   // Piece q: lane l -> LDS row r = wave*64 + 8q + l/8, physical slot l%8, which holds logical 16-byte chunk (l%8) ^ ((r>>1)&7).
   // Per-lane byte offsets into x are loop constants; the k-tile advance (128 B) is the scalar offset.
@@ -203,49 +197,60 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const GemmParams p) {
     const int grow = min(m0 + r, p.M - 1);  // rows past M re-read the last row; their outputs are never stored
     voff_x[q] = grow * p.K * 2 + (((lane & 7) ^ ((r >> 1) & 7)) << 4);
   }
-  auto dma_a = [&](int kt, int slot) {
+  // one DMA piece (8 rows x 128 B of this wave's 64 rows) of k-tile kt into ring slot `slot`
+  auto dma_piece = [&](int kt, int slot, int q) {
     const int so = min(kt, KT - 1) * (BK * 2);
-    lds_void_t *dst = (lds_void_t *)(As + slot * kATile + (wave * 64) * BK);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_t *)(As + slot * kATile + (wave * 64 + q * 8) * BK), 16, voff_x[q], so, 0, 0);
+  };
+  auto mfma_half = [&](const half8_t (&fa)[4], const half8_t (&fb)[2], int a0) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_t *)((half_t *)dst + q * 8 * BK), 16, voff_x[q], so, 0, 0);
+    for (int a = a0; a < a0 + 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[a], fb[b], acc[a][b], 0, 0, 0);
   };
 
   __builtin_amdgcn_s_setprio(2);  // the matrix wave outranks its SIMD's dequant wave for issue slots
-  dma_a(0, 0);
-  dma_a(1, 1);
-  dma_a(2, 2);
-  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // tile 0's pieces have landed (tiles 1, 2 still in flight)
-  __builtin_amdgcn_s_barrier();                       // prologue barrier (the dequant waves' __syncthreads)
+#pragma unroll
+  for (int q = 0; q < 8; ++q) dma_piece(0, 0, q);
+#pragma unroll
+  for (int q = 0; q < 8; ++q) dma_piece(1, 1, q);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // tile 0's pieces have landed (tile 1's still in flight)
+  __builtin_amdgcn_s_barrier();                      // prologue barrier (the dequant waves' __syncthreads)
+  dma_piece(2, 2, 0);
+  dma_piece(2, 2, 1);
   read_frags(0, 0, 0, fa0, fb0);
   // The issue order is pinned (sched_barrier): left alone, hipcc sinks every fragment read to just above its first use
   // (fewest live registers) and the lone matrix wave of the SIMD then sits out each LDS round trip with an idle matrix pipe.
+  // A DMA piece costs 60-180 issue cycles (MI355X_MICROARCH.md): one goes behind every four MFMAs (128 cycles of matrix-pipe
+  // work), never eight in a row (first version: all eight right after the barrier -- the pipe ran dry behind them).
+  // Between barrier #kt-1 and barrier #kt the wave requests the 8 pieces of tile kt+2 (slot (kt+2)%3, freed by barrier
+  // #kt-1): pieces 0,1 beside sub-step 3 of tile kt-1, pieces 2..7 beside sub-steps 0..2 of tile kt.  At barrier #kt the
+  // pieces of tile kt+1 are older than those 8: vmcnt(8) retires exactly them.
 #define G3_SB() __builtin_amdgcn_sched_barrier(0)
   int sa = 0;  // A ring slot of tile kt (kt % 3)
   for (int kt = 0; kt < KT; ++kt) {
     const int sb = kt & 1;
-    const int sa1 = (sa == 2) ? 0 : sa + 1;
+    const int sa1 = (sa == 2) ? 0 : sa + 1, sa2 = (sa == 0) ? 2 : sa - 1;  // slots of tiles kt+1, kt+2
     read_frags(sa, sb, 1, fa1, fb1);
     G3_SB();
-    mfma_all(fa0, fb0);  // sub-step 0
+    mfma_half(fa0, fb0, 0); G3_SB(); dma_piece(kt + 2, sa2, 2); G3_SB(); mfma_half(fa0, fb0, 2); G3_SB(); dma_piece(kt + 2, sa2, 3);  // sub-step 0
     G3_SB();
     read_frags(sa, sb, 2, fa0, fb0);
     G3_SB();
-    mfma_all(fa1, fb1);  // sub-step 1
+    mfma_half(fa1, fb1, 0); G3_SB(); dma_piece(kt + 2, sa2, 4); G3_SB(); mfma_half(fa1, fb1, 2); G3_SB(); dma_piece(kt + 2, sa2, 5);  // sub-step 1
     G3_SB();
     read_frags(sa, sb, 3, fa1, fb1);
     G3_SB();
-    mfma_all(fa0, fb0);  // sub-step 2
+    mfma_half(fa0, fb0, 0); G3_SB(); dma_piece(kt + 2, sa2, 6); G3_SB(); mfma_half(fa0, fb0, 2); G3_SB(); dma_piece(kt + 2, sa2, 7);  // sub-step 2
     G3_SB();
     // barrier #kt: my fragment reads of tile kt are complete (lgkmcnt(0)) and my DMA pieces of tile kt+1 have landed
     // (vmcnt(8): only tile kt+2's are still in flight).  After it: B stage sb and A slot sa are free, tile kt+1 is complete.
     asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     G3_SB();
-    dma_a(kt + 3, sa);  // tile kt+3 takes the slot tile kt just left
     read_frags(sa1, sb ^ 1, 0, fa0, fb0);  // past the last tile: stages nobody uses
     G3_SB();
-    mfma_all(fa1, fb1);  // sub-step 3
+    mfma_half(fa1, fb1, 0); G3_SB(); dma_piece(kt + 3, sa, 0); G3_SB(); mfma_half(fa1, fb1, 2); G3_SB(); dma_piece(kt + 3, sa, 1);  // sub-step 3
     G3_SB();
     sa = sa1;
   }

@@ -474,8 +474,8 @@ def test_wave_specialised_prefill_kernel_vs_oracle(layout, g, K, N, zk, bias):
     layer = to_layer(d, DEV)
     ref = Ref(d)
     big = K * N >= 4096 * 4096
-    for m in ((1024, 2048, 2049) if big else (1024, 1100, 1537)):   # whole tiles, and rows that end inside a 256-row tile
-        if m >= 2048 or not big:
+    for m in ((1024, 2048, 2049) if big else (8192, 8300, 6657)):   # whole tiles, and rows that end inside a 256-row tile
+        if m >= 2048:  # (fewer rows: too few tiles for the CUs -> gemm2's split-K form)
             assert ops.plan_describe([layer._descriptor(None, 0)], m).startswith("gemm3"), (layout, K, N, m)
         x = randx(m, K, seed=m)
         y = layer(torch.from_numpy(x).to(DEV)).cpu().numpy()
@@ -485,10 +485,11 @@ def test_wave_specialised_prefill_kernel_vs_oracle(layout, g, K, N, zk, bias):
     if big:
         return
     # bf16 activations at the same size take gemm2 (the DMA path cannot convert on the way): still exact to tolerance
-    xb = torch.from_numpy(randx(1024, K, seed=3)).to(torch.bfloat16)
+    xb = torch.from_numpy(randx(4096, K, seed=3)).to(torch.bfloat16)
     yb = layer(xb.to(DEV))
     assert yb.dtype == torch.bfloat16
     assert O.rel_err(yb.float().cpu().numpy(), ref.y64(xb.to(torch.float16).numpy())) <= TOL
     # determinism: same launch twice -> same bits
-    x = torch.from_numpy(randx(1024, K, seed=9)).to(DEV)
+    x = torch.from_numpy(randx(4096, K, seed=9)).to(DEV)
+    assert ops.plan_describe([layer._descriptor(None, 0)], 4096).startswith("gemm3")
     assert torch.equal(layer(x), layer(x))
