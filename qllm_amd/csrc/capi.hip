@@ -206,6 +206,7 @@ static int run_strip(const qllm_weight_t *w, void *const *y, int n, const void *
   p.add_zero_bias = w[0].add_zero_bias;
   p.act_bf16 = (act_dtype == QLLM_BF16);
   p.chain = chain;
+  p.lw = strip_lw(pl.nw, pl.spw, pl.cpl, w[0].group_size, chain != 0) ? 1 : 0;
   p.err = err;
   p.dbg = (chain && g_timeline && g_timeline_next < g_timeline_slots) ? g_timeline + 8 * (g_timeline_next++) : nullptr;
   int block = 0;
@@ -415,8 +416,9 @@ int qllm_chain_plan_describe(const qllm_weight_t *w, int32_t n_weights, int32_t 
   if (ok && strip_plan(w, n_weights, M, &pl, 1)) {
     int cols = 0;
     for (int i = 0; i < n_weights; ++i) cols += w[i].N;
-    snprintf(buf, buflen, "chained strip nw=%d cpl=%d spw=%d round=%d blocks=%d", pl.nw, pl.cpl, pl.spw,
-             strip_maxs(pl.nw, pl.spw, pl.cpl, 0, 1), cols / (16 * pl.cpl));
+    snprintf(buf, buflen, "chained strip nw=%d cpl=%d spw=%d round=%d%s blocks=%d", pl.nw, pl.cpl, pl.spw,
+             strip_maxs(pl.nw, pl.spw, pl.cpl, 0, 1), strip_lw(pl.nw, pl.spw, pl.cpl, w[0].group_size, 1) ? "+lds" : "",
+             cols / (16 * pl.cpl));
   } else {
     snprintf(buf, buflen, "not chainable");
   }

@@ -78,6 +78,7 @@ struct StripParams {
   int group_size;
   int add_zero_bias;
   int act_bf16;
+  int lw;           // chained link: second round's weights parked in LDS by DMA (strip_lw)
   int chain;        // chained decode link (strip.hip, CH): bit 0 = x is a 0xFFFF-armed buffer (poll), bit 1 = publish y
   uint32_t *err;    // chained links: device word, bit 0 raised when a poll loop gives up
   uint64_t *dbg;    // chained links, diagnostics (qllm_debug_timeline): 8 timestamps for this launch, or NULL
@@ -87,6 +88,7 @@ int strip_nw(int K, int strips_total);
 int strip_spw(int K, int group_size, int nw);
 // `chain`: 0 = ordinary launch, 1 = chained link
 int strip_maxs(int nw, int spw, int cpl, int ra, int chain);
+bool strip_lw(int nw, int spw, int cpl, int group_size, int chain);
 size_t strip_lds_bytes(int M, int spw, int nw, int cpl, int group_size, int ra, int chain);
 int strip_cpl(int cols_total, bool all_mult64, bool all_mult32);
 bool strip_x_ok(int M, int spw, int nw, int cpl, int chain);

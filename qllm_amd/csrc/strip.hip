@@ -18,6 +18,8 @@
 //   * up to 8 layers sharing x run as one launch (q/k/v, gate/up).
 //
 // Replaces gemv<half> (/root/reference/csrc/ort_cuda/dq_gemv.cu:41-150).
+#include <stdlib.h>
+
 #include "kernels.hpp"
 
 namespace qllm {
@@ -80,12 +82,17 @@ constexpr uint32_t kChainSpinLimit = 8192;  // polls of ~1 us each before a chai
 //       bit 1: publish y that way.  A block is at most half a CU (16 waves x <= 64 registers or 8 waves x <= 128) and the host
 //       keeps the grid <= 448, so two adjacent links are always co-resident and a polling link can never keep its producer's
 //       blocks off the chip; every poll loop is bounded (gives up after ~10 ms and raises bit 0 of *p.err).
-template <int NW, int CPL, int MAXS, int SPG, int XL, int BITS, bool RA = false, bool RA_BF16 = false, int MT = 1, bool CH = false>
+// LW (CH only, exactly two rounds): the SECOND round's weights are requested up front as well -- by LDS-DMA into a wave-private
+//       LDS area (no registers; 64 KB per 64-column block), its scale/zero words into registers -- so that ALL of the link's
+//       weight bytes are in flight before the activations arrive; round 1 then reads its packed words back with ds_read.
+//       (Measured before this existed: a two-round link spent 5-8 us after its input was complete, a one-round link 2.3.)
+template <int NW, int CPL, int MAXS, int SPG, int XL, int BITS, bool RA = false, bool RA_BF16 = false, int MT = 1, bool CH = false, bool LW = false>
 // (second launch-bound = minimum waves per SIMD: the 8-wave 64-column slab variant sits right at the 128-register edge
 //  that lets two blocks share a CU -- 130 registers halve its occupancy: gate/up 13.7 -> 15.0 us)
 __global__ __launch_bounds__(NW * 64, CH ? (NW == 8 ? 4 : 8) : ((NW == 8 && CPL == 4 && SPG == 4 && !RA) ? 4 : 1)) void strip_kernel(const StripParams p) {
   static_assert(BITS == 4 || (BITS == 3 && CPL == 1), "3-bit strips are 16 columns wide");
   static_assert(!CH || (!RA && XL <= 4 && BITS == 4 && MT == 1), "chained links: lds-slab form, 4 bits, at most 4 activation chunks per lane");
+  static_assert(!LW || (CH && CPL == 4), "LDS-parked second round: chained 64-column strips");
   static_assert(!RA || MAXS == 8, "register-A rounds are 8 k-steps");
   static_assert(MT == 1 || (RA && CPL == 1), "several row tiles: register-A, 16-column strips");
   constexpr int NG = MAXS / SPG;   // groups per round (MAXS is a multiple of SPG; rounds start on a group boundary)
@@ -295,26 +302,47 @@ __global__ __launch_bounds__(NW * 64, CH ? (NW == 8 ? 4 : 8) : ((NW == 8 && CPL 
   const half8_t b_mult = (BITS == 4) ? half8_t{(half_t)1.f, (half_t)1.f, (half_t)16.f, (half_t)16.f, (half_t)1.f, (half_t)1.f, (half_t)16.f, (half_t)16.f}
                                      : half8_t{(half_t)2.f, (half_t)1.f, (half_t)16.f, (half_t)8.f, (half_t)128.f, (half_t)64.f, (half_t)1.f, (half_t)1.f};
 
-  for (int r = 0; r < rounds; ++r) {
+  // LW: round 1's scale / zero words (registers) and the wave's LDS area for its packed words
+  half_t sc1[LW ? MAXS / SPG : 1][CPL];
+  uint32_t zraw1[LW ? MAXS / SPG : 1][2];
+  uint32_t *wlds = (uint32_t *)((half_t *)(red + NW * M * TN) + (size_t)NW * M * xrow) + (size_t)NW * ngw * 16 * 2 + (size_t)wave * (MAXS * 64 * CPL);
+
+  auto round_body = [&](const int r) __attribute__((always_inline)) {
     const int base = t0 + r * MAXS;
     // ---- 2. scale / zero of every group this round touches: RAW loads only (tiny; issued first) ----------------------
     const int G0 = base / SPG;
     half_t sc[NG][CPL];
     uint32_t zraw[NG][2];
+    auto load_meta = [&](int Gfirst, half_t (&scx)[NG][CPL], uint32_t (&zx)[NG][2]) {
 #pragma unroll
-    for (int j = 0; j < NG; ++j) {
-      const int G = min(G0 + j, Gmax);
-      if constexpr (CPL == 4) {
-        const half4_t sv = *(const half4_t *)(pr.scales + (size_t)G * N + n);
-        sc[j][0] = sv.x; sc[j][1] = sv.y; sc[j][2] = sv.z; sc[j][3] = sv.w;
-      } else if constexpr (CPL == 2) {
-        const half2_t sv = *(const half2_t *)(pr.scales + (size_t)G * N + n);
-        sc[j][0] = sv.x; sc[j][1] = sv.y;
-      } else {
-        sc[j][0] = pr.scales[(size_t)G * N + n];
+      for (int j = 0; j < NG; ++j) {
+        const int G = min(Gfirst + j, Gmax);
+        if constexpr (CPL == 4) {
+          const half4_t sv = *(const half4_t *)(pr.scales + (size_t)G * N + n);
+          scx[j][0] = sv.x; scx[j][1] = sv.y; scx[j][2] = sv.z; scx[j][3] = sv.w;
+        } else if constexpr (CPL == 2) {
+          const half2_t sv = *(const half2_t *)(pr.scales + (size_t)G * N + n);
+          scx[j][0] = sv.x; scx[j][1] = sv.y;
+        } else {
+          scx[j][0] = pr.scales[(size_t)G * N + n];
+        }
+        zx[j][0] = zbase[(size_t)G * zmul + zoff];
+        zx[j][1] = (CPL == 4) ? zbase[(size_t)G * zmul + zoff + zoff2] : 0u;
       }
-      zraw[j][0] = zbase[(size_t)G * zmul + zoff];
-      zraw[j][1] = (CPL == 4) ? zbase[(size_t)G * zmul + zoff + zoff2] : 0u;
+    };
+    if constexpr (LW) {
+      if (r == 1) {
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) sc[j][c] = sc1[j][c];
+          zraw[j][0] = zraw1[j][0]; zraw[j][1] = zraw1[j][1];
+        }
+      } else {
+        load_meta(G0, sc, zraw);
+      }
+    } else {
+      load_meta(G0, sc, zraw);
     }
     // ---- 2b. RA: this round's activation fragments, raw (16 B per k-step; L2-resident, so they land before the weights)
     uint4_t xq[RA ? MAXS : 1][MT];
@@ -330,6 +358,12 @@ __global__ __launch_bounds__(NW * 64, CH ? (NW == 8 ? 4 : 8) : ((NW == 8 && CPL 
     uint32_t w_hi[BITS == 3 ? MAXS : 1];
 #pragma unroll
     for (int s = 0; s < MAXS; ++s) {
+      if constexpr (LW) {
+        if (r == 1) {
+          w[s] = *(const wvec_t *)(wlds + (s * 64 + lane) * CPL);  // parked there by this wave's own DMA pieces
+          continue;
+        }
+      }
       if constexpr (BITS == 4) {
         const uint32_t *rowp = pr.qweight + (size_t)(4 * min(base + s, tmax)) * N;
         w[s] = __builtin_nontemporal_load((const wvec_t *)(rowp + lane_off));
@@ -338,6 +372,19 @@ __global__ __launch_bounds__(NW * 64, CH ? (NW == 8 ? 4 : 8) : ((NW == 8 && CPL 
         const uint32_t *rowp = pr.qweight + (size_t)(3 * min(base + s, tmax)) * N;
         w[s][0] = __builtin_nontemporal_load(rowp + lane_off3_lo);
         w_hi[s] = __builtin_nontemporal_load(rowp + lane_off3_hi);
+      }
+    }
+
+    if constexpr (LW) {
+      if (r == 0) {
+        // round 1: packed words by LDS-DMA (16 B per lane and k-step, lane-linear = the order they are read back in),
+        // non-temporal like the register loads; scale / zero words of its groups into registers
+#pragma unroll
+        for (int s = 0; s < MAXS; ++s) {
+          const uint32_t *rowp = pr.qweight + (size_t)(4 * min(base + MAXS + s, tmax)) * N;
+          __builtin_amdgcn_global_load_lds((gbl_cvoid_t *)(rowp + lane_off), (lds_void_t *)(wlds + s * 64 * CPL), 16, 0, 2);
+        }
+        load_meta(G0 + NG, sc1, zraw1);
       }
     }
 
@@ -455,6 +502,13 @@ __global__ __launch_bounds__(NW * 64, CH ? (NW == 8 ? 4 : 8) : ((NW == 8 && CPL 
         }
       }
     }
+    };
+  if constexpr (LW) {
+    round_body(0);
+    __builtin_amdgcn_sched_barrier(0);  // keep round 1's LDS reads below round 0's arithmetic (32 more live registers otherwise)
+    round_body(1);
+  } else {
+    for (int r = 0; r < rounds; ++r) round_body(r);
   }
 
   // ---- 6. reduce the NW waves' partials through LDS: red[wave][row][col] -------------------------------------------
@@ -511,12 +565,12 @@ __global__ __launch_bounds__(NW * 64, CH ? (NW == 8 ? 4 : 8) : ((NW == 8 && CPL 
   }
 }
 
-template <int NW, int CPL, int MAXS, int SPG, int XL, int BITS = 4, bool RA = false, bool RA_BF16 = false, int MT = 1, bool CH = false>
+template <int NW, int CPL, int MAXS, int SPG, int XL, int BITS = 4, bool RA = false, bool RA_BF16 = false, int MT = 1, bool CH = false, bool LW = false>
 static int launch_strip_t(const StripParams &p, int grid, size_t lds, hipStream_t stream) {
   // the >64 KB dynamic-LDS opt-in is a per-DEVICE function attribute: latch it per (kernel instantiation, device)
   static DeviceLatch attr_done;
-  if (int rc = lds_optin(attr_done, (const void *)strip_kernel<NW, CPL, MAXS, SPG, XL, BITS, RA, RA_BF16, MT, CH>)) return rc;
-  hipLaunchKernelGGL((strip_kernel<NW, CPL, MAXS, SPG, XL, BITS, RA, RA_BF16, MT, CH>), dim3(grid), dim3(NW * 64), lds, stream, p);
+  if (int rc = lds_optin(attr_done, (const void *)strip_kernel<NW, CPL, MAXS, SPG, XL, BITS, RA, RA_BF16, MT, CH, LW>)) return rc;
+  hipLaunchKernelGGL((strip_kernel<NW, CPL, MAXS, SPG, XL, BITS, RA, RA_BF16, MT, CH, LW>), dim3(grid), dim3(NW * 64), lds, stream, p);
   QLLM_HIP_CHECK(hipGetLastError());
   return QLLM_OK;
 }
@@ -525,17 +579,16 @@ static int launch_strip_t(const StripParams &p, int grid, size_t lds, hipStream_
 // (64-column strips always use rounds of 8: 4 dwords per load keep the register budget of a 1024-thread block;
 //  register-A launches always use rounds of 8: each k-step also holds 16 B of activations per lane)
 // chained links (chain != 0): 16-wave blocks must fit 64 registers -> one round of 8 (short K only); 8-wave blocks (128
-// registers): the largest round of {24, 16, 8} k-steps that pads the wave's chunk least
+// registers): see below
 int strip_maxs(int nw, int spw, int cpl, int ra, int chain) {
   if (ra || cpl >= 2) return 8;
   if (chain) {
     if (nw == 16) return 8;
-    int best = 8, best_pad = (spw + 7) / 8 * 8;
-    for (int m = 16; m <= 24; m += 8) {
-      const int pad = (spw + m - 1) / m * m;
-      if (pad <= best_pad) { best = m; best_pad = pad; }
-    }
-    return best;
+    // 8-wave, 16-column links: ONE round whenever the wave's chunk fits 48 loads (K <= 12288), so that all of the link's
+    // weights are in flight before its input arrives; longer chunks: rounds of 24
+    for (int m : {8, 16, 24, 32, 48})
+      if (spw <= m) return m;
+    return 24;
   }
   return nw == 8 ? 16 : (spw <= 8 ? 8 : 24);
 }
@@ -567,10 +620,19 @@ static int launch_strip_s(const StripParams &p, int grid, size_t lds, hipStream_
   return x2 ? launch_strip_t<NW_, CPL_, MAXS_, SPG, 2, 4, false, false, 1, true>(p, grid, lds, stream) \
             : launch_strip_t<NW_, CPL_, MAXS_, SPG, 4, 4, false, false, 1, true>(p, grid, lds, stream)
     if (p.cpl == 4) {
-      if constexpr (SPG == 4) { QLLM_CH(8, 4, 8); } else return set_error(QLLM_ERR_UNSUPPORTED, "chained 64-column strips: group size 128 only");
+      if constexpr (SPG == 4) {
+        if (p.lw)  // exactly two rounds: the second one parked in LDS by DMA
+          return x2 ? launch_strip_t<8, 4, 8, SPG, 2, 4, false, false, 1, true, true>(p, grid, lds, stream)
+                    : launch_strip_t<8, 4, 8, SPG, 4, 4, false, false, 1, true, true>(p, grid, lds, stream);
+        QLLM_CH(8, 4, 8);
+      } else {
+        return set_error(QLLM_ERR_UNSUPPORTED, "chained 64-column strips: group size 128 only");
+      }
     }
     if (p.nw == 16) { QLLM_CH(16, 1, 8); }
     const int m = strip_maxs(8, p.spw, 1, 0, 1);
+    if (m == 48) { QLLM_CH(8, 1, 48); }
+    if (m == 32) { QLLM_CH(8, 1, 32); }
     if (m == 24) { QLLM_CH(8, 1, 24); }
     if (m == 16) { QLLM_CH(8, 1, 16); }
     QLLM_CH(8, 1, 8);
@@ -614,8 +676,17 @@ size_t strip_lds_bytes(int M, int spw, int nw, int cpl, int group_size, int ra, 
   if (ra) return red;  // register-A: only the cross-wave reduction buffer
   const int pad = strip_spw_pad(nw, spw, cpl, 0, chain);
   const int groups = pad / (group_size / 32);  // groups per wave chunk
-  return red + (size_t)nw * M * (pad * 32 + 8) * sizeof(half_t) +
-         (size_t)nw * groups * 16 * 8;  // (Sx, Sx') float2 per (group, row), 16 rows per group
+  const size_t base = red + (size_t)nw * M * (pad * 32 + 8) * sizeof(half_t) +
+                      (size_t)nw * groups * 16 * 8;  // (Sx, Sx') float2 per (group, row), 16 rows per group
+  // chained 64-column links with two rounds park the second round's packed words in LDS: 8 k-steps x 64 lanes x 16 B per wave
+  return base + (strip_lw(nw, spw, cpl, group_size, chain) ? (size_t)nw * 8 * 64 * 16 : 0);
+}
+
+// chained link whose second (and last) round is requested up front through LDS-DMA: 8-wave 64-column strips, g128, 9..16 k-steps
+// per wave (K <= 4096)
+bool strip_lw(int nw, int spw, int cpl, int group_size, int chain) {
+  static const int on = getenv("QLLM_CHAIN_LW") ? atoi(getenv("QLLM_CHAIN_LW")) : 1;
+  return on && chain && cpl == 4 && nw == 8 && group_size == 128 && spw > 8 && spw <= 16;
 }
 
 // columns per lane, from measurements on Llama-2-7B shapes (tools/kbench.py --grouped, us per launch, cpl 1/2/4):
