@@ -83,7 +83,9 @@ static bool skinny_ok(const qllm_weight_t &w, int M) {
   return M <= skinny_max_m() && fused_common_ok(w) && w.K % 32 == 0 && w.g_idx == nullptr;
 }
 static int strip_min_strips() {
-  static int v = env_int("QLLM_STRIP_MIN", 192);
+  // measured (profiles/r02_narrow_shapes.md): even 8-80 strips beat the split-K kernel's three dependent round trips
+  // (K=8192, N=1024+128+128: 15.2 -> 9.8 us; K=4096, N=1024: 11.7 -> 4.8 us)
+  static int v = env_int("QLLM_STRIP_MIN", 8);
   return v;
 }
 // full-K strip kernel: row-stream layouts, M <= 64 (17..64: several 16-row tiles per block), enough 16-column strips to
@@ -139,7 +141,7 @@ static bool strip_plan(const qllm_weight_t *w, int n, int M, StripPlan *plan, in
   static int ra_longk = env_int("QLLM_STRIP_RA_LONGK", 1);
   const bool longk = ra_longk && (w[0].group_size == 64 || bits == 3) && strip_spw(w[0].K, w[0].group_size, 16) > 8;
   const int ra_base = (M >= ra_min) ? 1 : 0;
-  int first = (bits == 3 || M > 16) ? 1 : strip_cpl(cols, m64, m32);
+  int first = (bits == 3 || M > 16) ? 1 : strip_cpl(cols, m64, m32 && M <= 4);
   if (M > 16) force_cpl = 1;  // several row tiles per block: 16-column strips, 8-wave blocks, register-A
   if (force_cpl == 4 && m64 && bits == 4) first = 4;
   if (force_cpl == 2 && m32 && bits == 4) first = 2;

@@ -47,9 +47,14 @@ __device__ __forceinline__ int tile_off(int row, int slot) { return row * BK + (
 }  // namespace g3
 
 // LAYOUT 0 = GPTQ/HQQ row stream, 1 = AWQ GEMM.  fp16 activations.  Requires K % 128 == 0 (even number of k-tiles), N % 128 == 0, power-of-two group size >= 32, no g_idx.
-template <int LAYOUT>
-__global__ __launch_bounds__(512) void gemm3_kernel(const GemmParams p) {
+// MW: matrix waves, 4 (one per SIMD, 128x64 each) or 8 (two per SIMD, 64x64 each: 8 fragment reads per 8 MFMAs instead of 6,
+// but the two waves cover each other's LDS / barrier waits); always 4 dequant waves behind them.
+template <int LAYOUT, int MW>
+__global__ __launch_bounds__((MW + 4) * 64) void gemm3_kernel(const GemmParams p) {
   using namespace g3;
+  constexpr int AM = 8 / MW * 2;       // 32-row MFMA tiles per matrix wave along M: 4 or 2
+  constexpr int WROWS = AM * 32;       // rows per matrix wave: 128 or 64
+  constexpr int NP = 32 / MW;          // activation DMA pieces (8 rows x 128 B) per matrix wave and k-tile: 8 or 4
   extern __shared__ __attribute__((aligned(16))) half_t smem[];
   half_t *As = smem;               // [3][256][64]  (LDS-DMA ring)
   half_t *Bs = smem + 3 * kATile;  // [2][128 n][64 k]
@@ -70,9 +75,9 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const GemmParams p) {
   const int m0 = tm * BM, n0 = tn * BN;
   const int KT = p.K / BK;
 
-  if (wave >= 4) {
+  if (wave >= MW) {
     // ================================================= dequant waves ==================================================
-    const int t = tid - 256;  // 0..255
+    const int t = tid - MW * 64;  // 0..255
     // ---- B -------------------------------------------------------------------------------------------------------------
     // GPTQ: thread = column t % 128, word rows 4 (t / 128) .. +3 of the 8 in a k-tile -> 4 x b128 stores
     // AWQ : thread = word column t % 16 (8 columns), k rows 4 (t / 16) .. +3 -> per column one 8-byte store of 4 k
@@ -168,56 +173,63 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const GemmParams p) {
   }
 
   // =================================================== matrix waves ===================================================
-  const int wm = wave >> 1, wn = wave & 1;  // 2 (M) x 2 (N): rows wm*128.., columns wn*64..
+  const int wm = wave >> 1, wn = wave & 1;  // (MW/2) (M) x 2 (N): rows wm*WROWS.., columns wn*64..
   const int fr = lane & 31, fs = lane >> 5;  // fragment row (A: m, B: n) and k half of the 16-wide sub-step
-  float16_t acc[4][2];
+  float16_t acc[AM][2];
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < AM; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  half8_t fa0[4], fb0[2], fa1[4], fb1[2];
-  auto read_frags = [&](int sa, int sb, int ks, half8_t (&fa)[4], half8_t (&fb)[2]) {
+  half8_t fa0[AM], fb0[2], fa1[AM], fb1[2];
+  auto read_frags = [&](int sa, int sb, int ks, half8_t (&fa)[AM], half8_t (&fb)[2]) {
     const half_t *Ab = As + sa * kATile, *Bb = Bs + sb * kBTile;
 #pragma unroll
     for (int b = 0; b < 2; ++b) fb[b] = *(const half8_t *)(Bb + tile_off(wn * 64 + b * 32 + fr, ks * 2 + fs));
 #pragma unroll
-    for (int a = 0; a < 4; ++a) fa[a] = *(const half8_t *)(Ab + tile_off(wm * 128 + a * 32 + fr, ks * 2 + fs));
+    for (int a = 0; a < AM; ++a) fa[a] = *(const half8_t *)(Ab + tile_off(wm * WROWS + a * 32 + fr, ks * 2 + fs));
   };
   // ---- activation tile by LDS-DMA: this wave owns rows wave*64 .. +63 of the 256-row tile = 8 pieces of 8 rows x 128 B.
   // Piece q: lane l -> LDS row r = wave*64 + 8q + l/8, physical slot l%8, which holds logical 16-byte chunk (l%8) ^ ((r>>1)&7).
   // Per-lane byte offsets into x are loop constants; the k-tile advance (128 B) is the scalar offset.
   const auto rs_x = __builtin_amdgcn_make_buffer_rsrc((void *)p.x, 0, (int)min((size_t)p.M * p.K * 2, (size_t)0x7fffffff), 0x00020000);
-  int voff_x[8];
+  int voff_x[NP];
 #pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const int r = wave * 64 + 8 * q + (lane >> 3);
+  for (int q = 0; q < NP; ++q) {
+    const int r = wave * (8 * NP) + 8 * q + (lane >> 3);
     const int grow = min(m0 + r, p.M - 1);  // rows past M re-read the last row; their outputs are never stored
     voff_x[q] = grow * p.K * 2 + (((lane & 7) ^ ((r >> 1) & 7)) << 4);
   }
   // one DMA piece (8 rows x 128 B of this wave's 64 rows) of k-tile kt into ring slot `slot`
+  // (the builtin's operands are first copied into plain locals: called with template-dependent expressions, the HOST pass of
+  //  hipcc silently fails to instantiate the whole kernel -- no diagnostic, just an undefined __device_stub__ at load time)
+  const int rows_per_wave = 8 * NP;
   auto dma_piece = [&](int kt, int slot, int q) {
     const int so = min(kt, KT - 1) * (BK * 2);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_t *)(As + slot * kATile + (wave * 64 + q * 8) * BK), 16, voff_x[q], so, 0, 0);
+    const int vo = voff_x[q];
+    lds_void_t *dst = (lds_void_t *)(As + slot * kATile + (wave * rows_per_wave + q * 8) * BK);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, dst, 16, vo, so, 0, 0);
   };
-  auto mfma_half = [&](const half8_t (&fa)[4], const half8_t (&fb)[2], int a0) {
+  // half of a sub-step's MFMAs: row tiles [h * AM/2, (h+1) * AM/2)
+  auto mfma_half = [&](const half8_t (&fa)[AM], const half8_t (&fb)[2], int h) {
 #pragma unroll
-    for (int a = a0; a < a0 + 2; ++a)
+    for (int a = h * (AM / 2); a < (h + 1) * (AM / 2); ++a)
 #pragma unroll
       for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[a], fb[b], acc[a][b], 0, 0, 0);
   };
 
   __builtin_amdgcn_s_setprio(2);  // the matrix wave outranks its SIMD's dequant wave for issue slots
 #pragma unroll
-  for (int q = 0; q < 8; ++q) dma_piece(0, 0, q);
+  for (int q = 0; q < NP; ++q) dma_piece(0, 0, q);
 #pragma unroll
-  for (int q = 0; q < 8; ++q) dma_piece(1, 1, q);
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // tile 0's pieces have landed (tile 1's still in flight)
+  for (int q = 0; q < NP; ++q) dma_piece(1, 1, q);
+  if constexpr (NP == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // tile 0's pieces have landed (tile 1's still in flight)
+  else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   __builtin_amdgcn_s_barrier();                      // prologue barrier (the dequant waves' __syncthreads)
-  dma_piece(2, 2, 0);
-  dma_piece(2, 2, 1);
+#pragma unroll
+  for (int q = 0; q < NP / 4; ++q) dma_piece(2, 2, q);
   read_frags(0, 0, 0, fa0, fb0);
   // The issue order is pinned (sched_barrier): left alone, hipcc sinks every fragment read to just above its first use
   // (fewest live registers) and the lone matrix wave of the SIMD then sits out each LDS round trip with an idle matrix pipe.
@@ -231,26 +243,41 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const GemmParams p) {
   for (int kt = 0; kt < KT; ++kt) {
     const int sb = kt & 1;
     const int sa1 = (sa == 2) ? 0 : sa + 1, sa2 = (sa == 0) ? 2 : sa - 1;  // slots of tiles kt+1, kt+2
+    // pieces per sub-step: NP / 4 (2 or 1), one behind each half (NP = 8) or behind the second half (NP = 4) of its MFMAs;
+    // piece indices: sub-step 3 of the previous tile took [0, NP/4), sub-steps 0..2 take the rest
     read_frags(sa, sb, 1, fa1, fb1);
     G3_SB();
-    mfma_half(fa0, fb0, 0); G3_SB(); dma_piece(kt + 2, sa2, 2); G3_SB(); mfma_half(fa0, fb0, 2); G3_SB(); dma_piece(kt + 2, sa2, 3);  // sub-step 0
+    mfma_half(fa0, fb0, 0); G3_SB();
+    if constexpr (NP == 8) { dma_piece(kt + 2, sa2, 2); G3_SB(); }
+    mfma_half(fa0, fb0, 1); G3_SB();
+    dma_piece(kt + 2, sa2, NP == 8 ? 3 : 1);  // sub-step 0
     G3_SB();
     read_frags(sa, sb, 2, fa0, fb0);
     G3_SB();
-    mfma_half(fa1, fb1, 0); G3_SB(); dma_piece(kt + 2, sa2, 4); G3_SB(); mfma_half(fa1, fb1, 2); G3_SB(); dma_piece(kt + 2, sa2, 5);  // sub-step 1
+    mfma_half(fa1, fb1, 0); G3_SB();
+    if constexpr (NP == 8) { dma_piece(kt + 2, sa2, 4); G3_SB(); }
+    mfma_half(fa1, fb1, 1); G3_SB();
+    dma_piece(kt + 2, sa2, NP == 8 ? 5 : 2);  // sub-step 1
     G3_SB();
     read_frags(sa, sb, 3, fa1, fb1);
     G3_SB();
-    mfma_half(fa0, fb0, 0); G3_SB(); dma_piece(kt + 2, sa2, 6); G3_SB(); mfma_half(fa0, fb0, 2); G3_SB(); dma_piece(kt + 2, sa2, 7);  // sub-step 2
+    mfma_half(fa0, fb0, 0); G3_SB();
+    if constexpr (NP == 8) { dma_piece(kt + 2, sa2, 6); G3_SB(); }
+    mfma_half(fa0, fb0, 1); G3_SB();
+    dma_piece(kt + 2, sa2, NP == 8 ? 7 : 3);  // sub-step 2
     G3_SB();
     // barrier #kt: my fragment reads of tile kt are complete (lgkmcnt(0)) and my DMA pieces of tile kt+1 have landed
-    // (vmcnt(8): only tile kt+2's are still in flight).  After it: B stage sb and A slot sa are free, tile kt+1 is complete.
-    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    // (vmcnt(NP): only tile kt+2's are still in flight).  After it: B stage sb and A slot sa are free, tile kt+1 is complete.
+    if constexpr (NP == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     G3_SB();
     read_frags(sa1, sb ^ 1, 0, fa0, fb0);  // past the last tile: stages nobody uses
     G3_SB();
-    mfma_half(fa1, fb1, 0); G3_SB(); dma_piece(kt + 3, sa, 0); G3_SB(); mfma_half(fa1, fb1, 2); G3_SB(); dma_piece(kt + 3, sa, 1);  // sub-step 3
+    mfma_half(fa1, fb1, 0); G3_SB();
+    if constexpr (NP == 8) { dma_piece(kt + 3, sa, 0); G3_SB(); }
+    mfma_half(fa1, fb1, 1); G3_SB();
+    dma_piece(kt + 3, sa, NP == 8 ? 1 : 0);  // sub-step 3
     G3_SB();
     sa = sa1;
   }
@@ -267,7 +294,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const GemmParams p) {
 #pragma unroll
   for (int b = 0; b < 2; ++b) bv[b] = p.bias ? (float)p.bias[n0 + wn * 64 + b * 32 + fr] : 0.f;
 #pragma unroll
-  for (int a = 0; a < 4; ++a) {
+  for (int a = 0; a < AM; ++a) {
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -281,7 +308,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const GemmParams p) {
     for (int h = 0; h < 4; ++h) {
       const int c = lane + 64 * h, row = c >> 3, ch = c & 7;
       const uint4_t v = *(const uint4_t *)(ep + row * 72 + ch * 8);
-      const int m = m0 + wm * 128 + a * 32 + row;
+      const int m = m0 + wm * WROWS + a * 32 + row;
       if (m < p.M) *(uint4_t *)((half_t *)p.y + (size_t)m * p.N + n0 + wn * 64 + ch * 8) = v;
     }
   }
@@ -298,14 +325,14 @@ bool gemm3_ok(const GemmParams &p, int layout) {
   return p.group_size % 32 == 0 && p.gs_shift >= 5;
 }
 
-template <int LAYOUT>
+template <int LAYOUT, int MW>
 static int launch_gemm3_b(const GemmParams &p, hipStream_t stream) {
   using namespace g3;
   static DeviceLatch attr_done;
-  if (int rc = lds_optin(attr_done, (const void *)gemm3_kernel<LAYOUT>)) return rc;
+  if (int rc = lds_optin(attr_done, (const void *)gemm3_kernel<LAYOUT, MW>)) return rc;
   const int tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
   const size_t lds = (size_t)(3 * kATile + 2 * kBTile) * sizeof(half_t);  // 128 KB
-  hipLaunchKernelGGL((gemm3_kernel<LAYOUT>), dim3(tiles), dim3(512), lds, stream, p);
+  hipLaunchKernelGGL((gemm3_kernel<LAYOUT, MW>), dim3(tiles), dim3((MW + 4) * 64), lds, stream, p);
   QLLM_HIP_CHECK(hipGetLastError());
   return QLLM_OK;
 }
@@ -314,7 +341,9 @@ int launch_gemm3(const GemmParams &p_in, int layout, hipStream_t stream) {
   GemmParams p = p_in;
   static int raster = getenv("QLLM_GEMM2_RASTER") ? atoi(getenv("QLLM_GEMM2_RASTER")) : 1;
   p.raster = raster;
-  return layout == QLLM_LAYOUT_AWQ_GEMM ? launch_gemm3_b<1>(p, stream) : launch_gemm3_b<0>(p, stream);
+  static int mw = getenv("QLLM_GEMM3_MW") ? atoi(getenv("QLLM_GEMM3_MW")) : 4;
+  if (mw == 8) return layout == QLLM_LAYOUT_AWQ_GEMM ? launch_gemm3_b<1, 8>(p, stream) : launch_gemm3_b<0, 8>(p, stream);
+  return layout == QLLM_LAYOUT_AWQ_GEMM ? launch_gemm3_b<1, 4>(p, stream) : launch_gemm3_b<0, 4>(p, stream);
 }
 
 }  // namespace qllm

@@ -584,11 +584,21 @@ int strip_maxs(int nw, int spw, int cpl, int ra, int chain) {
   if (ra || cpl >= 2) return 8;
   if (chain) {
     if (nw == 16) return 8;
-    // 8-wave, 16-column links: ONE round whenever the wave's chunk fits 48 loads (K <= 12288), so that all of the link's
-    // weights are in flight before its input arrives; longer chunks: rounds of 24
-    for (int m : {8, 16, 24, 32, 48})
-      if (spw <= m) return m;
-    return 24;
+    // 8-wave, 16-column links: the largest round of {24, 16, 8} k-steps that pads the wave's chunk least.  (One round of
+    // 32 / 48 loads -- everything in flight before the input arrives -- was measured SLOWER on 11008 -> 4096: the 48-load
+    // form spills 12-23 registers and takes 4 us to issue; QLLM_CHAIN_ONE_ROUND=1 selects it for experiments.)
+    static const int one_round = getenv("QLLM_CHAIN_ONE_ROUND") ? atoi(getenv("QLLM_CHAIN_ONE_ROUND")) : 0;
+    if (one_round) {
+      for (int m : {8, 16, 24, 32, 48})
+        if (spw <= m) return m;
+      return 24;
+    }
+    int best = 8, best_pad = (spw + 7) / 8 * 8;
+    for (int m = 16; m <= 24; m += 8) {
+      const int pad = (spw + m - 1) / m * m;
+      if (pad <= best_pad) { best = m; best_pad = pad; }
+    }
+    return best;
   }
   return nw == 8 ? 16 : (spw <= 8 ? 8 : 24);
 }
@@ -685,7 +695,9 @@ size_t strip_lds_bytes(int M, int spw, int nw, int cpl, int group_size, int ra, 
 // chained link whose second (and last) round is requested up front through LDS-DMA: 8-wave 64-column strips, g128, 9..16 k-steps
 // per wave (K <= 4096)
 bool strip_lw(int nw, int spw, int cpl, int group_size, int chain) {
-  static const int on = getenv("QLLM_CHAIN_LW") ? atoi(getenv("QLLM_CHAIN_LW")) : 1;
+  // measured (profiles/r02_chain_experiments.md): the DMA form costs 36 spilled registers and 4-6 us to issue; the step got
+  // 40 % slower.  Kept as an experiment knob, off by default.
+  static const int on = getenv("QLLM_CHAIN_LW") ? atoi(getenv("QLLM_CHAIN_LW")) : 0;
   return on && chain && cpl == 4 && nw == 8 && group_size == 128 && spw > 8 && spw <= 16;
 }
 
@@ -693,9 +705,13 @@ bool strip_lw(int nw, int spw, int cpl, int group_size, int chain) {
 //   q/k/v 12288 cols: 11.7 / 10.6 / 8.5    gate/up 22016 cols: 18.7 / 16.1 / 15.6
 //   o 4096 cols: 5.3 / 6.1 / 7.0            down 4096 cols (K=11008): 10.1 / 11.2 / 14.7
 // -> 64-column strips (256-byte row segments) as soon as they alone give >= 160 blocks, else 16-column strips.
+// Llama-2-70B shapes and their 8-way shards (M = 1, us, cpl 1 / 2 / 4; tools/narrow_ab.py, profiles/r02_narrow_shapes.md):
+//   8192 -> 2 x 3584: 18.0 / 10.1 / 11.5    8192 -> 8192: 17.6 / 10.9 / 12.3    3584 -> 8192: 7.5 / 6.5 / 7.4    1024 -> 8192: 7.2 / 5.9 / 5.1
+// -> 32-column strips when they give >= 190 blocks and the 64-column ones do not (M <= 4 only: all_mult32 is passed false above).
 int strip_cpl(int cols_total, bool all_mult64, bool all_mult32) {
-  (void)all_mult32;
-  return (all_mult64 && cols_total / 64 >= 160) ? 4 : 1;
+  if (all_mult64 && cols_total / 64 >= 160) return 4;
+  if (all_mult32 && cols_total / 32 >= 190) return 2;
+  return 1;
 }
 
 // activation staging budget: at most 8 sixteen-byte chunks per lane

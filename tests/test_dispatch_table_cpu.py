@@ -81,9 +81,17 @@ def test_other_layouts_and_widths(lib):
     assert plan(lib, [W(4096, 4096, 128, 8)], 1).startswith("unsupported")
     # raw act-order descriptors (the modules use a row-sorted view instead): in-place gather in the 128x128 kernel
     assert plan(lib, [W(4096, 4096, g_idx=16)], 300) == "gemm tile=128x128 act-order-gather"
-    # narrow layers: too few strips to fill the chip -> split-K kernel
-    assert plan(lib, [W(4096, 1024)], 1).startswith("skinny")
+    # narrow layers: the full-K strips even when they cannot fill the chip (measured 2x faster than split-K's three round trips)
+    assert plan(lib, [W(4096, 1024)], 1).startswith("strip nw=16 cpl=1")
     assert plan(lib, [W(4096, 1024)] * 3, 1).startswith("strip")                    # grouped: 192 strips together
+    assert plan(lib, [W(4096, 64)], 1).startswith("skinny")                         # 4 strips: below the minimum of 8
+    # Llama-2-70B and its 8-way tensor-parallel shards (BASELINE configs[4]): 32-column strips where they alone give ~1 block per CU
+    assert plan(lib, [W(8192, 1024), W(8192, 128), W(8192, 128)], 1).startswith("strip nw=16 cpl=1")   # q/k/v shard: 80 strips
+    assert plan(lib, [W(8192, 3584)] * 2, 1).startswith("strip nw=16 cpl=2")                            # gate/up shard: 224 blocks
+    assert plan(lib, [W(8192, 8192)], 1).startswith("strip nw=16 cpl=2")
+    assert plan(lib, [W(3584, 8192)], 1).startswith("strip nw=16 cpl=2")                                # row-parallel down shard
+    assert plan(lib, [W(8192, 28672)], 1).startswith("strip nw=8 cpl=4")
+    assert plan(lib, [W(8192, 3584)] * 2, 16).startswith("strip nw=16 cpl=1")                           # M > 4: measured forms only
     # group sizes the strip kernel does not serve
     assert plan(lib, [W(4096, 4096, 32)], 1).startswith("skinny")
 

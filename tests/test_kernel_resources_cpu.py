@@ -33,8 +33,8 @@ def _resources(src):
     return res
 
 
-def _strip(nw, cpl, maxs, spg, xl, bits=4, ra=False, bf=False, mt=1, ch=False):
-    return (f"_ZN4qllm12strip_kernelILi{nw}ELi{cpl}ELi{maxs}ELi{spg}ELi{xl}ELi{bits}ELb{int(ra)}ELb{int(bf)}ELi{mt}ELb{int(ch)}EEEvNS_11StripParamsE")
+def _strip(nw, cpl, maxs, spg, xl, bits=4, ra=False, bf=False, mt=1, ch=False, lw=False):
+    return (f"_ZN4qllm12strip_kernelILi{nw}ELi{cpl}ELi{maxs}ELi{spg}ELi{xl}ELi{bits}ELb{int(ra)}ELb{int(bf)}ELi{mt}ELb{int(ch)}ELb{int(lw)}EEEvNS_11StripParamsE")
 
 
 def test_decode_strip_variants_fit_their_register_budget():
@@ -63,7 +63,7 @@ def test_chained_links_are_at_most_half_a_cu():
     16 waves x <= 64 registers or 8 waves x <= 128 -- enforced by __launch_bounds__, checked here on the emitted code; the
     g128 instantiations the Llama-2-7B chain uses must not pay for it with more than a stray spill."""
     res = _resources("strip.hip")
-    chained = {n: v for n, v in res.items() if n.endswith("ELb1EEEvNS_11StripParamsE")}
+    chained = {n: v for n, v in res.items() if re.search(r"ELb1ELb[01]EEEvNS_11StripParamsE$", n)}
     assert len(chained) >= 10
     for n, (vgpr, _spill) in chained.items():
         nw = int(re.search(r"strip_kernelILi(\d+)E", n).group(1))
@@ -71,6 +71,17 @@ def test_chained_links_are_at_most_half_a_cu():
     for name in (_strip(8, 4, 8, 4, 2, ch=True), _strip(16, 1, 8, 4, 2, ch=True), _strip(8, 1, 24, 4, 4, ch=True)):
         assert name in res, name
         assert res[name][1] <= 2, (name, res[name])
+
+
+def test_wave_specialised_prefill_kernel_budget():
+    """gemm3: 4 matrix + 4 dequant waves = 2 waves per SIMD (<= 256 registers); 8 + 4 waves = 3 per SIMD (<= 168)."""
+    res = _resources("gemm3.hip")
+    names = [n for n in res if "gemm3_kernel" in n]
+    assert len(names) == 4
+    for n in names:
+        vgpr, spill = res[n]
+        cap = 256 if "ELi4EEEv" in n else 168
+        assert spill == 0 and vgpr <= cap, (n, vgpr, spill)
 
 
 def test_prefill_kernels_do_not_spill():
