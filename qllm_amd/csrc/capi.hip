@@ -109,8 +109,16 @@ static bool strip_plan(const qllm_weight_t *w, int n, int M, StripPlan *plan, in
   if (chain && (M > chain_max_m() || w[0].bits != 4)) return false;
   // measured (graph replay, us; split-K kernel -> strips with 2 / 4 row tiles): M=32: 4096x4096 28.3 -> 13.4, 4096x11008 54.9 -> 36.3,
   // 11008x4096 50.1 -> 30.3; M=64: 33.8 -> 22.6, 52.5 -> 61.5, 48.1 -> 53.9 -- four row tiles only pay on the small shape
-  static int max_m = env_int("QLLM_STRIP_MAX_M", 32);
-  if (M > max_m || M > 64 || strip_min_strips() <= 0) return false;
+  // M = 33..64 (four row tiles), us per linear, split-K kernel -> strips (profiles/r02_mid_m.md): 4096x4096 26.8/31.4/33.5 ->
+  // 17.6/19.8/22.6 at M = 33/48/64; on the 11008-wide shapes the strips lose at M >= 48 (43.9 -> 55.1, 41.2 -> 49.8): small shape only
+  static int max_m = env_int("QLLM_STRIP_MAX_M", 0);
+  {
+    int cols_all = 0;
+    for (int i = 0; i < n; ++i) cols_all += w[i].N;
+    const int lim = max_m ? max_m : ((w[0].K <= 4096 && cols_all <= 4096) ? 64 : 32);
+    if (M > lim) return false;
+  }
+  if (M > 64 || strip_min_strips() <= 0) return false;
   if (!strip_group_ok(w[0].group_size)) return false;
   const int bits = w[0].bits;
   if (bits != 4 && bits != 3) return false;

@@ -393,8 +393,9 @@ bool gemm2_ok(const GemmParams &p, int layout) {
   static const char *e = getenv("QLLM_GEMM2");
   if (e && e[0] == '0') return false;
   // below 192 rows a 256-row tile wastes > 25 % of its MFMAs -- but with split-K the k-loop length, not the MFMA count, sets
-  // the time at these sizes; QLLM_GEMM2_MIN_M=65 is the first experiment of the next round (untested default stays 192)
-  static const int min_m = getenv("QLLM_GEMM2_MIN_M") ? atoi(getenv("QLLM_GEMM2_MIN_M")) : 192;
+  // the time at these sizes.  Measured (us per linear, 128x128 kernel -> this one; profiles/r02_mid_m.md): M = 96..160 on
+  // 4096x4096 100 -> 27.5, 4096x11008 103 -> 40, 11008x4096 258 -> 41.
+  static const int min_m = getenv("QLLM_GEMM2_MIN_M") ? atoi(getenv("QLLM_GEMM2_MIN_M")) : 65;
   if (p.g_idx || p.K % 64 != 0 || p.N % 128 != 0 || p.M < min_m) return false;
   return p.group_size % 32 == 0 && p.gs_shift >= 0;  // one group per thread per k-tile; power-of-two group size
 }

@@ -49,7 +49,7 @@ __device__ __forceinline__ int tile_off(int row, int slot) { return row * BK + (
 // LAYOUT 0 = GPTQ/HQQ row stream, 1 = AWQ GEMM.  fp16 activations.  Requires K % 128 == 0 (even number of k-tiles), N % 128 == 0, power-of-two group size >= 32, no g_idx.
 // MW: matrix waves, 4 (one per SIMD, 128x64 each) or 8 (two per SIMD, 64x64 each: 8 fragment reads per 8 MFMAs instead of 6,
 // but the two waves cover each other's LDS / barrier waits); always 4 dequant waves behind them.
-template <int LAYOUT, int MW>
+template <int LAYOUT, int MW, bool PRIO = true>
 __global__ __launch_bounds__((MW + 4) * 64) void gemm3_kernel(const GemmParams p) {
   using namespace g3;
   constexpr int AM = 8 / MW * 2;       // 32-row MFMA tiles per matrix wave along M: 4 or 2
@@ -220,7 +220,7 @@ __global__ __launch_bounds__((MW + 4) * 64) void gemm3_kernel(const GemmParams p
       for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[a], fb[b], acc[a][b], 0, 0, 0);
   };
 
-  __builtin_amdgcn_s_setprio(2);  // the matrix wave outranks its SIMD's dequant wave for issue slots
+  if constexpr (PRIO) __builtin_amdgcn_s_setprio(2);  // the matrix wave outranks its SIMD's dequant wave for issue slots
 #pragma unroll
   for (int q = 0; q < NP; ++q) dma_piece(0, 0, q);
 #pragma unroll
@@ -325,14 +325,14 @@ bool gemm3_ok(const GemmParams &p, int layout) {
   return p.group_size % 32 == 0 && p.gs_shift >= 5;
 }
 
-template <int LAYOUT, int MW>
+template <int LAYOUT, int MW, bool PRIO = true>
 static int launch_gemm3_b(const GemmParams &p, hipStream_t stream) {
   using namespace g3;
   static DeviceLatch attr_done;
-  if (int rc = lds_optin(attr_done, (const void *)gemm3_kernel<LAYOUT, MW>)) return rc;
+  if (int rc = lds_optin(attr_done, (const void *)gemm3_kernel<LAYOUT, MW, PRIO>)) return rc;
   const int tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
   const size_t lds = (size_t)(3 * kATile + 2 * kBTile) * sizeof(half_t);  // 128 KB
-  hipLaunchKernelGGL((gemm3_kernel<LAYOUT, MW>), dim3(tiles), dim3((MW + 4) * 64), lds, stream, p);
+  hipLaunchKernelGGL((gemm3_kernel<LAYOUT, MW, PRIO>), dim3(tiles), dim3((MW + 4) * 64), lds, stream, p);
   QLLM_HIP_CHECK(hipGetLastError());
   return QLLM_OK;
 }
@@ -342,6 +342,8 @@ int launch_gemm3(const GemmParams &p_in, int layout, hipStream_t stream) {
   static int raster = getenv("QLLM_GEMM2_RASTER") ? atoi(getenv("QLLM_GEMM2_RASTER")) : 1;
   p.raster = raster;
   static int mw = getenv("QLLM_GEMM3_MW") ? atoi(getenv("QLLM_GEMM3_MW")) : 4;
+  static int prio = getenv("QLLM_GEMM3_PRIO") ? atoi(getenv("QLLM_GEMM3_PRIO")) : 1;
+  if (mw == 4 && !prio) return layout == QLLM_LAYOUT_AWQ_GEMM ? launch_gemm3_b<1, 4, false>(p, stream) : launch_gemm3_b<0, 4, false>(p, stream);
   if (mw == 8) return layout == QLLM_LAYOUT_AWQ_GEMM ? launch_gemm3_b<1, 8>(p, stream) : launch_gemm3_b<0, 8>(p, stream);
   return layout == QLLM_LAYOUT_AWQ_GEMM ? launch_gemm3_b<1, 4>(p, stream) : launch_gemm3_b<0, 4>(p, stream);
 }

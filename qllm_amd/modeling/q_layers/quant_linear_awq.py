@@ -117,6 +117,11 @@ class WQLinear_GEMM(nn.Module, CompressWeight, HipForwardMixin):
             self._shadow_key = key
         return self._shadow[0]
 
+    def _prefill_through_row_stream(self) -> bool:
+        # the shadow exists anyway once the layer has decoded; QLLM_AWQ_PREFILL_SHADOW=0 keeps prefill on the in-place layout
+        return (os.environ.get("QLLM_AWQ_PREFILL_SHADOW", "1") != "0" and os.environ.get("QLLM_AWQ_DECODE_SHADOW", "1") != "0"
+                and self.outfeatures % 16 == 0)
+
     def forward(self, x):
         return self._hip_linear(x, None, 0)
 

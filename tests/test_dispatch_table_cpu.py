@@ -35,7 +35,7 @@ def test_llama7b_decode_routes(lib):
     assert plan(lib, [down], 1) == "strip nw=16 cpl=1 spw=24 form=lds-slab row_tiles=1"          # one round of 24 loads
     assert plan(lib, [attn] * 3, 1) == "strip nw=8 cpl=4 spw=16 form=lds-slab row_tiles=1"      # grouped q/k/v: 64-column strips
     assert plan(lib, [up] * 2, 1) == "strip nw=8 cpl=4 spw=16 form=lds-slab row_tiles=1"        # grouped gate/up
-    # batch 5..16: register-A form; 17..32: two row tiles; 33..64: split-K kernel
+    # batch 5..16: register-A form; 17..32: two row tiles; 33..64: four row tiles on the 4096x4096 shape, split-K kernel elsewhere
     for m in (5, 8, 16):
         assert "form=register-A row_tiles=1" in plan(lib, [attn], m)
         assert "form=register-A row_tiles=1" in plan(lib, [down], m)
@@ -45,7 +45,10 @@ def test_llama7b_decode_routes(lib):
         assert plan(lib, [attn], m) == "strip nw=8 cpl=1 spw=16 form=register-A row_tiles=2"
         assert plan(lib, [attn] * 3, m).endswith("row_tiles=2")
     for m in (33, 64):
-        assert plan(lib, [attn], m).startswith("skinny tile_cols=64")
+        assert plan(lib, [attn], m) == "strip nw=8 cpl=1 spw=16 form=register-A row_tiles=4"   # measured 1.5x over split-K
+        assert plan(lib, [up], m).startswith("skinny tile_cols=64")                           # ... which loses on the wide shapes
+        assert plan(lib, [down], m).startswith("skinny tile_cols=64")
+        assert plan(lib, [attn] * 3, m).startswith("skinny tile_cols=64")
 
 
 def test_llama7b_prefill_routes(lib):
@@ -60,7 +63,8 @@ def test_llama7b_prefill_routes(lib):
     assert plan(lib, [down], 1024) == "gemm2 tile=256x128 split_k=2"
     assert plan(lib, [up], 512) == "gemm2 tile=256x128 split_k=1"         # 172 tiles: a split would need two rounds
     assert plan(lib, [attn], 512, have_ws=0) == "gemm2 tile=256x128 split_k=1"  # no workspace: no split, still fused
-    assert plan(lib, [attn], 128) == "gemm tile=128x128"                  # 64 < M < 192: the older kernel (next round)
+    assert plan(lib, [attn], 128) == "gemm2 tile=256x128 split_k=8"       # 64 < M < 192: k-loop-bound, split-K (2.5-6x the 128x128 kernel)
+    assert plan(lib, [attn], 65) == "gemm2 tile=256x128 split_k=8"
     assert plan(lib, [W(4096, 4000)], 2048) == "gemm tile=128x128"        # ragged N
     assert plan(lib, [W(4096, 4096, layout=AWQ)], 2048) == g3               # AWQ layout read in place
     assert plan(lib, [W(4096, 4096, layout=AWQ)], 512) == "gemm2 tile=256x128 split_k=4"
