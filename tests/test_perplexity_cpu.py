@@ -42,3 +42,21 @@ def test_perplexity_matches_reference_algorithm():
     assert got[-1] > 1.0
     with pytest.raises(ValueError):
         Perplexity(model, tokens=tokens).calculate_perplexity(32, 32)  # no BOS id available
+
+
+def test_perplexity_reproduces_the_reference_class():
+    """tests/golden/perplexity_ref.json was minted by running the REFERENCE's Perplexity.calculate_perplexity
+    (qllm/plugin/perplexity_utils.py:97-201) on this tiny random Llama (tests/golden/make_goldens_ppl.py): same tokens, same
+    model recipe -> same running perplexities."""
+    import json
+    import os
+    import transformers
+    from conftest import GOLDEN_DIR
+    from qllm_amd.plugin.perplexity_utils import Perplexity
+    ref = json.load(open(os.path.join(GOLDEN_DIR, "perplexity_ref.json")))
+    torch.manual_seed(ref["seed"])
+    model = transformers.LlamaForCausalLM(transformers.LlamaConfig(**ref["config"])).eval()
+    tokens = torch.tensor([ref["tokens"]])
+    for case in ref["cases"]:
+        got = Perplexity(model, tokens=tokens, bos_token_id=ref["bos"]).calculate_perplexity(ref["n_ctx"], case["n_batch"])
+        assert np.allclose(got, case["perplexity"], rtol=2e-4), (got, case["perplexity"])
