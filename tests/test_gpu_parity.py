@@ -110,6 +110,7 @@ SKINNY_CASES = [
     ("GEMM", 64, 256, 72, "asym", True),       # ragged N for the AWQ tile
     ("GPTQ", 64, 96, 64, "asym", False),       # K below one wave chunk
     ("HQQ", 64, 11008, 4096, "f16", True),
+    ("HQQ", 64, 4096, 11008, "f16", False),    # BASELINE configs[3]: HQQ g64 (M = 16 is in the loop below)
     ("GPTQ", 32, 1024, 4096, "asym", True),    # strip kernel, several groups per wave chunk
     ("GPTQ", 16, 512, 3072, "asym", False),    # strip kernel, group smaller than one 32-k step
     ("GPTQ", 128, 4096, 3088, "sym", True),    # strips not a multiple of 16 (no XCD pairing remap)
@@ -191,6 +192,8 @@ GEMM_CASES = [
     ("GEMM", 128, 4096, 4096, "asym", False, False),
     ("HQQ", 64, 4096, 4096, "f16", False, False),
     ("GPTQ", 128, 4096, 4096, "asym", True, False),   # act-order (BASELINE configs[2])
+    ("GPTQ", 128, 4096, 11008, "asym", True, False),  # ... on the MLP shapes too
+    ("GPTQ", 128, 11008, 4096, "asym", True, True),
     ("GPTQ", 128, 768, 3072, "sym", False, True),
     ("GPTQ", 32, 512, 200, "asym", True, True),        # ragged N + act-order + bias
     ("GEMM", 64, 256, 72, "asym", False, True),
@@ -237,6 +240,7 @@ def test_act_order_nonuniform_groups_use_inplace_gather():
 
 
 @pytest.mark.parametrize("layout,g,K,N,zk", [("HQQ", 64, 4096, 4096, "f16"), ("HQQ", 128, 11008, 4096, "f16"),
+                                             ("HQQ", 64, 11008, 4096, "f16"), ("HQQ", 64, 4096, 11008, "f16"),
                                              ("GPTQ", 128, 4096, 4096, "sym")])
 def test_three_bit_decode_kernel(layout, g, K, N, zk):
     """3-bit bit-stream weights through the fused strip kernel (BASELINE configs[3]: HQQ mixed 3/4-bit layers)."""
