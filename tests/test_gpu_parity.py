@@ -347,8 +347,8 @@ def test_empty_batch_returns_empty_output():
 def test_c_abi_error_codes_on_device():
     from qllm_amd import _lib, ops
     lib = _lib.load()
-    # a narrow layer (48 column strips) is served by the split-K kernel, which needs the workspace
-    d = synth("GPTQ", 4, 128, 3072, 768, seed=60)
+    # group size 32 is not served by the full-K strips: the split-K kernel takes it, and that needs the workspace
+    d = synth("GPTQ", 4, 32, 3072, 768, seed=60)
     layer = to_layer(d, DEV)
     w = layer._descriptor(None, 0)
     x = torch.from_numpy(randx(1, 3072)).to(DEV)
