@@ -234,15 +234,20 @@ def pmc_traffic(args):
         env = dict(os.environ, TMPDIR="/tmp", QLLM_CHAIN_SERIAL="1")
         cmd = [rocprof, "--kernel-trace", "--pmc", ctr, "-d", d, "-o", "p", "--output-format", "csv", "--",
                sys.executable, os.path.abspath(__file__), "--pmc-child", "--steps", "2", "--warmup", "1", "--no-extra",
-               "--chain", str(args.chain), "--fused", str(args.fused)]
+               "--chain", str(args.chain), "--fused", str(args.fused), "--chain-mode", args.chain_mode]
         try:
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
             f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             tot, n = 0.0, 0
             for r in csv.DictReader(open(f[0])):
-                if "qllm::strip_kernel" in r["Kernel_Name"] and r["Counter_Name"] == ctr:
+                if r["Counter_Name"] != ctr:
+                    continue
+                if "qllm::strip_kernel" in r["Kernel_Name"]:
                     tot += float(r["Counter_Value"])
                     n += 1
+                elif "qllm::engine_kernel" in r["Kernel_Name"]:  # one dispatch = a whole step of the child (8 layers)
+                    tot += float(r["Counter_Value"])
+                    n += 8 * (4 if args.fused else 7)
             per[ctr] = tot / max(n, 1)
         except Exception as e:  # noqa: BLE001
             shutil.rmtree(d, ignore_errors=True)
@@ -262,6 +267,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--chain", type=int, default=int(os.environ.get("QLLM_BENCH_CHAIN", "1")),
                     help="1: the step runs inside ops.DecodeChain (links alternate between two streams)")
+    ap.add_argument("--chain-mode", default=os.environ.get("QLLM_CHAIN_MODE", "engine"), choices=["engine", "streams"],
+                    help="engine: the step's links as one persistent launch (loader wave + LDS ring); streams: one launch per link on two streams")
     ap.add_argument("--fused", type=int, default=int(os.environ.get("QLLM_BENCH_FUSED", "1")),
                     help="1: sibling groups (q/k/v and gate/up as one grouped launch each: 4 launches per layer instead of 7)")
     ap.add_argument("--tp", type=int, default=0, help="Llama-2-70B tensor-parallel leg (BASELINE configs[4]); 1 = shard shapes on one GPU")
@@ -296,7 +303,7 @@ def main():
     fused = bool(args.fused)
     stack = Stack(WQLinear_GEMM, n_layers, dev, seed=1234 + rank, fused=fused)
     h0 = torch.randn(1, HIDDEN, device=dev, dtype=torch.float16)
-    chain = ops.DecodeChain(dev) if args.chain else None
+    chain = ops.DecodeChain(dev, mode=args.chain_mode) if args.chain else None
     graph, out = capture(decode_step_fn(stack, h0, chain))
     torch.cuda.synchronize()
     assert torch.isfinite(out.float()).all(), "synthetic stack diverged"
@@ -353,9 +360,11 @@ def main():
         "config": {"workload": "llama2-7b-awq-w4-g128-decode-b1", "pack_mode": "GEMM", "bits": 4, "group_size": GROUP,
                    "layers": LAYERS, "linears_per_layer": 7, "batch": 1, "launches_per_step": launches,
                    "driven_through": "q_layer modules (sibling groups installed by the loader)", "grouped_qkv_gateup": fused,
-                   "decode_chain": bool(args.chain), "graph": True, "parallelism": f"replicas x{world}",
+                   "decode_chain": (args.chain_mode if args.chain else False), "graph": True, "parallelism": f"replicas x{world}",
                    "device": info["arch"], "compute_units": info["compute_units"]},
-        "roofline": {"bound": "hbm", "kernel": "qllm::strip_kernel (decode matvec; serves every launch of the step)",
+        "roofline": {"bound": "hbm", "kernel": ("qllm::engine_kernel (persistent decode engine: the step's %d links in one launch)" % launches
+                                                 if (args.chain and args.chain_mode == "engine") else
+                                                 "qllm::strip_kernel (decode matvec; serves every launch of the step)"),
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_source,
                      "bytes_per_launch": bpt // launches, "avg_launch_us": round(avg_launch_us, 3)},
@@ -373,11 +382,14 @@ def main():
             ms = time_events(g.replay, 20) / len(ls)
             extra[f"decode_{name}"] = {"us": round(ms * 1e3, 2), "GBps": round(alg_bytes(K, N, 1) / ms / 1e6, 1)}
         # the other launch forms of the same step (all through the modules)
+        other_mode = "streams" if args.chain_mode == "engine" else "engine"
         for tag, fz, ch in (("fused_single_stream", True, None), ("ungrouped_single_stream", False, None),
-                            ("ungrouped_chain", False, chain if chain is not None else ops.DecodeChain(dev)),
-                            ("fused_chain", True, chain if chain is not None else ops.DecodeChain(dev))):
-            if fz == fused and (ch is not None) == bool(args.chain):
+                            ("fused_chain_" + other_mode, True, ops.DecodeChain(dev, mode=other_mode)),
+                            ("fused_chain_" + args.chain_mode, True, chain if chain is not None else ops.DecodeChain(dev, mode=args.chain_mode))):
+            if fz == fused and ch is chain and chain is not None:
                 continue  # the headline form
+            if ch is None and not args.chain and fz == fused:
+                continue
             stack.set_fused(fz)
             gg, _ = capture(decode_step_fn(stack, h0, ch))
             ms = time_events(gg.replay, 20)

@@ -143,6 +143,28 @@ int qllm_linear_forward_chained(const qllm_weight_t *w, void *const *y, int32_t 
 /* Text description of the chained plan ("chained strip nw=.. cpl=.. spw=.. round=.. blocks=..") or "not chainable"; pure host. */
 int qllm_chain_plan_describe(const qllm_weight_t *w, int32_t n_weights, int32_t M, char *buf, size_t buflen);
 
+/* Persistent decode engine (no reference counterpart): a whole chain of batch-1 linears -- every
+ * launch of a decode step -- as ONE launch.  Per CU one resident workgroup: a loader wave streams the packed weights of the
+ * block's share of every link through an LDS ring without ever waiting for an activation; eight consumer waves take each slab
+ * from the ring, wait (in-band 0xFFFF hand-off, as for qllm_linear_forward_chained) only for the activation slice they need,
+ * and publish finished outputs write-through.
+ *   qllm_engine_link_init   host only: validates one layer of the chain and fills its record.  x / y: the layer's input and
+ *                           output (1 row); x_poll != 0: x is the output of an EARLIER link of the same program (its buffer
+ *                           must be 0xFF-filled before the run); strip0: running sum of N/32 over the preceding links (deals
+ *                           the 32-column strips to the workgroups round-robin).  QLLM_ERR_UNSUPPORTED unless M = 1, fp16
+ *                           activations, 4 bits, group size 128, row-stream layout (GPTQ / HQQ), N % 32 == 0, K % 128 == 0.
+ *   qllm_engine_run         launches the program: `links_device` = the records, in chain order, in DEVICE memory.  Links may
+ *                           only read outputs of links before them.  Bounded spins: bit 0 of *err_word = an activation never
+ *                           arrived, bits 1-2 = internal ring hand-off timed out. */
+typedef struct qllm_engine_link {
+  const void *qweight, *scales, *qzeros, *bias, *x;
+  void *y;
+  int32_t N, K, n_strips, strip0, slabs, zero_kind, add_zero_bias, x_poll;
+} qllm_engine_link_t;
+int qllm_engine_link_init(const qllm_weight_t *w, const void *x, void *y, int32_t M, int32_t act_dtype, int32_t x_poll,
+                          int32_t strip0, qllm_engine_link_t *out);
+int qllm_engine_run(const qllm_engine_link_t *links_device, int32_t n_links, void *err_word, void *stream);
+
 /* Diagnostics (process-global, not thread-safe; NULL switches it off): the next chained launches each take one 64-byte slot
  * of `buf` (device memory, n_slots x 8 x u64, in launch order) and record 100 MHz device timestamps of their first and last
  * block: [entry, weight loads issued, input complete, exit] x 2.  A launch captured into a hipGraph keeps its slot. */

@@ -23,7 +23,7 @@ EXPORTS = (
     "qllm_linear_forward", "qllm_linear_forward_grouped", "qllm_dequant", "qllm_ort_gemv", "qllm_ort_dequant",
     "qllm_awq_gemm_forward", "qllm_unpack_qweight", "qllm_pack_qweight", "qllm_ort_dequantize4bits",
     "qllm_plan_describe", "qllm_linear_forward_chained", "qllm_chain_plan_describe",
-    "qllm_debug_timeline",
+    "qllm_debug_timeline", "qllm_engine_link_init", "qllm_engine_run",
 )
 CHAIN_POLL_X, CHAIN_PUBLISH_Y = 1, 2
 
@@ -36,6 +36,14 @@ class QllmWeight(C.Structure):
         ("K", C.c_int32), ("N", C.c_int32), ("group_size", C.c_int32), ("bits", C.c_int32),
         ("layout", C.c_int32), ("add_zero_bias", C.c_int32),
     ]
+
+
+class QllmEngineLink(C.Structure):
+    """struct qllm_engine_link (include/qllm_mi355x.h)."""
+    _fields_ = [("qweight", C.c_void_p), ("scales", C.c_void_p), ("qzeros", C.c_void_p), ("bias", C.c_void_p),
+                ("x", C.c_void_p), ("y", C.c_void_p),
+                ("N", C.c_int32), ("K", C.c_int32), ("n_strips", C.c_int32), ("strip0", C.c_int32), ("slabs", C.c_int32),
+                ("zero_kind", C.c_int32), ("add_zero_bias", C.c_int32), ("x_poll", C.c_int32)]
 
 
 class QllmDeviceInfo(C.Structure):
@@ -94,6 +102,10 @@ def _declare(lib):
     lib.qllm_linear_forward_chained.argtypes = [wp, C.POINTER(vp), i32, vp, i32, i32, i32, vp, vp]
     lib.qllm_chain_plan_describe.restype = C.c_int
     lib.qllm_chain_plan_describe.argtypes = [wp, i32, i32, C.c_char_p, sz]
+    lib.qllm_engine_link_init.restype = C.c_int
+    lib.qllm_engine_link_init.argtypes = [wp, vp, vp, i32, i32, i32, i32, C.POINTER(QllmEngineLink)]
+    lib.qllm_engine_run.restype = C.c_int
+    lib.qllm_engine_run.argtypes = [vp, i32, vp, vp]
     lib.qllm_debug_timeline.restype = C.c_int
     lib.qllm_debug_timeline.argtypes = [vp, i32]
     lib.qllm_ort_dequantize4bits.restype = C.c_int

@@ -403,6 +403,45 @@ int qllm_linear_forward_chained(const qllm_weight_t *w, void *const *y, int32_t 
   return run_strip(w, y, n_weights, x, M, act_dtype, (hipStream_t)stream, chain_flags, (uint32_t *)err_word);
 }
 
+int qllm_engine_link_init(const qllm_weight_t *w, const void *x, void *y, int32_t M, int32_t act_dtype, int32_t x_poll,
+                          int32_t strip0, qllm_engine_link_t *out) {
+  clear_error();
+  if (!out) return set_error(QLLM_ERR_INVALID, "out is NULL");
+  int rc = validate_weight(w);
+  if (rc) return rc;
+  rc = check_io(x, y, M, act_dtype);
+  if (rc) return rc;
+  if ((uintptr_t)y % 4) return set_error(QLLM_ERR_INVALID, "y must be 4-byte aligned");
+  if (!engine_link_ok(*w, M, act_dtype))
+    return set_error(QLLM_ERR_UNSUPPORTED, "decode engine serves M=1, fp16, 4-bit g128 row-stream layers with N%%32==0, K%%128==0");
+  static_assert(sizeof(qllm_engine_link_t) == sizeof(EngineLink), "C struct and device struct must agree");
+  EngineLink e;
+  e.qweight = (const uint32_t *)w->qweight;
+  e.scales = (const half_t *)w->scales;
+  e.qzeros = w->qzeros;
+  e.bias = (const half_t *)w->bias;
+  e.x = (const uint16_t *)x;
+  e.y = (uint16_t *)y;
+  e.N = w->N;
+  e.K = w->K;
+  e.n_strips = w->N / 32;
+  e.strip0 = strip0;
+  e.slabs = (w->K + 1023) / 1024;
+  e.zero_kind = zero_kind_of(*w);
+  e.add_zero_bias = w->add_zero_bias;
+  e.x_poll = x_poll ? 1 : 0;
+  memcpy(out, &e, sizeof(e));
+  return QLLM_OK;
+}
+
+int qllm_engine_run(const qllm_engine_link_t *links_device, int32_t n_links, void *err_word, void *stream) {
+  clear_error();
+  if (!links_device || n_links < 1) return set_error(QLLM_ERR_INVALID, "links_device must hold >= 1 link");
+  if (!err_word || (uintptr_t)err_word % 4) return set_error(QLLM_ERR_INVALID, "err_word must be a 4-byte aligned device word");
+  static int grid = env_int("QLLM_ENGINE_GRID", kNumCU);
+  return launch_engine((const EngineLink *)links_device, n_links, (uint32_t *)err_word, grid, (hipStream_t)stream);
+}
+
 int qllm_debug_timeline(void *buf, int32_t n_slots) {
   clear_error();
   g_timeline = (uint64_t *)buf;

@@ -94,6 +94,26 @@ int strip_cpl(int cols_total, bool all_mult64, bool all_mult32);
 bool strip_x_ok(int M, int spw, int nw, int cpl, int chain);
 int launch_strip(const StripParams &p, int grid, hipStream_t stream);
 
+// ---- engine.hip (persistent decode engine: loader wave + LDS ring + consumer waves) -------------------------------------
+struct EngineLink {  // == qllm_engine_link_t (include/qllm_mi355x.h)
+  const uint32_t *qweight;
+  const half_t *scales;
+  const void *qzeros;
+  const half_t *bias;
+  const uint16_t *x;
+  uint16_t *y;
+  int32_t N, K;
+  int32_t n_strips;  // N / 32
+  int32_t strip0;    // global index of this link's first 32-column strip (strips are dealt to blocks round-robin)
+  int32_t slabs;     // ceil(K / 1024)
+  int32_t zero_kind;
+  int32_t add_zero_bias;
+  int32_t x_poll;    // x is another link's output (0xFFFF-armed buffer)
+};
+bool engine_link_ok(const qllm_weight_t &w, int M, int act_dtype);
+size_t engine_lds_bytes();
+int launch_engine(const EngineLink *links_dev, int n_links, uint32_t *err, int grid, hipStream_t stream);
+
 // ---- gemm.hip ------------------------------------------------------------------------------------------------
 struct GemmParams {
   const void *x;

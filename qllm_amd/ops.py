@@ -103,7 +103,16 @@ class DecodeChain:
     graph's static outputs.  A forward the chain cannot take (shape without a chained plan, M > 4) joins both streams and
     runs as an ordinary launch.  torch ops on chained outputs must come after the `with` block (or after `chain.join()`)."""
 
-    def __init__(self, device=None, arena_bytes: int = 8 << 20):
+    def __init__(self, device=None, arena_bytes: int = 8 << 20, mode: Optional[str] = None):
+        # "engine": the links of a step are RECORDED and run as one persistent launch (csrc/engine.hip: a loader wave per CU
+        #           streams the weights through an LDS ring, consumer waves wait only for activations);
+        # "streams": every link is its own launch, alternating between two streams (csrc/strip.hip, CH variants).
+        self.mode = mode or os.environ.get("QLLM_CHAIN_MODE", "engine")
+        if self.mode not in ("engine", "streams"):
+            raise ValueError("DecodeChain mode must be 'engine' or 'streams'")
+        self._prog: list = []          # engine mode: recorded links of the current segment
+        self._prog_cache: dict = {}    # program bytes -> device copy
+        self._strip0 = 0
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         if self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
@@ -141,7 +150,11 @@ class DecodeChain:
         self._turn = 0
         self.links = 0
         self.fallbacks = 0
-        if os.environ.get("QLLM_CHAIN_SERIAL", "0") == "1":
+        self._prog = []
+        self._strip0 = 0
+        if self.mode == "engine":
+            self._live = (self._main, self._main)
+        elif os.environ.get("QLLM_CHAIN_SERIAL", "0") == "1":
             # profiling aid: the same chained kernels, all on the caller's stream (no overlap; every poll succeeds at once) --
             # counter-collecting profilers serialise dispatches, under which an overlapped chain would sit out its time-outs
             self._live = (self._main, self._main)
@@ -157,17 +170,39 @@ class DecodeChain:
         _active_chain.pop(self.device.index, None)
         self._high = max(self._high, self._cursor)
         self.join()
-        if self._capturing and self._cursor > self._armed and exc[0] is None:
+        if self._capturing and self._cursor > self._armed and (not exc or exc[0] is None):
             raise RuntimeError("DecodeChain: the captured step used more of the arena than the warm-up steps before it, so its "
                                "replays would not re-arm those bytes; run the same step once eagerly before capturing")
         self._main = None
         return False
 
     def join(self):
-        """Order the caller's stream after everything issued on the chain's streams so far."""
+        """Order the caller's stream after everything issued (or recorded) in the chain so far."""
+        if self.mode == "engine":
+            self._flush()
+            return
         for s in self._live:
             if s is not self._main:
                 self._main.wait_stream(s)
+
+    def _flush(self):
+        """engine mode: launch the links recorded since the last flush as one persistent program on the caller's stream."""
+        if not self._prog:
+            return
+        n = len(self._prog)
+        arr = (_lib.QllmEngineLink * n)(*self._prog)
+        key = bytes(arr)
+        dev = self._prog_cache.get(key)
+        if dev is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("DecodeChain(engine): this step's program is not on the device yet and cannot be uploaded inside "
+                                   "a graph capture; run the same step once eagerly before capturing")
+            dev = torch.frombuffer(bytearray(key), dtype=torch.uint8).to(self.device)
+            self._prog_cache[key] = dev
+        with torch.cuda.device(self.device):
+            rc = _lib.load().qllm_engine_run(dev.data_ptr(), n, self.err.data_ptr(), self._main.cuda_stream)
+        _lib.check(rc)
+        self._prog = []
 
     # -- used by the forward wrappers -----------------------------------------------------------------------------------
     def owns(self, t: torch.Tensor) -> bool:
@@ -200,8 +235,35 @@ def active_chain(device: torch.device) -> Optional[DecodeChain]:
     return _active_chain.get(device.index if device.index is not None else torch.cuda.current_device())
 
 
+def _engine_record(chain: DecodeChain, ws_desc: Sequence[QllmWeight], x2d: torch.Tensor):
+    """engine mode: validate + record the layers (one link each; layers that share x just name the same input).  None when
+    one of them is outside the engine's scope: nothing is recorded then."""
+    lib = _lib.load()
+    if x2d.shape[0] != 1:
+        return None
+    cursor, strip0, n_prog = chain._cursor, chain._strip0, len(chain._prog)
+    poll = 1 if chain.owns(x2d) else 0
+    outs = []
+    for w in ws_desc:
+        y = chain.alloc((1, w.N), x2d.dtype)
+        link = _lib.QllmEngineLink()
+        rc = lib.qllm_engine_link_init(C.byref(w), x2d.data_ptr(), y.data_ptr(), 1, _act_dtype(x2d), poll, chain._strip0, C.byref(link))
+        if rc == _lib.QLLM_ERR_UNSUPPORTED:
+            chain._cursor, chain._strip0 = cursor, strip0
+            del chain._prog[n_prog:]
+            return None
+        _lib.check(rc)
+        chain._prog.append(link)
+        chain._strip0 += w.N // 32
+        outs.append(y)
+    chain.links += 1
+    return outs
+
+
 def _chained_forward(chain: DecodeChain, ws_desc: Sequence[QllmWeight], x2d: torch.Tensor):
     """One chained link, or None when the library has no chained plan for it (the caller then joins and launches normally)."""
+    if chain.mode == "engine":
+        return _engine_record(chain, ws_desc, x2d)
     lib = _lib.load()
     n, m = len(ws_desc), x2d.shape[0]
     arr = (QllmWeight * n)(*ws_desc)

@@ -50,14 +50,15 @@ def _step(blocks, h, keep=None):
     return h
 
 
-def test_chained_step_matches_ordinary_launches_and_oracle():
+@pytest.mark.parametrize("mode", ["engine", "streams"])
+def test_chained_step_matches_ordinary_launches_and_oracle(mode):
     from qllm_amd import ops
     blocks = _blocks(2)
     h0 = torch.from_numpy(randx(1, H, seed=3)).to(DEV)
     plain = []
     y_plain = _step(blocks, h0, plain)
     torch.cuda.synchronize()
-    chain = ops.DecodeChain(DEV)
+    chain = ops.DecodeChain(DEV, mode=mode)
     kept = []
     with chain:
         y_chain = _step(blocks, h0, kept)
@@ -79,13 +80,14 @@ def test_chained_step_matches_ordinary_launches_and_oracle():
         assert O.rel_err(y.float().cpu().numpy(), ref.y64(x_np)) <= 2e-3, name
 
 
-def test_chained_step_under_graph_replay_is_stable():
+@pytest.mark.parametrize("mode", ["engine", "streams"])
+def test_chained_step_under_graph_replay_is_stable(mode):
     """Capture one chained step (two streams inside the graph), replay it many times while another stream keeps part of the
     chip busy (uneven load, warm L1s): every replay must reproduce the first result bit for bit."""
     from qllm_amd import ops
     blocks = _blocks(3, seed=100)
     h0 = torch.from_numpy(randx(1, H, seed=5)).to(DEV)
-    chain = ops.DecodeChain(DEV)
+    chain = ops.DecodeChain(DEV, mode=mode)
 
     def step():
         with chain:
@@ -155,11 +157,12 @@ def test_chained_link_gives_up_instead_of_hanging():
     assert ops.chain_plan_describe([w], 5) == "not chainable"
 
 
-def test_chain_falls_back_for_shapes_without_a_chained_plan():
-    """A narrow layer inside the chain joins both streams, runs as an ordinary launch, and the chain carries on."""
+@pytest.mark.parametrize("mode", ["engine", "streams"])
+def test_chain_falls_back_for_shapes_without_a_chained_plan(mode):
+    """A layer the chain cannot take (here: group size 32) joins / flushes, runs as an ordinary launch, and the chain carries on."""
     from qllm_amd import ops
     wide = synth("GPTQ", 4, 128, H, H, seed=11)
-    narrow = synth("GPTQ", 4, 128, H, 768, seed=12)     # 48 strips: split-K kernel, no chained plan
+    narrow = synth("GPTQ", 4, 32, H, 768, seed=12)      # g32: split-K kernel, no chained plan, outside the engine's scope
     back = synth("GPTQ", 4, 128, 768, H, seed=13)
     for d in (wide, narrow, back):
         d["scales"] = (d["scales"].astype(np.float32) * 0.3).astype(np.float16)
@@ -167,7 +170,7 @@ def test_chain_falls_back_for_shapes_without_a_chained_plan():
     x = torch.from_numpy(randx(1, H, seed=4)).to(DEV)
     ref = l3(l2(l1(x)))
     torch.cuda.synchronize()
-    chain = ops.DecodeChain(DEV)
+    chain = ops.DecodeChain(DEV, mode=mode)
     with chain:
         y = l3(l2(l1(x)))
     torch.cuda.synchronize()
