@@ -267,7 +267,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--chain", type=int, default=int(os.environ.get("QLLM_BENCH_CHAIN", "1")),
                     help="1: the step runs inside ops.DecodeChain (links alternate between two streams)")
-    ap.add_argument("--chain-mode", default=os.environ.get("QLLM_CHAIN_MODE", "engine"), choices=["engine", "streams"],
+    ap.add_argument("--chain-mode", default=os.environ.get("QLLM_CHAIN_MODE", "streams"), choices=["engine", "streams"],
                     help="engine: the step's links as one persistent launch (loader wave + LDS ring); streams: one launch per link on two streams")
     ap.add_argument("--fused", type=int, default=int(os.environ.get("QLLM_BENCH_FUSED", "1")),
                     help="1: sibling groups (q/k/v and gate/up as one grouped launch each: 4 launches per layer instead of 7)")

@@ -439,7 +439,9 @@ int qllm_engine_run(const qllm_engine_link_t *links_device, int32_t n_links, voi
   if (!links_device || n_links < 1) return set_error(QLLM_ERR_INVALID, "links_device must hold >= 1 link");
   if (!err_word || (uintptr_t)err_word % 4) return set_error(QLLM_ERR_INVALID, "err_word must be a 4-byte aligned device word");
   static int grid = env_int("QLLM_ENGINE_GRID", kNumCU);
-  return launch_engine((const EngineLink *)links_device, n_links, (uint32_t *)err_word, grid, (hipStream_t)stream);
+  // diagnostics (qllm_debug_timeline): the buffer must hold (grid * n_links + 2 * grid) * 4 u64, i.e. n_slots * 8 >= that
+  uint64_t *dbg = (g_timeline && (size_t)g_timeline_slots * 8 >= ((size_t)grid * n_links + 2 * grid) * 4) ? g_timeline : nullptr;
+  return launch_engine((const EngineLink *)links_device, n_links, (uint32_t *)err_word, grid, (hipStream_t)stream, dbg);
 }
 
 int qllm_debug_timeline(void *buf, int32_t n_slots) {

@@ -111,8 +111,9 @@ struct EngineLink {  // == qllm_engine_link_t (include/qllm_mi355x.h)
   int32_t x_poll;    // x is another link's output (0xFFFF-armed buffer)
 };
 bool engine_link_ok(const qllm_weight_t &w, int M, int act_dtype);
+constexpr int kEngineMaxLinks = 1024;  // links per program (the kernel keeps a packed table of them in LDS)
 size_t engine_lds_bytes();
-int launch_engine(const EngineLink *links_dev, int n_links, uint32_t *err, int grid, hipStream_t stream);
+int launch_engine(const EngineLink *links_dev, int n_links, uint32_t *err, int grid, hipStream_t stream, uint64_t *dbg = nullptr);
 
 // ---- gemm.hip ------------------------------------------------------------------------------------------------
 struct GemmParams {

@@ -107,10 +107,12 @@ class DecodeChain:
         # "engine": the links of a step are RECORDED and run as one persistent launch (csrc/engine.hip: a loader wave per CU
         #           streams the weights through an LDS ring, consumer waves wait only for activations);
         # "streams": every link is its own launch, alternating between two streams (csrc/strip.hip, CH variants).
-        self.mode = mode or os.environ.get("QLLM_CHAIN_MODE", "engine")
+        self.mode = mode or os.environ.get("QLLM_CHAIN_MODE", "streams")  # measured: streams 865 tok/s, engine 775 (profiles/r02_engine.md)
         if self.mode not in ("engine", "streams"):
             raise ValueError("DecodeChain mode must be 'engine' or 'streams'")
         self._prog: list = []          # engine mode: recorded links of the current segment
+        self._keep: list = []          # ... and the tensors they name, alive until the segment is launched (a recorded link holds
+                                       #     raw pointers; an input freed before the flush could be handed out again)
         self._prog_cache: dict = {}    # program bytes -> device copy
         self._strip0 = 0
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
@@ -151,6 +153,7 @@ class DecodeChain:
         self.links = 0
         self.fallbacks = 0
         self._prog = []
+        self._keep = []
         self._strip0 = 0
         if self.mode == "engine":
             self._live = (self._main, self._main)
@@ -203,6 +206,7 @@ class DecodeChain:
             rc = _lib.load().qllm_engine_run(dev.data_ptr(), n, self.err.data_ptr(), self._main.cuda_stream)
         _lib.check(rc)
         self._prog = []
+        self._keep = []  # (stream-ordered reuse after the launch is safe: it runs on the caller's stream)
 
     # -- used by the forward wrappers -----------------------------------------------------------------------------------
     def owns(self, t: torch.Tensor) -> bool:
@@ -256,6 +260,7 @@ def _engine_record(chain: DecodeChain, ws_desc: Sequence[QllmWeight], x2d: torch
         chain._prog.append(link)
         chain._strip0 += w.N // 32
         outs.append(y)
+    chain._keep.append(x2d)
     chain.links += 1
     return outs
 
