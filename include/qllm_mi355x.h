@@ -224,6 +224,14 @@ int qllm_unpack_qweight(const void *qweight, int32_t layout, int32_t bits, int32
 int qllm_pack_qweight(const int32_t *q_kn, int32_t layout, int32_t bits, int32_t K, int32_t N, void *qweight,
                       void *stream);
 
+/* out[m, k] = x[m, perm[k]] for a row-major [M, K] matrix of 2-byte activations (fp16 or bf16; act_dtype only names the
+ * element size).  The act-order helper: the reference's kernels index scales[g_idx[k]] per weight row
+ * (quant_linear_gptq.py:38-43, ort_ops gemv/dequant with g_idx); this library serves act-order layers from a copy whose rows
+ * are sorted by group (perm = argsort(g_idx), built at load with qllm_unpack_qweight / qllm_pack_qweight), which needs the same
+ * permutation applied to the columns of x at every forward.  perm: K int32 on the device, a permutation of 0..K-1 (entries are
+ * not range-checked).  x, perm, out 16-byte aligned, out must not alias x; K % 8 == 0 and K <= 28672, else QLLM_ERR_UNSUPPORTED. */
+int qllm_gather_columns(const void *x, const int32_t *perm, void *out, int32_t M, int32_t K, int32_t act_dtype, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -21,7 +21,7 @@ ABI_VERSION = 2
 EXPORTS = (
     "qllm_abi_version", "qllm_last_error", "qllm_device_info", "qllm_workspace_bytes", "qllm_workspace_init",
     "qllm_linear_forward", "qllm_linear_forward_grouped", "qllm_dequant", "qllm_ort_gemv", "qllm_ort_dequant",
-    "qllm_awq_gemm_forward", "qllm_unpack_qweight", "qllm_pack_qweight", "qllm_ort_dequantize4bits",
+    "qllm_awq_gemm_forward", "qllm_unpack_qweight", "qllm_pack_qweight", "qllm_gather_columns", "qllm_ort_dequantize4bits",
     "qllm_plan_describe", "qllm_linear_forward_chained", "qllm_chain_plan_describe",
     "qllm_debug_timeline", "qllm_engine_link_init", "qllm_engine_run",
 )
@@ -96,6 +96,8 @@ def _declare(lib):
     lib.qllm_unpack_qweight.argtypes = [vp, i32, i32, i32, i32, vp, vp]
     lib.qllm_pack_qweight.restype = C.c_int
     lib.qllm_pack_qweight.argtypes = [vp, i32, i32, i32, i32, vp, vp]
+    lib.qllm_gather_columns.restype = C.c_int
+    lib.qllm_gather_columns.argtypes = [vp, vp, vp, i32, i32, i32, vp]
     lib.qllm_plan_describe.restype = C.c_int
     lib.qllm_plan_describe.argtypes = [wp, i32, i32, i32, C.c_char_p, sz]
     lib.qllm_linear_forward_chained.restype = C.c_int

@@ -444,6 +444,18 @@ int qllm_engine_run(const qllm_engine_link_t *links_device, int32_t n_links, voi
   return launch_engine((const EngineLink *)links_device, n_links, (uint32_t *)err_word, grid, (hipStream_t)stream, dbg);
 }
 
+int qllm_gather_columns(const void *x, const int32_t *perm, void *out, int32_t M, int32_t K, int32_t act_dtype, void *stream) {
+  clear_error();
+  if (!x || !perm || !out) return set_error(QLLM_ERR_INVALID, "x / perm / out must not be NULL");
+  if (M < 0 || K <= 0) return set_error(QLLM_ERR_INVALID, "M must be >= 0 and K >= 1 (got M=%d K=%d)", M, K);
+  if (act_dtype != QLLM_F16 && act_dtype != QLLM_BF16) return set_error(QLLM_ERR_INVALID, "act_dtype must be QLLM_F16 or QLLM_BF16");
+  if ((uintptr_t)x % 16 || (uintptr_t)out % 16 || (uintptr_t)perm % 16) return set_error(QLLM_ERR_INVALID, "x / perm / out must be 16-byte aligned");
+  if (x == out) return set_error(QLLM_ERR_INVALID, "the gather is not in-place: out must not alias x");
+  if (!gather_columns_ok(K)) return set_error(QLLM_ERR_UNSUPPORTED, "column gather serves K %% 8 == 0, K <= 28672 (got %d)", K);
+  if (M == 0) return QLLM_OK;
+  return launch_gather_columns(x, perm, out, M, K, (hipStream_t)stream);
+}
+
 int qllm_debug_timeline(void *buf, int32_t n_slots) {
   clear_error();
   g_timeline = (uint64_t *)buf;
@@ -613,7 +625,7 @@ int qllm_plan_describe(const qllm_weight_t *w, int32_t n_weights, int32_t M, int
     p.group_size = w[0].group_size;
     p.gs_shift = ((w[0].group_size & (w[0].group_size - 1)) == 0) ? __builtin_ctz((unsigned)w[0].group_size) : -1;
     if (gemm2_ok(p, w[0].layout) && gemm3_ok(p, w[0].layout) && gemm2_split_k(M, w[0].N, w[0].K) == 1) {
-      snprintf(buf, buflen, "gemm3 tile=256x128 matrix-waves=4 staging-waves=4");
+      snprintf(buf, buflen, "gemm3 tile=256x128 matrix-waves=8 staging-waves=4");
     } else if (gemm2_ok(p, w[0].layout)) {
       const int S = have_workspace ? gemm2_split_k(M, w[0].N, w[0].K) : 1;
       snprintf(buf, buflen, "gemm2 tile=256x%d split_k=%d", gemm2_tile_n(M, w[0].N, S), S);

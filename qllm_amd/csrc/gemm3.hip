@@ -341,7 +341,7 @@ int launch_gemm3(const GemmParams &p_in, int layout, hipStream_t stream) {
   GemmParams p = p_in;
   static int raster = getenv("QLLM_GEMM2_RASTER") ? atoi(getenv("QLLM_GEMM2_RASTER")) : 1;
   p.raster = raster;
-  static int mw = getenv("QLLM_GEMM3_MW") ? atoi(getenv("QLLM_GEMM3_MW")) : 4;
+  static int mw = getenv("QLLM_GEMM3_MW") ? atoi(getenv("QLLM_GEMM3_MW")) : 8;  // measured (profiles/r02_prefill_summary.md): 8 matrix waves 908 / 923 / 1004 TFLOP/s, 4: 873 / 915 / 1003
   static int prio = getenv("QLLM_GEMM3_PRIO") ? atoi(getenv("QLLM_GEMM3_PRIO")) : 1;
   if (mw == 4 && !prio) return layout == QLLM_LAYOUT_AWQ_GEMM ? launch_gemm3_b<1, 4, false>(p, stream) : launch_gemm3_b<0, 4, false>(p, stream);
   if (mw == 8) return layout == QLLM_LAYOUT_AWQ_GEMM ? launch_gemm3_b<1, 8>(p, stream) : launch_gemm3_b<0, 8>(p, stream);

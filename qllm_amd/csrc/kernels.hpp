@@ -94,6 +94,10 @@ int strip_cpl(int cols_total, bool all_mult64, bool all_mult32);
 bool strip_x_ok(int M, int spw, int nw, int cpl, int chain);
 int launch_strip(const StripParams &p, int grid, hipStream_t stream);
 
+// ---- gather.hip (act-order: out[m, k] = x[m, perm[k]], 2-byte elements) ------------------------------------------------------
+bool gather_columns_ok(int K);
+int launch_gather_columns(const void *x, const int32_t *perm, void *out, int M, int K, hipStream_t stream);
+
 // ---- engine.hip (persistent decode engine: loader wave + LDS ring + consumer waves) -------------------------------------
 struct EngineLink {  // == qllm_engine_link_t (include/qllm_mi355x.h)
   const uint32_t *qweight;

@@ -94,7 +94,7 @@ class QuantLinearGPTQ(nn.Module, CompressWeight, HipForwardMixin):
                 b = self._f16(self.bias).contiguous() if self.bias is not None else None
                 desc = ops.make_weight("GPTQ", qw, self._f16(self.scales).contiguous(), self.qzeros.contiguous(), None, b,
                                        self.infeatures, self.outfeatures, self.groupsize, 4, add_zero_bias)
-                self._ao, self._ao_key = (desc, perm), key
+                self._ao, self._ao_key = (desc, perm.to(torch.int32).contiguous()), key
         return self._ao if self._ao else None
 
     def forward(self, x):
@@ -108,7 +108,7 @@ class QuantLinearGPTQ(nn.Module, CompressWeight, HipForwardMixin):
             if ao is not None:
                 from ... import ops
                 (desc, _keep), perm = ao
-                x2d = x.reshape(-1, x.shape[-1]).index_select(1, perm)
+                x2d = ops.gather_columns(x.reshape(-1, x.shape[-1]).contiguous(), perm)
                 try:
                     return ops.linear_forward(desc, x2d).reshape(x.shape[:-1] + (self.outfeatures,))
                 except ops.QllmUnsupported:

@@ -427,6 +427,25 @@ def ort_dequantize4bits(qweight: torch.Tensor, scales: torch.Tensor, qzeros: tor
     return out if scales.dtype == torch.float16 else out.to(scales.dtype)
 
 
+def gather_columns(x2d: torch.Tensor, perm: torch.Tensor) -> torch.Tensor:
+    """x2d[:, perm] for a contiguous [M, K] fp16 / bf16 matrix and an int32 device permutation (act-order layers: the
+    activation side of the row-sorted weight copy).  The library's LDS-staged gather; shapes it does not take
+    (K % 8, K > 28672) fall back to index_select."""
+    _check_x(x2d, ())
+    if perm.dtype != torch.int32 or perm.device != x2d.device or perm.numel() != x2d.shape[1] or not perm.is_contiguous():
+        raise RuntimeError("perm must be a contiguous int32 tensor of K entries on x's device")
+    out = torch.empty_like(x2d)
+    if x2d.shape[0] == 0:
+        return out
+    with torch.cuda.device(x2d.device):
+        rc = _lib.load().qllm_gather_columns(x2d.data_ptr(), perm.data_ptr(), out.data_ptr(), x2d.shape[0], x2d.shape[1],
+                                             _act_dtype(x2d), _stream_ptr())
+    if rc == _lib.QLLM_ERR_UNSUPPORTED:
+        return x2d.index_select(1, perm.long())
+    _lib.check(rc)
+    return out
+
+
 def unpack_qweight(qweight: torch.Tensor, layout: str, bits: int, in_features: int, out_features: int) -> torch.Tensor:
     _check_input(qweight, "qweight")
     q = torch.empty((in_features, out_features), dtype=torch.int32, device=qweight.device)
@@ -451,5 +470,5 @@ def pack_qweight(q_kn: torch.Tensor, layout: str, bits: int) -> torch.Tensor:
     return out
 
 
-__all__ = ["make_weight", "linear_forward", "linear_forward_grouped", "dequant", "unpack_qweight", "pack_qweight",
+__all__ = ["make_weight", "linear_forward", "linear_forward_grouped", "dequant", "gather_columns", "unpack_qweight", "pack_qweight",
            "workspace", "QllmUnsupported", "LAYOUTS", "DecodeChain", "active_chain", "plan_describe", "chain_plan_describe"]

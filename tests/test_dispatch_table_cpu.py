@@ -53,7 +53,7 @@ def test_llama7b_decode_routes(lib):
 
 def test_llama7b_prefill_routes(lib):
     attn, up, down = W(4096, 4096), W(4096, 11008), W(11008, 4096)
-    g3 = "gemm3 tile=256x128 matrix-waves=4 staging-waves=4"
+    g3 = "gemm3 tile=256x128 matrix-waves=8 staging-waves=4"
     assert plan(lib, [attn], 2048) == g3                                   # 256 tiles, one per CU: the wave-specialised kernel
     assert plan(lib, [attn], 8192) == g3
     assert plan(lib, [down], 2048) == g3 and plan(lib, [up], 2048) == g3

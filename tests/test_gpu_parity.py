@@ -497,3 +497,34 @@ def test_wave_specialised_prefill_kernel_vs_oracle(layout, g, K, N, zk, bias):
     x = torch.from_numpy(randx(4096, K, seed=9)).to(DEV)
     assert ops.plan_describe([layer._descriptor(None, 0)], 4096).startswith("gemm3")
     assert torch.equal(layer(x), layer(x))
+
+
+# ---- column gather (act-order: the activation side of the row-sorted weight copy) ---------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,K", [(1, 4096), (3, 8), (7, 136), (16, 4096), (300, 11008), (2048, 4096), (33, 16384), (5, 28672)])
+def test_gather_columns_is_bit_exact(M, K, dtype):
+    from qllm_amd import ops
+    gen = torch.Generator().manual_seed(M * 131 + K)
+    x = torch.randn(M, K, generator=gen).to(dtype).to(DEV)
+    perm = torch.randperm(K, generator=gen).to(torch.int32).to(DEV)
+    got = ops.gather_columns(x, perm)
+    want = x.index_select(1, perm.long())
+    assert got.shape == want.shape and got.dtype == dtype
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+
+
+def test_gather_columns_arguments_and_fallback():
+    from qllm_amd import _lib, ops
+    x = torch.randn(4, 4100).half().to(DEV)                       # K % 8 != 0: no kernel, the wrapper falls back to index_select
+    perm = torch.randperm(4100).to(torch.int32).to(DEV)
+    assert torch.equal(ops.gather_columns(x, perm), x.index_select(1, perm.long()))
+    lib = _lib.load()
+    rc = lib.qllm_gather_columns(x.data_ptr(), perm.data_ptr(), x.data_ptr(), 4, 4096, _lib.DT_F16, None)   # aliasing
+    assert rc == _lib.QLLM_ERR_INVALID
+    rc = lib.qllm_gather_columns(x.data_ptr(), perm.data_ptr(), torch.empty_like(x).data_ptr(), 4, 4100, _lib.DT_F16, None)
+    assert rc == _lib.QLLM_ERR_UNSUPPORTED
+    assert ops.gather_columns(x[:0].contiguous(), perm).shape == (0, 4100)
+    with pytest.raises(RuntimeError):
+        ops.gather_columns(x, perm.long())                          # int64 perm
+    with pytest.raises(RuntimeError):
+        ops.gather_columns(x, perm[:-1].contiguous())               # wrong length
