@@ -124,8 +124,9 @@ static bool strip_plan(const qllm_weight_t *w, int n, int M, StripPlan *plan, in
   if (bits != 4 && bits != 3) return false;
   for (int i = 0; i < n; ++i) {
     if (w[i].bits != bits || w[i].K % 32 != 0 || w[i].g_idx) return false;
-    // 3-bit: fp16 (HQQ) or symmetric zeros only -- packed 3-bit zero points straddle words
-    if (bits == 3 && !(w[i].layout == QLLM_LAYOUT_HQQ || (w[i].layout == QLLM_LAYOUT_GPTQ && !w[i].qzeros))) return false;
+    // 3-bit: fp16 (HQQ), symmetric, or packed zero points (a column's field may straddle two words of the N*3/32-word row)
+    if (bits == 3 && !(w[i].layout == QLLM_LAYOUT_HQQ || w[i].layout == QLLM_LAYOUT_GPTQ)) return false;
+    if (bits == 3 && w[i].layout == QLLM_LAYOUT_GPTQ && w[i].qzeros && w[i].N % 32 != 0) return false;
     if ((uintptr_t)w[i].qweight % 16 || (uintptr_t)w[i].scales % 16 || (w[i].qzeros && (uintptr_t)w[i].qzeros % 8)) return false;
   }
   int cols = 0;

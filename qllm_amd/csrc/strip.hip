@@ -287,9 +287,11 @@ __global__ __launch_bounds__(NW * 64, CH ? (NW == 8 ? 4 : 8) : ((NW == 8 && CPL 
   // fp16 -> the dword(s) holding halves (G, n..n+CPL-1); symmetric -> any valid dword (ignored)
   const int zk = pr.zero_kind;
   const uint32_t *zbase = (zk == ZK_SYM) ? (const uint32_t *)pr.scales : (const uint32_t *)pr.qzeros;
-  const int zmul = (zk == ZK_PACKED) ? (N >> 3) : (N >> 1);
-  const int zoff = (zk == ZK_PACKED) ? (n >> 3) : (n >> 1);
-  const int zoff2 = (zk == ZK_F16 && CPL == 4) ? 1 : 0;
+  // (3-bit packed: column n sits at bit 3n of the group's row of N*3/32 words and may straddle two of them: the lane keeps the
+  //  word holding its first bit and the next one -- clamped to the row, where nothing straddles -- and funnel-shifts)
+  const int zmul = (zk == ZK_PACKED) ? (BITS == 3 ? (N * 3) >> 5 : (N >> 3)) : (N >> 1);
+  const int zoff = (zk == ZK_PACKED) ? (BITS == 3 ? (n * 3) >> 5 : (n >> 3)) : (n >> 1);
+  const int zoff2 = (BITS == 3) ? ((zk == ZK_PACKED && zoff + 1 < zmul) ? 1 : 0) : ((zk == ZK_F16 && CPL == 4) ? 1 : 0);
   const uint32_t zsel_p = (zk == ZK_PACKED) ? 0xffffffffu : 0u, zsel_h = (zk == ZK_F16) ? 0xffffffffu : 0u;
   const uint32_t zsel_s = (zk == ZK_SYM) ? __builtin_bit_cast(uint32_t, (float)(1 << (BITS - 1))) : 0u;
   // RA: this lane's activation row (MFMA row i; rows >= M re-read row M-1, their outputs are never stored), k-slot 8g
@@ -327,7 +329,7 @@ __global__ __launch_bounds__(NW * 64, CH ? (NW == 8 ? 4 : 8) : ((NW == 8 && CPL 
           scx[j][0] = pr.scales[(size_t)G * N + n];
         }
         zx[j][0] = zbase[(size_t)G * zmul + zoff];
-        zx[j][1] = (CPL == 4) ? zbase[(size_t)G * zmul + zoff + zoff2] : 0u;
+        zx[j][1] = (CPL == 4 || BITS == 3) ? zbase[(size_t)G * zmul + zoff + zoff2] : 0u;
       }
     };
     if constexpr (LW) {
@@ -484,7 +486,9 @@ __global__ __launch_bounds__(NW * 64, CH ? (NW == 8 ? 4 : 8) : ((NW == 8 && CPL 
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
           // this group's scale / zero of column n+c, converted to fp32 here (keeps the raw 16/32-bit words live instead)
-          const float zp = (float)(((zraw[j][0] >> (4 * ((n + c) & 7))) + (uint32_t)p.add_zero_bias) & 15u);
+          const uint32_t zfield = (BITS == 3) ? (uint32_t)(((((uint64_t)zraw[j][1]) << 32) | zraw[j][0]) >> ((3 * n) & 31))
+                                              : (zraw[j][0] >> (4 * ((n + c) & 7)));
+          const float zp = (float)((zfield + (uint32_t)p.add_zero_bias) & (uint32_t)((1 << BITS) - 1));
           const uint32_t zd = (CPL >= 2) ? zraw[j][c >> 1] : zraw[j][0];
           const bool hi = (CPL >= 2) ? (c & 1) : (n & 1);
           const float zh = (float)__builtin_bit_cast(half_t, (uint16_t)(hi ? (zd >> 16) : (zd & 0xffffu)));

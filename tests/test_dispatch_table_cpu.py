@@ -80,7 +80,7 @@ def test_other_layouts_and_widths(lib):
     # 3 bits: fused for HQQ / symmetric zeros at decode sizes only
     assert plan(lib, [W(4096, 4096, 64, 3, HQQ)], 16).startswith("strip nw=16 cpl=1")
     assert plan(lib, [W(4096, 4096, 128, 3, GPTQ, zeros=None)], 1).startswith("strip")
-    assert plan(lib, [W(4096, 4096, 128, 3, GPTQ)], 1).startswith("unsupported")   # packed 3-bit zeros straddle words
+    assert plan(lib, [W(4096, 4096, 128, 3, GPTQ)], 1).startswith("strip")          # packed 3-bit zeros: funnel shift over two words
     assert plan(lib, [W(4096, 4096, 64, 3, HQQ)], 300).startswith("unsupported")    # prefill: dequant + GEMM
     assert plan(lib, [W(4096, 4096, 128, 8)], 1).startswith("unsupported")
     # raw act-order descriptors (the modules use a row-sorted view instead): in-place gather in the 128x128 kernel

@@ -265,6 +265,33 @@ def test_three_bit_decode_kernel(layout, g, K, N, zk):
         assert O.rel_err(y, ref.y64(x)) <= 2e-3, (layout, m)
 
 
+@pytest.mark.parametrize("g,K,N,compat", [(128, 4096, 4096, 0), (64, 4096, 11008, 0), (128, 11008, 4096, 1), (128, 1024, 256, 0)])
+def test_three_bit_packed_zero_points_decode_kernel(g, K, N, compat):
+    """GPTQ 3-bit with PACKED zero points (a column's 3-bit field may straddle two words of the N*3/32-word row): served by the
+    fused strip kernel at decode sizes, with and without the AutoGPTQ +1 (quant_linear_gptq.py:33-36)."""
+    from qllm_amd import ops
+    d = synth("GPTQ", 3, g, K, N, "asym", False, True, seed=K + N + g)
+    d["compat"] = compat
+    layer = to_layer(d, DEV)
+    w = oracle_w(d)
+    old = os.environ.get("COMPATIBLE_WITH_AUTOGPTQ")
+    os.environ["COMPATIBLE_WITH_AUTOGPTQ"] = str(compat)
+    try:
+        for m in (1, 5, 16):
+            x = randx(m, K, seed=m)
+            y = layer(torch.from_numpy(x).to(DEV)).cpu().numpy()
+            assert O.rel_err(y, oracle_y(d, x, w)) <= TOL, (g, K, N, m)
+    finally:
+        if old is None:
+            os.environ.pop("COMPATIBLE_WITH_AUTOGPTQ", None)
+        else:
+            os.environ["COMPATIBLE_WITH_AUTOGPTQ"] = old
+    qw, sc, qz = (torch.from_numpy(np.ascontiguousarray(d[k])).to(DEV) for k in ("qweight", "scales", "qzeros"))
+    wd, keep = ops.make_weight("GPTQ", qw, sc, qz, None, None, K, N, g, 3, compat)
+    plan = ops.plan_describe([wd], 1)
+    assert plan.startswith("strip"), plan
+
+
 def test_odd_bits_route_through_dequant_kernel():
     for layout, bits, g in (("HQQ", 3, 64), ("GPTQ", 3, 128), ("GPTQ", 8, 128), ("HQQ", 2, 64)):
         d = synth(layout, bits, g, 4096, 1024, seed=bits)
