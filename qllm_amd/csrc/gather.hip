@@ -10,7 +10,6 @@
 
 namespace qllm {
 
-namespace {
 constexpr int kGatherThreads = 256;
 constexpr int kMaxChunks = 14;  // 8-element output chunks per thread: K <= 256 * 8 * 14 = 28672
 
@@ -62,6 +61,7 @@ __global__ __launch_bounds__(kGatherThreads) void gather_columns_kernel(const ui
   }
 }
 
+namespace {
 template <int CHUNKS>
 int launch_b(const void *x, const int32_t *perm, void *out, int M, int K, int parts, hipStream_t stream) {
   // rows per block: enough blocks to cover the chip several times, at least 2 rows each so the double buffer has something to hide
