@@ -147,5 +147,8 @@ if pf:
         P += ["Context (`python tools/one_shape.py --ref`): the same shape as a dense fp16 `torch.matmul` (hipBLASLt), weights already dequantised:", "", "```"]
         P += [l.rstrip() for l in open(fn) if "TFLOP" in l]
         P += ["```", ""]
+    notes = f"{out}/{tag}_prefill_notes.md"
+    if os.path.exists(notes):  # hand-written reading of the numbers above, kept next to them
+        P += [l.rstrip("\n") for l in open(notes)]
     open(f"{out}/{tag}_prefill_summary.md", "w").write("\n".join(P) + "\n")
     print("\n".join(P))
