@@ -231,9 +231,7 @@ static int run_strip(const qllm_weight_t *w, void *const *y, int n, const void *
     q.N = w[i].N;
     q.n_strips = w[i].N / (16 * pl.cpl);
     q.block_begin = block;
-#ifdef QLLM_STRIP_HEADER
     p.block_begin8[i] = block;
-#endif
     q.zero_kind = zero_kind_of(w[i]);
     block += q.n_strips;
   }

@@ -118,21 +118,13 @@ __global__ __launch_bounds__(NW * 64, CH ? (NW == 8 ? 4 : 8) : ((NW == 8 && CPL 
   int pi = 0;
 #pragma unroll
   for (int q = 1; q < kMaxProblems; ++q)
-#ifdef QLLM_STRIP_HEADER
     if (q < p.n_prob && (int)blockIdx.x >= p.block_begin8[q]) pi = q;
-#else
-    if (q < p.n_prob && (int)blockIdx.x >= p.prob[q].block_begin) pi = q;
-#endif
-#ifdef QLLM_STRIP_HEADER
   // ... and the whole problem record plus the remaining launch scalars pulled in ONE batch: the empty asm "uses" them here, so
   // hipcc must have issued every s_load before this point instead of one at a time at first use
   const StripProblem pr = p.prob[pi];
   asm volatile("" ::"s"(pr.qweight), "s"(pr.scales), "s"(pr.qzeros), "s"(pr.bias), "s"(pr.y), "s"(pr.N), "s"(pr.n_strips),
                "s"(pr.block_begin), "s"(pr.zero_kind), "s"(p.x), "s"(p.M), "s"(p.K), "s"(p.T), "s"(p.spw), "s"(p.group_size),
                "s"(p.add_zero_bias), "s"(p.act_bf16));
-#else
-  const StripProblem &pr = p.prob[pi];
-#endif
 
   int b = blockIdx.x - pr.block_begin;
   if (CPL == 1 && (pr.n_strips & 15) == 0) {

