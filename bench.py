@@ -60,13 +60,16 @@ def alg_bytes(K, N, M, g=GROUP, zeros="packed", act_order=False):
     return K * N // 2 + G * N * 2 + z + (4 * K if act_order else 0) + 2 * M * K + 2 * M * N
 
 
-def make_layer(cls, K, N, dev, gen, act_order=False):
-    layer = cls(4, GROUP, K, N, False, dtype=torch.float16)
+def make_layer(cls, K, N, dev, gen, act_order=False, bits=4, group=GROUP):
+    layer = cls(bits, group, K, N, False, dtype=torch.float16)
     shape_w, shape_z, shape_s = layer.qweight.shape, layer.qzeros.shape, layer.scales.shape
     layer.qweight = torch.randint(-2 ** 31, 2 ** 31 - 1, shape_w, dtype=torch.int32, device=dev, generator=gen)
-    layer.qzeros = torch.randint(-2 ** 31, 2 ** 31 - 1, shape_z, dtype=torch.int32, device=dev, generator=gen)
+    if layer.qzeros.dtype.is_floating_point:  # HQQ: fp16 zero points
+        layer.qzeros = (torch.rand(shape_z, device=dev, generator=gen) * (2 ** bits - 1)).to(torch.float16)
+    else:
+        layer.qzeros = torch.randint(-2 ** 31, 2 ** 31 - 1, shape_z, dtype=torch.int32, device=dev, generator=gen)
     # std(q - z) ~ 6.5 for independent uniform nibbles: scale so each linear roughly preserves magnitude
-    base = 1.0 / (K ** 0.5 * 6.5)
+    base = 1.0 / (K ** 0.5 * 6.5 * (2 ** bits) / 16)
     layer.scales = ((torch.rand(shape_s, device=dev, generator=gen) * 0.4 + 0.8) * base).to(torch.float16)
     if act_order:
         layer.g_idx = layer.g_idx[torch.randperm(K)].contiguous()
@@ -76,16 +79,17 @@ def make_layer(cls, K, N, dev, gen, act_order=False):
 class Block(torch.nn.Module):
     """One decoder layer's quantized linears under their Llama names (what swap_quantized_linears leaves in a model)."""
 
-    def __init__(self, cls, dev, gen, act_order=False, hidden=HIDDEN, inter=INTER, kv=None):
+    def __init__(self, cls, dev, gen, act_order=False, hidden=HIDDEN, inter=INTER, kv=None, bits=4, group=GROUP):
         super().__init__()
         kv = hidden if kv is None else kv
-        self.q_proj = make_layer(cls, hidden, hidden, dev, gen, act_order)
-        self.k_proj = make_layer(cls, hidden, kv, dev, gen, act_order)
-        self.v_proj = make_layer(cls, hidden, kv, dev, gen, act_order)
-        self.o_proj = make_layer(cls, hidden, hidden, dev, gen, act_order)
-        self.gate_proj = make_layer(cls, hidden, inter, dev, gen, act_order)
-        self.up_proj = make_layer(cls, hidden, inter, dev, gen, act_order)
-        self.down_proj = make_layer(cls, inter, hidden, dev, gen, act_order)
+        mk = lambda K, N: make_layer(cls, K, N, dev, gen, act_order, bits, group)  # noqa: E731
+        self.q_proj = mk(hidden, hidden)
+        self.k_proj = mk(hidden, kv)
+        self.v_proj = mk(hidden, kv)
+        self.o_proj = mk(hidden, hidden)
+        self.gate_proj = mk(hidden, inter)
+        self.up_proj = mk(hidden, inter)
+        self.down_proj = mk(inter, hidden)
 
     def forward(self, h):
         q = self.q_proj(h)
@@ -100,11 +104,11 @@ class Block(torch.nn.Module):
 class Stack(torch.nn.Module):
     """The quantized linears of the decoder stack, driven in model order through the module API."""
 
-    def __init__(self, cls, n_layers, dev, seed, act_order=False, fused=True):
+    def __init__(self, cls, n_layers, dev, seed, act_order=False, fused=True, bits=4, group=GROUP):
         super().__init__()
         from qllm_amd.modeling.q_layers import install_sibling_groups
         gen = torch.Generator(device=dev).manual_seed(seed)
-        self.blocks = torch.nn.ModuleList([Block(cls, dev, gen, act_order) for _ in range(n_layers)])
+        self.blocks = torch.nn.ModuleList([Block(cls, dev, gen, act_order, bits=bits, group=group) for _ in range(n_layers)])
         self.groups = install_sibling_groups(self, [cls]) if fused else 0
 
     def set_fused(self, on: bool):
@@ -221,6 +225,30 @@ def cpu_baseline_leg(dev):
                 ms_per_shape={"4096x4096": round(per_shape[0] * 1e3, 2), "4096x11008": round(per_shape[1] * 1e3, 2),
                               "11008x4096": round(per_shape[2] * 1e3, 2)},
                 gpu_vs_cpu_rel_err_11008x4096=round(rel, 6))
+
+
+def hqq_leg(dev):
+    """BASELINE configs[3]: HQQ g64 fp16 zeros, batch 16, 4-bit and 3-bit decoder layers (the reference mixes them per layer).
+    Four layers of each width (> the 256 MB Infinity Cache together with their neighbours), through the modules with the
+    loader's sibling groups, like the headline leg; the 7-launch form beside it."""
+    extra = {}
+    from qllm_amd.modeling.q_layers import QuantLinearHQQ
+    x16 = torch.randn(16, HIDDEN, device=dev, dtype=torch.float16)
+    for bits_sel, tag in ((4, "hqq_w4_g64_m16"), (3, "hqq_w3_g64_m16")):
+        hs = Stack(QuantLinearHQQ, 4, dev, seed=7 + bits_sel, bits=bits_sel, group=64)
+        nbytes = 4 * sum(alg_bytes(K, N, 16, 64, "f16") * bits_sel // 4
+                         for (K, N) in [(HIDDEN, HIDDEN)] * 4 + [(HIDDEN, INTER)] * 2 + [(INTER, HIDDEN)])
+        res = {}
+        for fz in (True, False):
+            hs.set_fused(fz)
+            gh, _ = capture(lambda: hs(x16))
+            ms = time_events(gh.replay, 20) / 4
+            del gh
+            res["grouped" if fz else "ungrouped"] = ms
+        extra[tag] = {"ms_per_layer": round(res["grouped"], 4), "GBps": round(nbytes / 4 / res["grouped"] / 1e6, 1),
+                      "ms_per_layer_7_launches": round(res["ungrouped"], 4)}
+        del hs
+    return extra
 
 
 def pmc_traffic(args):
@@ -410,26 +438,7 @@ def main():
             extra[f"prefill_m2048_{tag}"] = {"ms_per_4_layers": round(ms, 3), "TFLOPs": round(tf, 1),
                                              "frac_of_mfma_peak": round(tf / MFMA_PEAK_TFLOPS, 4)}
             del ps
-        # BASELINE configs[3]: HQQ g64 fp16 zeros, batch 16, alternating 4-bit / 3-bit layers.  Two decoder layers' 7 linears each.
-        from qllm_amd.modeling.q_layers import QuantLinearHQQ
-        hq = []
-        for li, bits in enumerate((4, 3)):
-            for (K, N) in [(HIDDEN, HIDDEN)] * 4 + [(HIDDEN, INTER)] * 2 + [(INTER, HIDDEN)]:
-                l = QuantLinearHQQ(bits, 64, K, N, False, dtype=torch.float16)
-                l.qweight = torch.randint(-2 ** 31, 2 ** 31 - 1, l.qweight.shape, dtype=torch.int32, device=dev)
-                l.qzeros = (torch.rand(l.qzeros.shape, device=dev) * (2 ** bits - 1)).half()
-                l.scales = ((torch.rand(l.scales.shape, device=dev) * 0.4 + 0.8) / (K ** 0.5 * 6.5)).half()
-                hq.append((l.to(dev), K))
-        xs16 = {K: torch.randn(16, K, device=dev, dtype=torch.float16) for K in (HIDDEN, INTER)}
-        for bits_sel, tag in ((4, "hqq_w4_g64_m16"), (3, "hqq_w3_g64_m16")):
-            ls = [(l, K) for (l, K) in hq if l.bits == bits_sel]
-            gh, _ = capture(lambda: [l(xs16[K]) for l, K in ls])
-            ms = time_events(gh.replay, 20)
-            del gh
-            nbytes = sum(alg_bytes(l.infeatures, l.outfeatures, 16, 64, "f16") * bits_sel // 4 for l, _ in ls)
-            extra[tag] = {"ms_per_layer": round(ms, 4), "GBps": round(nbytes / ms / 1e6, 1)}
-        del hq
-        torch.cuda.empty_cache()
+        extra.update(hqq_leg(dev))
         try:  # BASELINE configs[4] on one GPU: the per-rank shard shapes of Llama-2-70B at TP = 8
             from tools import tp_bench
             extra.update(tp_bench.shard_shapes_leg(dev))

@@ -80,3 +80,32 @@ def test_awq_inference_engine_stub():
         assert O.rel_err(y.cpu().numpy(), Ref(d).y16(x)) <= 1e-2
     with pytest.raises(RuntimeError):
         eng.gemm_forward_cuda(torch.from_numpy(x).to(DEV)[:, :100].contiguous(), qweight, scales, qzeros, 8)   # K not a multiple of g
+
+
+def test_awq_inference_engine_stub_decode_uses_a_row_stream_copy():
+    """M <= 64 through the stub: served from a cached row-stream copy of the caller's integers (strip kernel); the copy follows
+    in-place updates of the caller's tensors (keyed on identity AND version) and can be switched off."""
+    eng = _load_stub("awq_inference_engine")
+    d = synth("GEMM", 4, 128, 4096, 4096, seed=7)
+    qweight, scales, qzeros = _t(d, "qweight", "scales", "qzeros")
+    for m in (1, 5, 64):
+        x = randx(m, 4096, seed=m)
+        y = eng.gemm_forward_cuda(torch.from_numpy(x).to(DEV), qweight, scales, qzeros, 8)
+        assert O.rel_err(y.cpu().numpy(), Ref(d).y16(x)) <= 1e-2 and O.rel_err(y.float().cpu().numpy(), Ref(d).y64(x)) <= 2e-3
+    assert len(eng._rows) == 1                                           # one weight, one copy, reused across M
+    x = randx(1, 4096, seed=1)
+    xt = torch.from_numpy(x).to(DEV)
+    y_shadow = eng.gemm_forward_cuda(xt, qweight, scales, qzeros, 8)
+    os.environ["QLLM_AWQ_DECODE_SHADOW"] = "0"
+    try:
+        y_inplace = eng.gemm_forward_cuda(xt, qweight, scales, qzeros, 8)
+    finally:
+        del os.environ["QLLM_AWQ_DECODE_SHADOW"]
+    assert O.rel_err(y_shadow.cpu().numpy(), y_inplace.cpu().numpy()) <= 2e-3
+    # the caller overwrites its weights in place (e.g. loads another checkpoint into the same buffers): no stale copy
+    d2 = synth("GEMM", 4, 128, 4096, 4096, seed=8)
+    qweight.copy_(torch.from_numpy(d2["qweight"]))
+    qzeros.copy_(torch.from_numpy(d2["qzeros"]))
+    scales.copy_(torch.from_numpy(d2["scales"]))
+    y2 = eng.gemm_forward_cuda(xt, qweight, scales, qzeros, 8)
+    assert O.rel_err(y2.cpu().numpy(), Ref(d2).y16(x)) <= 1e-2

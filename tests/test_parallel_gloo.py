@@ -80,7 +80,52 @@ def _worker_body(rank, world, port, names, q):
             if err > 2e-3:  # different summation order + fp16 partials in this CPU stand-in
                 ok = False
                 msgs.append(f"{name} row-parallel err {err}")
-        # Megatron pair: column-parallel (no gather) feeding row-parallel: one all-reduce for the pair
+    # Megatron pair (o_proj after q/k/v, down after gate/up): column-parallel WITHOUT the gather feeding row-parallel with
+    # input_is_parallel: rank r's output columns are exactly rank r's input rows of the second layer, so the pair costs ONE
+    # all-reduce and no all-gather.  Count the collectives, compare with the unsharded pair.
+    from oracle import ref_cpu as O
+    rng = np.random.default_rng(5)
+
+    def mk(K, N, bias):
+        qw, qz = O.pack_gptq(rng.integers(0, 16, (K, N), dtype=np.int32), rng.integers(0, 16, (K // 128, N), dtype=np.int32), 4)
+        l = QuantLinearGPTQ(4, 128, K, N, bias, dtype=torch.float16)
+        l.qweight, l.qzeros = torch.from_numpy(qw), torch.from_numpy(qz)
+        l.scales = torch.from_numpy((rng.random((K // 128, N)) * 0.01 + 0.002).astype(np.float16))
+        if bias:
+            l.bias = torch.from_numpy((rng.standard_normal(N) * 0.1).astype(np.float16))
+        return l
+
+    A, B = mk(256, 512, False), mk(512, 256, True)
+    x = torch.from_numpy(rng.standard_normal((3, 256)).astype(np.float16))
+    y_full = _oracle_forward(B, _oracle_forward(A, x))
+    calls = {"all_reduce": 0, "all_gather": 0}
+    real_ar, real_ag = dist.all_reduce, dist.all_gather_into_tensor
+
+    def count_ar(*a, **k):
+        calls["all_reduce"] += 1
+        return real_ar(*a, **k)
+
+    def count_ag(*a, **k):
+        calls["all_gather"] += 1
+        return real_ag(*a, **k)
+
+    dist.all_reduce, dist.all_gather_into_tensor = count_ar, count_ag
+    try:
+        col = P.ColumnParallelQuantLinear.from_full(A, gather_output=False)
+        row = P.RowParallelQuantLinear.from_full(B, input_is_parallel=True)
+        h = col(x)
+        assert h.shape == (3, 512 // world)
+        y = row(h)
+    finally:
+        dist.all_reduce, dist.all_gather_into_tensor = real_ar, real_ag
+    if calls != {"all_reduce": 1, "all_gather": 0}:
+        ok = False
+        msgs.append(f"Megatron pair used {calls}")
+    # (the bias of a row-parallel layer must be added once, not once per rank)
+    err = float((y.float() - y_full.float()).abs().max() / y_full.float().abs().max())
+    if err > 2e-3:
+        ok = False
+        msgs.append(f"Megatron pair err {err}")
     if rank == 0:
         q.put((ok, msgs))
     dist.barrier()
