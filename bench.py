@@ -60,7 +60,7 @@ def alg_bytes(K, N, M, g=GROUP, zeros="packed", act_order=False):
     return K * N // 2 + G * N * 2 + z + (4 * K if act_order else 0) + 2 * M * K + 2 * M * N
 
 
-def make_layer(cls, K, N, dev, gen, act_order=False, bits=4, group=GROUP):
+def make_layer(cls, K, N, dev, gen, act_order=False, bits=4, group=GROUP, g_idx=None):
     layer = cls(bits, group, K, N, False, dtype=torch.float16)
     shape_w, shape_z, shape_s = layer.qweight.shape, layer.qzeros.shape, layer.scales.shape
     layer.qweight = torch.randint(-2 ** 31, 2 ** 31 - 1, shape_w, dtype=torch.int32, device=dev, generator=gen)
@@ -71,8 +71,8 @@ def make_layer(cls, K, N, dev, gen, act_order=False, bits=4, group=GROUP):
     # std(q - z) ~ 6.5 for independent uniform nibbles: scale so each linear roughly preserves magnitude
     base = 1.0 / (K ** 0.5 * 6.5 * (2 ** bits) / 16)
     layer.scales = ((torch.rand(shape_s, device=dev, generator=gen) * 0.4 + 0.8) * base).to(torch.float16)
-    if act_order:
-        layer.g_idx = layer.g_idx[torch.randperm(K)].contiguous()
+    if act_order:  # (g_idx: the order shared with the layers fed by the same input, see Block)
+        layer.g_idx = (layer.g_idx[torch.randperm(K)] if g_idx is None else g_idx).contiguous()
     return layer.to(dev)
 
 
@@ -82,14 +82,19 @@ class Block(torch.nn.Module):
     def __init__(self, cls, dev, gen, act_order=False, hidden=HIDDEN, inter=INTER, kv=None, bits=4, group=GROUP):
         super().__init__()
         kv = hidden if kv is None else kv
-        mk = lambda K, N: make_layer(cls, K, N, dev, gen, act_order, bits, group)  # noqa: E731
-        self.q_proj = mk(hidden, hidden)
-        self.k_proj = mk(hidden, kv)
-        self.v_proj = mk(hidden, kv)
-        self.o_proj = mk(hidden, hidden)
-        self.gate_proj = mk(hidden, inter)
-        self.up_proj = mk(hidden, inter)
-        self.down_proj = mk(inter, hidden)
+        # act-order: GPTQ's permutation is argsort(diag(H)) of the layer INPUT's Hessian (qllm/quantization/gptq/gptq.py:168), so
+        # q/k/v share one g_idx and gate/up another, as in a real checkpoint; o_proj and down_proj have their own
+        def order(K):
+            return (torch.arange(K, dtype=torch.int32) // group)[torch.randperm(K)] if act_order else None
+        mk = lambda K, N, gi=None: make_layer(cls, K, N, dev, gen, act_order, bits, group, gi)  # noqa: E731
+        g_attn, g_mlp = order(hidden), order(hidden)
+        self.q_proj = mk(hidden, hidden, g_attn)
+        self.k_proj = mk(hidden, kv, g_attn)
+        self.v_proj = mk(hidden, kv, g_attn)
+        self.o_proj = mk(hidden, hidden, order(hidden))
+        self.gate_proj = mk(hidden, inter, g_mlp)
+        self.up_proj = mk(hidden, inter, g_mlp)
+        self.down_proj = mk(inter, hidden, order(inter))
 
     def forward(self, h):
         q = self.q_proj(h)

@@ -23,11 +23,13 @@
 //     after barrier #t nobody reads B stage t%2 / A slot t%3 any more, and B stage (t+1)%2 / A slot (t+1)%3 are complete
 //     (every matrix wave waited for its own DMA pieces of tile t+1 before arriving).  The matrix waves use the raw
 //     s_barrier with explicit lgkmcnt(0) / vmcnt(8): __syncthreads() would drain the DMA ring (vmcnt(0)).
-//   * LDS rows are 64 halves (128 B) with the eight 16-byte slots XORed by (row >> 1) & 7: conflict-free for the 32x32x16
+//   * LDS rows are 64 halves (128 B) with the eight 16-byte slots XORed by lds_row_swizzle(row) (common.hpp; the plain
+//     (row >> 1) & 7 of the first version left the staging waves' ds_write_b128 2-way conflicted: 8 consecutive rows hit only 4
+//     slots -- 2.2 M of 15.3 M LDS cycles per launch): conflict-free for the 32x32x16
 //     fragment reads (lane l -> row l % 32, slot 2*ks + l / 32: each 16-lane service group of ds_read_b128 sees 8 even and
 //     8 odd rows with 8 distinct row>>1 values mod 8) and for the GPTQ weight stores (8 consecutive rows at one slot).  An
 //     LDS-DMA piece lands lane-linear (lane l -> row l / 8, physical slot l % 8), so the swizzle is applied to the SOURCE:
-//     lane l fetches logical chunk (l % 8) ^ ((row >> 1) & 7) of its row (cdna_hip_programming.md rule 21).
+//     lane l fetches logical chunk (l % 8) ^ lds_row_swizzle(row) of its row (cdna_hip_programming.md rule 21).
 //   * epilogue: + bias, one rounding, transposed through wave-private LDS into 16-byte row-contiguous stores.
 // Serves what gemm2's 256x128 form serves when no split-K is wanted (M >= 1024 on the Llama shapes); gemm2 keeps the rest.
 // Replaces gemm_forward_4bit_cuda_m16n128k32 (/root/reference/csrc/awq_cuda/quantization/gemm_cuda_gen.cu:31-353).
@@ -43,7 +45,7 @@ constexpr int kATile = BM * BK, kBTile = BN * BK;  // halves per stage
 typedef float float16_t __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void lds_void_t;
 
-__device__ __forceinline__ int tile_off(int row, int slot) { return row * BK + ((slot ^ (row >> 1)) & 7) * 8; }  // in halves
+__device__ __forceinline__ int tile_off(int row, int slot) { return row * BK + ((slot ^ lds_row_swizzle(row)) & 7) * 8; }  // in halves
 }  // namespace g3
 
 // LAYOUT 0 = GPTQ/HQQ row stream, 1 = AWQ GEMM.  fp16 activations.  Requires K % 128 == 0 (even number of k-tiles), N % 128 == 0, power-of-two group size >= 32, no g_idx.
@@ -200,7 +202,7 @@ __global__ __launch_bounds__((MW + 4) * 64) void gemm3_kernel(const GemmParams p
   for (int q = 0; q < NP; ++q) {
     const int r = wave * (8 * NP) + 8 * q + (lane >> 3);
     const int grow = min(m0 + r, p.M - 1);  // rows past M re-read the last row; their outputs are never stored
-    voff_x[q] = grow * p.K * 2 + (((lane & 7) ^ ((r >> 1) & 7)) << 4);
+    voff_x[q] = grow * p.K * 2 + (((lane & 7) ^ lds_row_swizzle(r)) << 4);
   }
   // one DMA piece (8 rows x 128 B of this wave's 64 rows) of k-tile kt into ring slot `slot`
   // (the builtin's operands are first copied into plain locals: called with template-dependent expressions, the HOST pass of

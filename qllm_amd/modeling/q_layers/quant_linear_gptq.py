@@ -12,6 +12,32 @@ from ._hip_forward import HipForwardMixin, _tkey, autogptq_compat
 from .compress_weight import CompressWeight, general_pack_on_row, general_unpack_on_row
 
 
+# ---- act-order: one gather of x per distinct permutation ----------------------------------------------------------------
+# GPTQ derives the act-order permutation from the Hessian of the layer's INPUT (reference: qllm/quantization/gptq/gptq.py:168,
+# perm = argsort(diag(H)), H accumulated from the inputs, :97-102), so layers fed by the same tensor -- q/k/v, gate/up -- carry the
+# same g_idx.  Equal permutations are interned to ONE device tensor, and the most recent gather per device is kept with a
+# reference to the very tensor it was made from (identity + version, like the sibling groups): the second and third sibling
+# reuse it instead of gathering again.
+_PERMS: dict = {}
+_LAST_GATHER: dict = {}
+
+
+def _intern_perm(perm: torch.Tensor) -> torch.Tensor:
+    import hashlib
+    key = (perm.device, perm.numel(), hashlib.sha1(perm.cpu().numpy().tobytes()).hexdigest())
+    return _PERMS.setdefault(key, perm)
+
+
+def _gathered(x: torch.Tensor, perm: torch.Tensor) -> torch.Tensor:
+    from ... import ops
+    hit = _LAST_GATHER.get(x.device)
+    if hit is not None and hit[0] is x and hit[1] == x._version and hit[2] is perm:
+        return hit[3]
+    out = ops.gather_columns(x.reshape(-1, x.shape[-1]).contiguous(), perm)
+    _LAST_GATHER[x.device] = (x, x._version, perm, out)
+    return out
+
+
 class QuantLinearGPTQ(nn.Module, CompressWeight, HipForwardMixin):
     """Buffers (state-dict compatible with the reference / AutoGPTQ-style checkpoints):
         qweight i32 [K//32*bits, N]   column n = bit stream along K
@@ -94,7 +120,7 @@ class QuantLinearGPTQ(nn.Module, CompressWeight, HipForwardMixin):
                 b = self._f16(self.bias).contiguous() if self.bias is not None else None
                 desc = ops.make_weight("GPTQ", qw, self._f16(self.scales).contiguous(), self.qzeros.contiguous(), None, b,
                                        self.infeatures, self.outfeatures, self.groupsize, 4, add_zero_bias)
-                self._ao, self._ao_key = (desc, perm.to(torch.int32).contiguous()), key
+                self._ao, self._ao_key = (desc, _intern_perm(perm.to(torch.int32).contiguous())), key
         return self._ao if self._ao else None
 
     def forward(self, x):
@@ -108,7 +134,7 @@ class QuantLinearGPTQ(nn.Module, CompressWeight, HipForwardMixin):
             if ao is not None:
                 from ... import ops
                 (desc, _keep), perm = ao
-                x2d = ops.gather_columns(x.reshape(-1, x.shape[-1]).contiguous(), perm)
+                x2d = _gathered(x, perm)
                 try:
                     return ops.linear_forward(desc, x2d).reshape(x.shape[:-1] + (self.outfeatures,))
                 except ops.QllmUnsupported:

@@ -526,6 +526,40 @@ def test_wave_specialised_prefill_kernel_vs_oracle(layout, g, K, N, zk, bias):
     assert torch.equal(layer(x), layer(x))
 
 
+def test_act_order_siblings_share_one_gather():
+    """q/k/v of a GPTQ act-order checkpoint carry the same g_idx (the order comes from the shared input's Hessian,
+    qllm/quantization/gptq/gptq.py:168): the three modules must gather x once, and again after x changes in place."""
+    from qllm_amd import ops
+    K, g = 4096, 128
+    base = synth("GPTQ", 4, g, K, 4096, "asym", True, False, seed=41)
+    ds = [base] + [dict(synth("GPTQ", 4, g, K, n, "asym", False, False, seed=42 + i), g_idx=base["g_idx"].copy()) for i, n in enumerate((1024, 1024))]
+    layers = [to_layer(d, DEV) for d in ds]
+    calls = []
+    real = ops.gather_columns
+    ops.gather_columns = lambda x, perm: (calls.append(1), real(x, perm))[1]
+    try:
+        for m in (1, 300):
+            x = torch.from_numpy(randx(m, K, seed=m)).to(DEV)
+            calls.clear()
+            ys = [l(x) for l in layers]
+            assert len(calls) == 1, calls
+            for d, y in zip(ds, ys):
+                assert O.rel_err(y.cpu().numpy(), oracle_y(d, x.cpu().numpy())) <= TOL
+            x.mul_(0.5)                                    # same tensor object, new version: never a stale gather
+            calls.clear()
+            y0 = layers[0](x)
+            assert len(calls) == 1
+            assert O.rel_err(y0.cpu().numpy(), oracle_y(ds[0], x.cpu().numpy())) <= TOL
+        other_d = synth("GPTQ", 4, g, K, 1024, "asym", True, False, seed=77)   # its own order: its own gather
+        other = to_layer(other_d, DEV)
+        calls.clear()
+        y_o = other(x)
+        assert len(calls) == 1
+        assert O.rel_err(y_o.cpu().numpy(), oracle_y(other_d, x.cpu().numpy())) <= TOL
+    finally:
+        ops.gather_columns = real
+
+
 # ---- column gather (act-order: the activation side of the row-sorted weight copy) ---------------------------------------
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("M,K", [(1, 4096), (3, 8), (7, 136), (16, 4096), (300, 11008), (2048, 4096), (33, 16384), (5, 28672)])
