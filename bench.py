@@ -298,8 +298,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--chain", type=int, default=int(os.environ.get("QLLM_BENCH_CHAIN", "1")),
-                    help="1: the step runs inside ops.DecodeChain (links alternate between two streams)")
+    ap.add_argument("--chain", type=int, default=int(os.environ.get("QLLM_BENCH_CHAIN", "0")),
+                    help="1: the step runs inside ops.DecodeChain (flag-synchronised links, --chain-mode).  Default 0: since the 64-byte "
+                         "argument header the plain grouped graph is as fast (profiles/r02_chain_experiments.md); the chained and the "
+                         "engine form of the same step are reported under extra")
     ap.add_argument("--chain-mode", default=os.environ.get("QLLM_CHAIN_MODE", "streams"), choices=["engine", "streams"],
                     help="engine: the step's links as one persistent launch (loader wave + LDS ring); streams: one launch per link on two streams")
     ap.add_argument("--fused", type=int, default=int(os.environ.get("QLLM_BENCH_FUSED", "1")),
@@ -424,9 +426,16 @@ def main():
             if ch is None and not args.chain and fz == fused:
                 continue
             stack.set_fused(fz)
-            gg, _ = capture(decode_step_fn(stack, h0, ch))
-            ms = time_events(gg.replay, 20)
-            del gg
+            try:
+                gg, _ = capture(decode_step_fn(stack, h0, ch))
+                ms = time_events(gg.replay, 20)
+                del gg
+                if ch is not None:
+                    ch.check()  # a link that timed out waiting for its input invalidates the number
+            except Exception as e:  # noqa: BLE001  (a side leg must not take the headline down with it)
+                extra["decode_stack_" + tag] = {"error": f"{type(e).__name__}: {e}"}
+                torch.cuda.synchronize()
+                continue
             extra["decode_stack_" + tag] = {"ms_per_token": round(ms, 4), "tokens_per_s": round(1e3 / ms, 1),
                                             "GBps": round(bpt / ms / 1e6, 1), "frac_of_hbm_peak": round(bpt / ms / 1e6 / HBM_PEAK_GBPS, 4)}
         stack.set_fused(fused)

@@ -2,9 +2,9 @@
 # End-of-round evidence run on the GPU box (one gpurun call):  bash tools/profile_round2.sh <tag>
 #   1. full -m gpu parity suite                                  -> gpurun_out/<tag>_pytest.log
 #   2. default bench.py line (incl. its own PMC passes)           -> gpurun_out/<tag>_bench.json
-#   3. rocprofv3 --kernel-trace --stats of `bench.py --no-extra` with the chain's links SERIALISED on one stream
-#      (QLLM_CHAIN_SERIAL=1: under the tracer an overlapped chain shows 60 us kernels that mostly wait), then FETCH_SIZE /
-#      WRITE_SIZE in their own passes                              -> gpurun_out/prof_<tag>/{trace,pmc_fetch,pmc_write}
+#   3. rocprofv3 --kernel-trace --stats of `bench.py --no-extra` (the headline form: plain grouped graph, one stream), then
+#      FETCH_SIZE / WRITE_SIZE in their own passes                  -> gpurun_out/prof_<tag>/{trace,pmc_fetch,pmc_write}
+#      (QLLM_CHAIN_SERIAL=1 only matters for `--chain 1` runs: under the tracer an overlapped chain shows 60 us kernels that wait)
 #   4. prefill: kbench under --kernel-trace --stats, two SQ counter passes on the 4096x4096 M=2048 GEMM, hipBLASLt context line
 # tools/summarize_prof2.py condenses (3)/(4) into profiles/.
 tag=${1:-r02}

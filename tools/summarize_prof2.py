@@ -70,10 +70,10 @@ L = [f"# {tag}: decode step under rocprofv3, per launch", "",
      "Command (on the GPU box, `cd /tmp && export TMPDIR=/tmp` first):",
      "`QLLM_CHAIN_SERIAL=1 rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 20 --warmup 3 --no-extra`;",
      "HBM counters from two separate passes `--kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (5 steps) of the same command.",
-     "`QLLM_CHAIN_SERIAL=1` puts the chain's links on ONE stream: the kernels are the chained instantiations the headline run uses,",
-     "but each starts when its predecessor has finished, so a dispatch's duration is its own work (under the tracer an overlapped",
-     "chain shows ~60 us kernels that mostly wait for their input).  The headline number is the un-profiled overlapped run.", "",
-     f"bench line under the profiler (serialised links): value={bench['value']} {bench['unit']}, ms_per_step={bench['ms_per_step']}, "
+     "The headline form of the step: the plain grouped graph (4 launches per decoder layer on one stream, ordinary instantiations of",
+     "the strip kernel).  `QLLM_CHAIN_SERIAL=1` only matters for `--chain 1` runs (it puts chained links on one stream: under the",
+     "tracer an overlapped chain shows ~60 us kernels that mostly wait for their input).", "",
+     f"bench line under the profiler: value={bench['value']} {bench['unit']}, ms_per_step={bench['ms_per_step']}, "
      f"avg launch {bench['roofline']['avg_launch_us']} us incl. gaps", ""]
 if full:
     L += [f"un-profiled default run of the same commit (`{tag}_bench.json`): value={full['value']} {full['unit']}, "
