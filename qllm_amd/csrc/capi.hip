@@ -503,6 +503,28 @@ int qllm_linear_forward(const qllm_weight_t *w, const void *x, void *y, int32_t 
     if (strip_ok(w, 1, M)) return run_strip(w, ys, 1, x, M, act_dtype, (hipStream_t)stream);
     return run_skinny(w, ys, 1, x, M, act_dtype, workspace, workspace_bytes, (hipStream_t)stream);
   }
+  if (w->bits == 3 && M > 64 && w->layout != QLLM_LAYOUT_AWQ_GEMM && !w->g_idx && (uintptr_t)w->qweight % 16 == 0 &&
+      (uintptr_t)w->scales % 16 == 0 && (!w->qzeros || (uintptr_t)w->qzeros % 8 == 0)) {
+    // 3-bit row-stream layers at prefill sizes: the wave-specialised kernel with 3-bit staging waves (gemm3.hip, LAYOUT 2)
+    GemmParams p = {};
+    p.x = x;
+    p.qweight = (const uint32_t *)w->qweight;
+    p.scales = (const half_t *)w->scales;
+    p.qzeros = w->qzeros;
+    p.bias = (const half_t *)w->bias;
+    p.y = y;
+    p.M = M;
+    p.K = w->K;
+    p.N = w->N;
+    p.group_size = w->group_size;
+    p.gs_shift = ((w->group_size & (w->group_size - 1)) == 0) ? __builtin_ctz((unsigned)w->group_size) : -1;
+    p.add_zero_bias = w->add_zero_bias;
+    p.zero_kind = zero_kind_of(*w);
+    p.act_bf16 = (act_dtype == QLLM_BF16);
+    p.n_groups = (w->K + w->group_size - 1) / w->group_size;
+    p.split_k = 1;
+    if (gemm3_ok(p, kGemm3Rows3Bit)) return launch_gemm3(p, kGemm3Rows3Bit, (hipStream_t)stream);
+  }
   if (gemm_ok(*w)) {
     GemmParams p;
     p.x = x;
@@ -613,6 +635,20 @@ int qllm_plan_describe(const qllm_weight_t *w, int32_t n_weights, int32_t M, int
     skinny_plan(w[0].K, M, tiles_total, skinny_target_waves(), &S, &spw);
     snprintf(buf, buflen, "skinny tile_cols=%d split_k=%d spw=%d", tn, S, spw);
     return QLLM_OK;
+  }
+  if (n_weights == 1 && w[0].bits == 3 && M > 64 && w[0].layout != QLLM_LAYOUT_AWQ_GEMM && !w[0].g_idx &&
+      (uintptr_t)w[0].qweight % 16 == 0 && (uintptr_t)w[0].scales % 16 == 0 && (!w[0].qzeros || (uintptr_t)w[0].qzeros % 8 == 0)) {
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.M = M;
+    p.K = w[0].K;
+    p.N = w[0].N;
+    p.group_size = w[0].group_size;
+    p.gs_shift = ((w[0].group_size & (w[0].group_size - 1)) == 0) ? __builtin_ctz((unsigned)w[0].group_size) : -1;
+    if (gemm3_ok(p, kGemm3Rows3Bit)) {
+      snprintf(buf, buflen, "gemm3 tile=256x128 matrix-waves=8 staging-waves=4 bits=3");
+      return QLLM_OK;
+    }
   }
   if (n_weights == 1 && gemm_ok(w[0])) {
     GemmParams p;

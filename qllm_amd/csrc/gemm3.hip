@@ -48,7 +48,8 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 __device__ __forceinline__ int tile_off(int row, int slot) { return row * BK + ((slot ^ lds_row_swizzle(row)) & 7) * 8; }  // in halves
 }  // namespace g3
 
-// LAYOUT 0 = GPTQ/HQQ row stream, 1 = AWQ GEMM.  fp16 activations.  Requires K % 128 == 0 (even number of k-tiles), N % 128 == 0, power-of-two group size >= 32, no g_idx.
+// LAYOUT 0 = GPTQ/HQQ row stream (4 bits), 1 = AWQ GEMM, 2 = GPTQ/HQQ row stream with 3-bit weights (bit stream: the 32 k of
+// a half k-tile are 3 consecutive word rows of the column).  fp16 activations.  Requires K % 128 == 0 (even number of k-tiles), N % 128 == 0, power-of-two group size >= 32, no g_idx.
 // MW: matrix waves, 4 (one per SIMD, 128x64 each) or 8 (two per SIMD, 64x64 each: 8 fragment reads per 8 MFMAs instead of 6,
 // but the two waves cover each other's LDS / barrier waits); always 4 dequant waves behind them.
 template <int LAYOUT, int MW, bool PRIO = true>
@@ -82,20 +83,24 @@ __global__ __launch_bounds__((MW + 4) * 64) void gemm3_kernel(const GemmParams p
     const int t = tid - MW * 64;  // 0..255
     // ---- B -------------------------------------------------------------------------------------------------------------
     // GPTQ: thread = column t % 128, word rows 4 (t / 128) .. +3 of the 8 in a k-tile -> 4 x b128 stores
+    //       (3 bits: word rows 3 (t / 128) .. +2 of the 6 in a k-tile = the same 32 k -> the same 4 stores)
     // AWQ : thread = word column t % 16 (8 columns), k rows 4 (t / 16) .. +3 -> per column one 8-byte store of 4 k
-    const int bcol = (LAYOUT == 0) ? (t & 127) : 8 * (t & 15);
-    const int brow = (LAYOUT == 0) ? 4 * (t >> 7) : 4 * (t >> 4);
+    constexpr bool ROWS = LAYOUT != 1;   // row-stream layouts
+    constexpr int WPT = (LAYOUT == 2) ? 3 : 4;  // packed words per thread and k-tile
+    const int bcol = ROWS ? (t & 127) : 8 * (t & 15);
+    const int brow = ROWS ? 4 * (t >> 7) : 4 * (t >> 4);
     const int nB = n0 + bcol;
     const uint32_t nibmask = nib_mask_vgpr();
     const int zk = p.zero_kind;
     const uint32_t *zbase = (zk == ZK_SYM) ? (const uint32_t *)p.scales : (const uint32_t *)p.qzeros;
-    const int zmul = (zk == ZK_PACKED) ? (p.N >> 3) : (p.N >> 1);
-    const int zoff = (zk == ZK_PACKED) ? (nB >> 3) : (nB >> 1);
+    const int zmul = (zk == ZK_PACKED) ? (LAYOUT == 2 ? (p.N * 3) >> 5 : (p.N >> 3)) : (p.N >> 1);
+    const int zoff = (zk == ZK_PACKED) ? (LAYOUT == 2 ? (nB * 3) >> 5 : (nB >> 3)) : (nB >> 1);
+    const int zoff2 = (LAYOUT == 2 && zk == ZK_PACKED && zoff + 1 < zmul) ? 1 : 0;  // packed 3-bit zero points may straddle two words
     struct BSet {
       uint32_t w[4];
       half8_t s8;     // AWQ: the 8 columns' scales
       uint32_t sraw;  // GPTQ: the column's scale, raw 16 bits
-      uint32_t z;
+      uint32_t z, z2;
     };
     BSet bset[2];
     // buffer loads: per-lane byte offsets are loop constants, the k-tile / group advance is a scalar offset (SALU only)
@@ -103,28 +108,48 @@ __global__ __launch_bounds__((MW + 4) * 64) void gemm3_kernel(const GemmParams p
     const auto rs_w = __builtin_amdgcn_make_buffer_rsrc((void *)p.qweight, 0, (int)((size_t)p.K * p.N / 2), 0x00020000);
     const auto rs_s = __builtin_amdgcn_make_buffer_rsrc((void *)p.scales, 0, Gn * p.N * 2, 0x00020000);
     const auto rs_z = __builtin_amdgcn_make_buffer_rsrc((void *)zbase, 0, Gn * zmul * 4, 0x00020000);
-    const int wrow_bytes = (LAYOUT == 0) ? p.N * 4 : (p.N >> 3) * 4;        // bytes per packed row
-    const int ktile_bytes = ((LAYOUT == 0) ? 8 : BK) * wrow_bytes;         // packed rows per k-tile: 8 (GPTQ) / 64 (AWQ)
-    const int voff_w = brow * wrow_bytes + ((LAYOUT == 0) ? nB * 4 : (nB >> 3) * 4);
+    const int wrow_bytes = ROWS ? p.N * 4 : (p.N >> 3) * 4;                 // bytes per packed row
+    const int ktile_bytes = (LAYOUT == 0 ? 8 : (LAYOUT == 2 ? 6 : BK)) * wrow_bytes;  // packed rows per k-tile: 8 / 6 (3 bits) / 64 (AWQ)
+    const int voff_w = (LAYOUT == 2 ? 3 * (t >> 7) : brow) * wrow_bytes + (ROWS ? nB * 4 : (nB >> 3) * 4);
     const int voff_s = nB * 2, voff_z = zoff * 4;
-    const int krow0 = (LAYOUT == 0) ? 8 * brow : brow;                     // this thread's first k inside a k-tile
+    const int krow0 = ROWS ? 8 * brow : brow;                               // this thread's first k inside a k-tile
     auto load_b = [&](int kt, BSet &bs) {
       const int ktc = min(kt, KT - 1);
       const int so = ktc * ktile_bytes;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) bs.w[r] = __builtin_amdgcn_raw_buffer_load_b32(rs_w, voff_w + r * wrow_bytes, so, 0);
+      for (int r = 0; r < WPT; ++r) bs.w[r] = __builtin_amdgcn_raw_buffer_load_b32(rs_w, voff_w + r * wrow_bytes, so, 0);
       // one group per thread per k-tile (group_size >= 32); krow0 is per-lane only through brow (0 or 32 k for GPTQ)
       const int G0 = (ktc * BK) >> p.gs_shift, G1 = (ktc * BK + 32) >> p.gs_shift;
-      const int G = (LAYOUT == 0) ? ((krow0 >= 32) ? G1 : G0) : ((ktc * BK + krow0) >> p.gs_shift);
-      if constexpr (LAYOUT == 0)
+      const int G = ROWS ? ((krow0 >= 32) ? G1 : G0) : ((ktc * BK + krow0) >> p.gs_shift);
+      if constexpr (ROWS)
         bs.sraw = __builtin_amdgcn_raw_buffer_load_b16(rs_s, voff_s + G * p.N * 2, 0, 0);
       else
         bs.s8 = __builtin_bit_cast(half8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_s, voff_s + G * p.N * 2, 0, 0));
       bs.z = __builtin_amdgcn_raw_buffer_load_b32(rs_z, voff_z + G * zmul * 4, 0, 0);
+      if constexpr (LAYOUT == 2) bs.z2 = __builtin_amdgcn_raw_buffer_load_b32(rs_z, voff_z + zoff2 * 4 + G * zmul * 4, 0, 0);
     };
     auto store_b = [&](int stage, const BSet &bs) {
       half_t *Bb = Bs + stage * kBTile;
-      if constexpr (LAYOUT == 0) {
+      if constexpr (LAYOUT == 2) {
+        // 32 k = 96 bits of the column's bit stream in w[0..2]: four 24-bit fields of 8 values each, natural k order
+        const uint32_t zfield = (uint32_t)(((((uint64_t)bs.z2) << 32) | bs.z) >> ((3 * nB) & 31));
+        const half_t zp = (half_t)(float)((zfield + (uint32_t)p.add_zero_bias) & 7u);
+        const half_t zf = __builtin_bit_cast(half_t, (uint16_t)((nB & 1) ? (bs.z >> 16) : (bs.z & 0xffffu)));
+        const half_t sc = __builtin_bit_cast(half_t, (uint16_t)bs.sraw);
+        const ColConst cc = make_col_const(sc, (zk == ZK_PACKED) ? zp : ((zk == ZK_F16) ? zf : (half_t)4.f));
+        const uint32_t f[4] = {bs.w[0] & 0xffffffu, __builtin_amdgcn_alignbit(bs.w[1], bs.w[0], 24) & 0xffffffu,
+                               __builtin_amdgcn_alignbit(bs.w[2], bs.w[1], 16) & 0xffffffu, bs.w[2] >> 8};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          half2_t b[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const uint32_t lo = (f[r] >> (6 * j)) & 7u, hi = (f[r] >> (6 * j + 3)) & 7u;
+            b[j] = deq_pair(lo | (hi << 16) | kMagic, cc);
+          }
+          *(half8_t *)(Bb + tile_off(bcol, brow + r)) = half8_t{b[0].x, b[0].y, b[1].x, b[1].y, b[2].x, b[2].y, b[3].x, b[3].y};
+        }
+      } else if constexpr (LAYOUT == 0) {
         const half_t zp = (half_t)(float)(((bs.z >> (4 * (nB & 7))) + (uint32_t)p.add_zero_bias) & 15u);
         const half_t zf = __builtin_bit_cast(half_t, (uint16_t)((nB & 1) ? (bs.z >> 16) : (bs.z & 0xffffu)));
         const half_t sc = __builtin_bit_cast(half_t, (uint16_t)bs.sraw);
@@ -345,6 +370,7 @@ int launch_gemm3(const GemmParams &p_in, int layout, hipStream_t stream) {
   p.raster = raster;
   static int mw = getenv("QLLM_GEMM3_MW") ? atoi(getenv("QLLM_GEMM3_MW")) : 8;  // measured (profiles/r02_prefill_summary.md): 8 matrix waves 908 / 923 / 1004 TFLOP/s, 4: 873 / 915 / 1003
   static int prio = getenv("QLLM_GEMM3_PRIO") ? atoi(getenv("QLLM_GEMM3_PRIO")) : 1;
+  if (layout == kGemm3Rows3Bit) return launch_gemm3_b<2, 8>(p, stream);
   if (mw == 4 && !prio) return layout == QLLM_LAYOUT_AWQ_GEMM ? launch_gemm3_b<1, 4, false>(p, stream) : launch_gemm3_b<0, 4, false>(p, stream);
   if (mw == 8) return layout == QLLM_LAYOUT_AWQ_GEMM ? launch_gemm3_b<1, 8>(p, stream) : launch_gemm3_b<0, 8>(p, stream);
   return layout == QLLM_LAYOUT_AWQ_GEMM ? launch_gemm3_b<1, 4>(p, stream) : launch_gemm3_b<0, 4>(p, stream);

@@ -81,7 +81,9 @@ def test_other_layouts_and_widths(lib):
     assert plan(lib, [W(4096, 4096, 64, 3, HQQ)], 16).startswith("strip nw=16 cpl=1")
     assert plan(lib, [W(4096, 4096, 128, 3, GPTQ, zeros=None)], 1).startswith("strip")
     assert plan(lib, [W(4096, 4096, 128, 3, GPTQ)], 1).startswith("strip")          # packed 3-bit zeros: funnel shift over two words
-    assert plan(lib, [W(4096, 4096, 64, 3, HQQ)], 300).startswith("unsupported")    # prefill: dequant + GEMM
+    assert plan(lib, [W(4096, 4096, 64, 3, HQQ)], 300).startswith("unsupported")    # mid-size prefill: dequant + GEMM
+    assert plan(lib, [W(4096, 4096, 64, 3, HQQ)], 2048) == "gemm3 tile=256x128 matrix-waves=8 staging-waves=4 bits=3"
+    assert plan(lib, [W(4096, 11008, 128, 3, GPTQ)], 1024).endswith("bits=3")
     assert plan(lib, [W(4096, 4096, 128, 8)], 1).startswith("unsupported")
     # raw act-order descriptors (the modules use a row-sorted view instead): in-place gather in the 128x128 kernel
     assert plan(lib, [W(4096, 4096, g_idx=16)], 300) == "gemm tile=128x128 act-order-gather"

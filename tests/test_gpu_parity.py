@@ -292,6 +292,39 @@ def test_three_bit_packed_zero_points_decode_kernel(g, K, N, compat):
     assert plan.startswith("strip"), plan
 
 
+@pytest.mark.parametrize("layout,g,K,N,zk,compat", [("HQQ", 64, 4096, 4096, "f16", 0), ("GPTQ", 128, 4096, 11008, "asym", 0),
+                                                    ("GPTQ", 128, 11008, 4096, "asym", 1), ("GPTQ", 32, 1024, 256, "sym", 0)])
+def test_three_bit_prefill_kernel(layout, g, K, N, zk, compat):
+    """3-bit row-stream layers at prefill sizes: the wave-specialised GEMM with 3-bit staging waves (fp16, symmetric and packed --
+    possibly word-straddling -- zero points), W reproduced with the reference's three roundings; M below the kernel's range
+    still takes dequant + GEMM."""
+    from qllm_amd import ops
+    d = synth(layout, 3, g, K, N, "sym" if zk == "sym" else "asym", False, True, seed=K + N + g + 3)
+    d["compat"] = compat
+    if zk == "sym":
+        d_launch = dict(d, qzeros=None)
+    else:
+        d_launch = d
+    qw, sc = (torch.from_numpy(np.ascontiguousarray(d[k])).to(DEV) for k in ("qweight", "scales"))
+    qz = None if zk == "sym" else torch.from_numpy(np.ascontiguousarray(d["qzeros"])).to(DEV)
+    b = torch.from_numpy(d["bias"]).to(DEV)
+    wd, keep = ops.make_weight(layout, qw, sc, qz, None, b, K, N, g, 3, compat)
+    assert ops.plan_describe([wd], 2048).endswith("bits=3") and ops.plan_describe([wd], 300).startswith("unsupported")
+    ref_d = d if zk != "sym" else dict(d, qzeros=O.pack_along_cols(np.full((K // g, N), 4, np.int32), 3))
+    ref = Ref(ref_d)   # (fp32-carried CPU matmul: the half GEMM of the host is impractically slow at these sizes)
+    for m in (1024, 2048 + 77):
+        x = randx(m, K, seed=m)
+        y = ops.linear_forward(wd, torch.from_numpy(x).to(DEV)).cpu().numpy()
+        assert y.shape == (m, N) and np.isfinite(y).all()
+        assert O.rel_err(y, ref.y16(x)) <= TOL, (layout, K, N, m)
+        assert O.rel_err(y, ref.y64(x)) <= 2e-3, (layout, K, N, m)
+    # ... and through the module (HQQ mixed-bit models, BASELINE configs[3])
+    if layout == "HQQ":
+        layer = to_layer(d, DEV)
+        x = randx(1500, K, seed=9)
+        assert O.rel_err(layer(torch.from_numpy(x).to(DEV)).cpu().numpy(), ref.y16(x)) <= TOL
+
+
 def test_odd_bits_route_through_dequant_kernel():
     for layout, bits, g in (("HQQ", 3, 64), ("GPTQ", 3, 128), ("GPTQ", 8, 128), ("HQQ", 2, 64)):
         d = synth(layout, bits, g, 4096, 1024, seed=bits)
