@@ -382,7 +382,7 @@ def main():
     avg_launch_us = ev_ms * 1e3 / (args.steps * launches)
     achieved = (bpt / launches) / (avg_launch_us * 1e-6) / 1e9
 
-    traffic, traffic_source = None, "skipped (--no-pmc)"
+    traffic, traffic_source = None, "skipped (--no-pmc / --no-extra / multi-GPU run: rank 0 of a 1-GPU run collects it)"
     if rank == 0 and world == 1 and not args.no_pmc and not args.no_extra:
         del graph
         traffic, traffic_source = pmc_traffic(args)
