@@ -108,3 +108,65 @@ def test_plan_describe_validates(lib):
     assert lib.qllm_plan_describe(arr, 1, 1, 1, buf, 256) == _lib.QLLM_ERR_INVALID and "bits" in _lib.last_error()
     assert lib.qllm_plan_describe(arr, 0, 1, 1, buf, 256) == _lib.QLLM_ERR_INVALID
     assert lib.qllm_plan_describe(None, 1, 1, 1, buf, 256) == _lib.QLLM_ERR_INVALID
+
+
+# ---- round 2 entry points that are pure host code: checked without a GPU ------------------------------------------------
+def chain_plan(lib, ws, m):
+    arr = (_lib.QllmWeight * len(ws))(*ws)
+    buf = C.create_string_buffer(256)
+    assert lib.qllm_chain_plan_describe(arr, len(ws), m, buf, 256) == 0, _lib.last_error()
+    return buf.value.decode()
+
+
+def test_chained_link_plans(lib):
+    """The co-residency rule of the decode chain: a chained link has 120..448 blocks of at most half a CU."""
+    attn, up, down = W(4096, 4096), W(4096, 11008), W(11008, 4096)
+    for ws in ([attn] * 3, [attn], [up] * 2, [down]):
+        d = chain_plan(lib, ws, 1)
+        assert d.startswith("chained strip"), d
+        blocks = int(d.rsplit("blocks=", 1)[1])
+        assert 120 <= blocks <= 448, d
+    assert chain_plan(lib, [attn] * 3, 1).startswith("chained strip nw=8 cpl=4")
+    assert chain_plan(lib, [down], 1).startswith("chained strip nw=8 cpl=1")       # 16 waves would need > 64 registers
+    assert chain_plan(lib, [W(4096, 1024)], 1) == "not chainable"                  # 64 strips: too few blocks for a link
+    assert chain_plan(lib, [attn], 8) == "not chainable"                           # chained links are for M <= 4
+    assert chain_plan(lib, [W(4096, 4096, layout=AWQ)], 1) == "not chainable"      # row-stream layouts only
+    assert chain_plan(lib, [W(4096, 4096, 64, 3, HQQ)], 1) == "not chainable"      # 4 bits only
+
+
+def test_engine_link_init_validates_and_fills(lib):
+    link = _lib.QllmEngineLink()
+    w = W(4096, 11008)
+    assert lib.qllm_engine_link_init(C.byref(w), 32, 64, 1, _lib.DT_F16, 1, 40, C.byref(link)) == 0, _lib.last_error()
+    assert (link.N, link.K, link.n_strips, link.strip0, link.slabs, link.x_poll) == (11008, 4096, 344, 40, 4, 1)
+    w = W(11008, 4096)
+    assert lib.qllm_engine_link_init(C.byref(w), 32, 64, 1, _lib.DT_F16, 0, 0, C.byref(link)) == 0
+    assert (link.n_strips, link.slabs, link.x_poll) == (128, 11, 0)                 # the last slab is only partly filled
+    U = _lib.QLLM_ERR_UNSUPPORTED
+    for bad, m, dt in ((W(4096, 4096), 2, _lib.DT_F16),                             # M = 1 only
+                       (W(4096, 4096), 1, _lib.DT_BF16),                            # fp16 activations
+                       (W(4096, 4096, 64), 1, _lib.DT_F16),                         # group size 128
+                       (W(4096, 4096, layout=AWQ), 1, _lib.DT_F16),                 # row-stream layouts
+                       (W(4096, 4096, g_idx=16), 1, _lib.DT_F16),                   # no act-order
+                       (W(4096, 4112), 1, _lib.DT_F16),                             # N % 32
+                       (W(28672, 8192), 1, _lib.DT_F16),                            # K beyond the LDS input buffers
+                       (W(4096, 4096, 128, 3, HQQ), 1, _lib.DT_F16)):               # 4 bits
+        assert lib.qllm_engine_link_init(C.byref(bad), 32, 64, m, dt, 0, 0, C.byref(link)) == U, (bad.K, bad.N, m)
+    assert lib.qllm_engine_link_init(C.byref(W(4096, 4096)), 32, 66, 1, _lib.DT_F16, 0, 0, C.byref(link)) == _lib.QLLM_ERR_INVALID  # y % 4
+    assert lib.qllm_engine_link_init(C.byref(W(4096, 4096)), 32, 64, 1, _lib.DT_F16, 0, 0, None) == _lib.QLLM_ERR_INVALID
+    assert lib.qllm_engine_run(None, 1, 64, None) == _lib.QLLM_ERR_INVALID
+    assert lib.qllm_engine_run(64, 0, 64, None) == _lib.QLLM_ERR_INVALID
+    assert lib.qllm_engine_run(64, 1, 66, None) == _lib.QLLM_ERR_INVALID            # error word alignment
+
+
+def test_gather_columns_argument_checks(lib):
+    I, U = _lib.QLLM_ERR_INVALID, _lib.QLLM_ERR_UNSUPPORTED
+    g = lib.qllm_gather_columns
+    assert g(None, 64, 128, 4, 4096, _lib.DT_F16, None) == I
+    assert g(64, 64, 64, 4, 4096, _lib.DT_F16, None) == I and "alias" in _lib.last_error()
+    assert g(64, 64, 136, 4, 4096, _lib.DT_F16, None) == I                           # 16-byte alignment
+    assert g(64, 128, 256, 4, 4096, 7, None) == I                                    # element type
+    assert g(64, 128, 256, -1, 4096, _lib.DT_F16, None) == I
+    assert g(64, 128, 256, 4, 4100, _lib.DT_F16, None) == U                          # K % 8
+    assert g(64, 128, 256, 4, 32768, _lib.DT_BF16, None) == U                        # K beyond the LDS row buffers
+    assert g(64, 128, 256, 0, 4096, _lib.DT_F16, None) == 0                          # empty batch: nothing launched
