@@ -487,6 +487,20 @@ int qllm_chain_plan_describe(const qllm_weight_t *w, int32_t n_weights, int32_t 
   return QLLM_OK;
 }
 
+// gemm3 over K-split blocks when the 256x128 tiling leaves CUs idle and the caller's workspace can hold the partial tiles.
+// true: p.split_k / slabs / counters are set (split_k > 1); false: p untouched (callers then run unsplit or pick gemm2)
+static bool gemm3_use_split(GemmParams &p, void *workspace, size_t workspace_bytes) {
+  const int S = gemm3_split_k(p.M, p.N, p.K);
+  if (S <= 1) return false;
+  const size_t need = kCounterBytes + gemm2_slab_bytes(p.M, p.N, S);
+  const int tiles = ((p.M + 255) / 256) * (p.N / 128);
+  if (!workspace || workspace_bytes < need || (uintptr_t)workspace % 256 != 0 || tiles > (int)(kCounterBytes / sizeof(int))) return false;
+  p.split_k = S;
+  p.counters = (int *)workspace;
+  p.slabs = (float *)((char *)workspace + kCounterBytes);
+  return true;
+}
+
 int qllm_linear_forward(const qllm_weight_t *w, const void *x, void *y, int32_t M, int32_t act_dtype, void *workspace,
                         size_t workspace_bytes, void *stream) {
   clear_error();
@@ -523,7 +537,10 @@ int qllm_linear_forward(const qllm_weight_t *w, const void *x, void *y, int32_t 
     p.act_bf16 = (act_dtype == QLLM_BF16);
     p.n_groups = (w->K + w->group_size - 1) / w->group_size;
     p.split_k = 1;
-    if (gemm3_ok(p, kGemm3Rows3Bit)) return launch_gemm3(p, kGemm3Rows3Bit, (hipStream_t)stream);
+    if (gemm3_ok(p, kGemm3Rows3Bit)) {
+      gemm3_use_split(p, workspace, workspace_bytes);
+      return launch_gemm3(p, kGemm3Rows3Bit, (hipStream_t)stream);
+    }
   }
   if (gemm_ok(*w)) {
     GemmParams p;
@@ -550,7 +567,11 @@ int qllm_linear_forward(const qllm_weight_t *w, const void *x, void *y, int32_t 
     p.counters = nullptr;
     if (gemm2_ok(p, w->layout)) {
       // large M: the wave-specialised 256x128 kernel (no split-K needed: every CU has at least one tile)
-      if (gemm3_ok(p, w->layout) && gemm2_split_k(M, w->N, w->K) == 1) return launch_gemm3(p, w->layout, (hipStream_t)stream);
+      if (gemm3_ok(p, w->layout) && (gemm2_split_k(M, w->N, w->K) == 1 || gemm3_use_split(p, workspace, workspace_bytes)))
+        return launch_gemm3(p, w->layout, (hipStream_t)stream);
+      p.split_k = 1;
+      p.slabs = nullptr;
+      p.counters = nullptr;
       // split-K when the tiling leaves CUs idle and the caller's workspace can hold the partial tiles (else: no split)
       const int S = gemm2_split_k(M, w->N, w->K);
       const size_t need = kCounterBytes + gemm2_slab_bytes(M, w->N, S);
@@ -646,7 +667,9 @@ int qllm_plan_describe(const qllm_weight_t *w, int32_t n_weights, int32_t M, int
     p.group_size = w[0].group_size;
     p.gs_shift = ((w[0].group_size & (w[0].group_size - 1)) == 0) ? __builtin_ctz((unsigned)w[0].group_size) : -1;
     if (gemm3_ok(p, kGemm3Rows3Bit)) {
-      snprintf(buf, buflen, "gemm3 tile=256x128 matrix-waves=8 staging-waves=4 bits=3");
+      const int S = have_workspace ? gemm3_split_k(M, w[0].N, w[0].K) : 1;
+      if (S > 1) snprintf(buf, buflen, "gemm3 tile=256x128 matrix-waves=8 staging-waves=4 bits=3 split_k=%d", S);
+      else snprintf(buf, buflen, "gemm3 tile=256x128 matrix-waves=8 staging-waves=4 bits=3");
       return QLLM_OK;
     }
   }
@@ -659,8 +682,10 @@ int qllm_plan_describe(const qllm_weight_t *w, int32_t n_weights, int32_t M, int
     p.N = w[0].N;
     p.group_size = w[0].group_size;
     p.gs_shift = ((w[0].group_size & (w[0].group_size - 1)) == 0) ? __builtin_ctz((unsigned)w[0].group_size) : -1;
-    if (gemm2_ok(p, w[0].layout) && gemm3_ok(p, w[0].layout) && gemm2_split_k(M, w[0].N, w[0].K) == 1) {
-      snprintf(buf, buflen, "gemm3 tile=256x128 matrix-waves=8 staging-waves=4");
+    const int S2 = gemm2_split_k(M, w[0].N, w[0].K), S3 = gemm3_split_k(M, w[0].N, w[0].K);
+    if (gemm2_ok(p, w[0].layout) && gemm3_ok(p, w[0].layout) && (S2 == 1 || (have_workspace && S3 > 1))) {
+      if (S2 > 1) snprintf(buf, buflen, "gemm3 tile=256x128 matrix-waves=8 staging-waves=4 split_k=%d", S3);
+      else snprintf(buf, buflen, "gemm3 tile=256x128 matrix-waves=8 staging-waves=4");
     } else if (gemm2_ok(p, w[0].layout)) {
       const int S = have_workspace ? gemm2_split_k(M, w[0].N, w[0].K) : 1;
       snprintf(buf, buflen, "gemm2 tile=256x%d split_k=%d", gemm2_tile_n(M, w[0].N, S), S);

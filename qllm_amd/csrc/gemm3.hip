@@ -66,17 +66,24 @@ __global__ __launch_bounds__((MW + 4) * 64) void gemm3_kernel(const GemmParams p
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = p.N / BN;
-  const int nblk = tiles_m * tiles_n;
+  // split-K (p.split_k > 1: fewer tiles than CUs): S consecutive block ids share an output tile and own consecutive K ranges;
+  // each publishes its fp32 partial tile to a slab, the last to arrive sums them in fixed order (the protocol of gemm2.hip)
+  const int S = p.split_k;
+  const int nblk = tiles_m * tiles_n * S;
   int bid = blockIdx.x;
   {  // each XCD (block id % 8) walks a contiguous run of tiles
     const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, idx = bid / 8;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
+  const int ksplit = bid % S;
+  bid /= S;
+  const int tile_id = bid;
   // p.raster 1: n fastest (an XCD's run shares activation rows, which stay in its L2 while the small packed weights stream)
   const int tm = p.raster ? (bid / tiles_n) : (bid % tiles_m);
   const int tn = p.raster ? (bid % tiles_n) : (bid / tiles_m);
   const int m0 = tm * BM, n0 = tn * BN;
-  const int KT = p.K / BK;
+  const int KT = p.K / BK / S;   // this block's k-tiles (even: launch_gemm3 only splits when K / 64 is a multiple of 2 S)
+  const int KT0 = ksplit * KT;  // ... starting at this one
 
   if (wave >= MW) {
     // ================================================= dequant waves ==================================================
@@ -114,7 +121,7 @@ __global__ __launch_bounds__((MW + 4) * 64) void gemm3_kernel(const GemmParams p
     const int voff_s = nB * 2, voff_z = zoff * 4;
     const int krow0 = ROWS ? 8 * brow : brow;                               // this thread's first k inside a k-tile
     auto load_b = [&](int kt, BSet &bs) {
-      const int ktc = min(kt, KT - 1);
+      const int ktc = KT0 + min(kt, KT - 1);
       const int so = ktc * ktile_bytes;
 #pragma unroll
       for (int r = 0; r < WPT; ++r) bs.w[r] = __builtin_amdgcn_raw_buffer_load_b32(rs_w, voff_w + r * wrow_bytes, so, 0);
@@ -196,6 +203,10 @@ __global__ __launch_bounds__((MW + 4) * 64) void gemm3_kernel(const GemmParams p
       __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();  // matches the matrix waves' barrier in front of their epilogue
+    if (S > 1) {          // ... and the two around the split-K ticket
+      __syncthreads();
+      __syncthreads();
+    }
     return;
   }
 
@@ -234,7 +245,7 @@ __global__ __launch_bounds__((MW + 4) * 64) void gemm3_kernel(const GemmParams p
   //  hipcc silently fails to instantiate the whole kernel -- no diagnostic, just an undefined __device_stub__ at load time)
   const int rows_per_wave = 8 * NP;
   auto dma_piece = [&](int kt, int slot, int q) {
-    const int so = min(kt, KT - 1) * (BK * 2);
+    const int so = (KT0 + min(kt, KT - 1)) * (BK * 2);
     const int vo = voff_x[q];
     lds_void_t *dst = (lds_void_t *)(As + slot * kATile + (wave * rows_per_wave + q * 8) * BK);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, dst, 16, vo, so, 0, 0);
@@ -313,6 +324,42 @@ __global__ __launch_bounds__((MW + 4) * 64) void gemm3_kernel(const GemmParams p
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // stray DMA pieces past the last tile: land before the LDS is reused
   __builtin_amdgcn_s_barrier();                                // (matched by the dequant waves' final barrier)
 
+  // ---- split-K: publish the fp32 partial tile; the last block to arrive sums the S partials in fixed order (deterministic).
+  // Write-through (sc1) stores, every storing wave drains them, one relaxed agent-scope ticket per block, the last arriver reads
+  // with sc1 loads and re-arms the counter.  Slab element (tile, split, wave, register, lane): 256 contiguous bytes per instruction.
+  if (S > 1) {
+    int &s_ticket = *(int *)(smem + 24 * 1024);  // past the epilogue's wave-private regions (8 x 4.5 KB)
+    constexpr int WREGS = AM * 2 * 16;
+    float *slab = p.slabs + ((size_t)tile_id * S + ksplit) * (size_t)(BM * BN) + (size_t)wave * (WREGS * 64) + lane;
+#pragma unroll
+    for (int a = 0; a < AM; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st_sc1(slab + ((a * 2 + b) * 16 + r) * 64, acc[a][b][r]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) s_ticket = __hip_atomic_fetch_add(p.counters + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_ticket != S - 1) return;
+#pragma unroll
+    for (int a = 0; a < AM; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    for (int sp = 0; sp < S; ++sp) {
+      const float *src = p.slabs + ((size_t)tile_id * S + sp) * (size_t)(BM * BN) + (size_t)wave * (WREGS * 64) + lane;
+#pragma unroll
+      for (int a = 0; a < AM; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[a][b][r] += ld_sc1(src + ((a * 2 + b) * 16 + r) * 64);
+    }
+    if (tid == 0) __hip_atomic_store(p.counters + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+
   // ---- epilogue: + bias, round once, transpose through wave-private LDS, 16-byte row-contiguous stores ---------------------
   // C/D layout of 32x32 tiles: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).  (All fragment reads that
   // matter completed before the last barrier; the stray ones above only fill registers.)
@@ -342,10 +389,13 @@ __global__ __launch_bounds__((MW + 4) * 64) void gemm3_kernel(const GemmParams p
 }
 
 bool gemm3_ok(const GemmParams &p, int layout) {
-  (void)layout;
   static const int on = getenv("QLLM_GEMM3") ? atoi(getenv("QLLM_GEMM3")) : 1;
+  // 4 bits: from M = 1024 (below it gemm2's split-K form was the measured choice; QLLM_GEMM3_MIN_M moves the line);
+  // 3 bits: every prefill size -- the alternative there is the dequant kernel + a dense GEMM
   static const int min_m = getenv("QLLM_GEMM3_MIN_M") ? atoi(getenv("QLLM_GEMM3_MIN_M")) : 1024;
-  if (!on || p.g_idx || p.K % 128 != 0 || p.N % 128 != 0 || p.M < min_m) return false;  // K % 128: an even number of k-tiles
+  static const int min_m3 = getenv("QLLM_GEMM3_MIN_M_3BIT") ? atoi(getenv("QLLM_GEMM3_MIN_M_3BIT")) : 65;
+  if (!on || p.g_idx || p.K % 128 != 0 || p.N % 128 != 0) return false;  // K % 128: an even number of k-tiles
+  if (p.M < (layout == kGemm3Rows3Bit ? min_m3 : min_m)) return false;
   // fp16 activations only: the activation tile goes to LDS by DMA, which cannot convert bf16 on the way (gemm2 does);
   // 32-bit byte offsets into x and the packed weights
   if (p.act_bf16 || (size_t)p.M * p.K * 2 >= 0x7fffffffull || (size_t)p.K * p.N / 2 >= 0x7fffffffull) return false;
@@ -357,15 +407,24 @@ static int launch_gemm3_b(const GemmParams &p, hipStream_t stream) {
   using namespace g3;
   static DeviceLatch attr_done;
   if (int rc = lds_optin(attr_done, (const void *)gemm3_kernel<LAYOUT, MW, PRIO>)) return rc;
-  const int tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
+  const int tiles = ((p.M + BM - 1) / BM) * (p.N / BN) * p.split_k;
   const size_t lds = (size_t)(3 * kATile + 2 * kBTile) * sizeof(half_t);  // 128 KB
   hipLaunchKernelGGL((gemm3_kernel<LAYOUT, MW, PRIO>), dim3(tiles), dim3((MW + 4) * 64), lds, stream, p);
   QLLM_HIP_CHECK(hipGetLastError());
   return QLLM_OK;
 }
 
+// split-K factor for gemm3: gemm2's rule (largest S <= 8 with tiles * S <= CUs and >= 8 k-tiles per block), kept only when every
+// block then owns an EVEN number of k-tiles (the staging loop runs two per trip); 1 otherwise
+int gemm3_split_k(int M, int N, int K) {
+  int s = gemm2_split_k(M, N, K);
+  while (s > 1 && (K / 64) % (2 * s) != 0) s /= 2;
+  return s;
+}
+
 int launch_gemm3(const GemmParams &p_in, int layout, hipStream_t stream) {
   GemmParams p = p_in;
+  if (p.split_k < 1 || !p.slabs || !p.counters) p.split_k = 1;
   static int raster = getenv("QLLM_GEMM2_RASTER") ? atoi(getenv("QLLM_GEMM2_RASTER")) : 1;
   p.raster = raster;
   static int mw = getenv("QLLM_GEMM3_MW") ? atoi(getenv("QLLM_GEMM3_MW")) : 8;  // measured (profiles/r02_prefill_summary.md): 8 matrix waves 908 / 923 / 1004 TFLOP/s, 4: 873 / 915 / 1003

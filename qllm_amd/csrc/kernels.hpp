@@ -146,6 +146,7 @@ int launch_gemm2(const GemmParams &p, int layout, hipStream_t stream);
 // ---- gemm3.hip (256x128 tile, 4 matrix waves + 4 staging waves; no split-K) ---------------------------------------------
 constexpr int kGemm3Rows3Bit = 100;  // `layout` value for launch_gemm3 / gemm3_ok: GPTQ / HQQ row stream with 3-bit weights
 bool gemm3_ok(const GemmParams &p, int layout);
+int gemm3_split_k(int M, int N, int K);
 int launch_gemm3(const GemmParams &p, int layout, hipStream_t stream);
 
 }  // namespace qllm

@@ -309,10 +309,10 @@ def test_three_bit_prefill_kernel(layout, g, K, N, zk, compat):
     qz = None if zk == "sym" else torch.from_numpy(np.ascontiguousarray(d["qzeros"])).to(DEV)
     b = torch.from_numpy(d["bias"]).to(DEV)
     wd, keep = ops.make_weight(layout, qw, sc, qz, None, b, K, N, g, 3, compat)
-    assert ops.plan_describe([wd], 2048).endswith("bits=3") and ops.plan_describe([wd], 300).startswith("unsupported")
+    assert "bits=3" in ops.plan_describe([wd], 2048) and "bits=3" in ops.plan_describe([wd], 300)
     ref_d = d if zk != "sym" else dict(d, qzeros=O.pack_along_cols(np.full((K // g, N), 4, np.int32), 3))
     ref = Ref(ref_d)   # (fp32-carried CPU matmul: the half GEMM of the host is impractically slow at these sizes)
-    for m in (1024, 2048 + 77):
+    for m in (65, 300, 1024, 2048 + 77):   # 65 / 300: few tiles -> blocks split K and meet in the workspace
         x = randx(m, K, seed=m)
         y = ops.linear_forward(wd, torch.from_numpy(x).to(DEV)).cpu().numpy()
         assert y.shape == (m, N) and np.isfinite(y).all()
