@@ -113,7 +113,7 @@ int qllm_workspace_init(void *workspace, size_t bytes, void *stream);
  * converted on load, replacing the reference's bf16->f16 shims, ort_ops.cc:119-138, quant_linear_awq.py:29-36).
  * Dispatch: M <= 64 -> weight-streaming MFMA matvec (HBM-bound); larger M -> LDS-tiled MFMA GEMM.
  * Fused widths: 4 bits everywhere; 3 bits (GPTQ / HQQ row stream; fp16, symmetric or packed zero points) for M <= 64 and, with
- * K % 128 == 0, N % 128 == 0 and fp16 activations, for every larger M; every other width / shape returns QLLM_ERR_UNSUPPORTED and the
+ * K % 64 == 0, N % 128 == 0 and fp16 activations, for every larger M; every other width / shape returns QLLM_ERR_UNSUPPORTED and the
  * caller takes the reference's own two-step branch (qllm_dequant + a dense GEMM, quant_linear_gptq.py:81-85).
  * Replaces QuantLinearTorchFunction.forward + bias for all three layouts. */
 int qllm_linear_forward(const qllm_weight_t *w, const void *x, void *y, int32_t M, int32_t act_dtype,

@@ -49,7 +49,7 @@ __device__ __forceinline__ int tile_off(int row, int slot) { return row * BK + (
 }  // namespace g3
 
 // LAYOUT 0 = GPTQ/HQQ row stream (4 bits), 1 = AWQ GEMM, 2 = GPTQ/HQQ row stream with 3-bit weights (bit stream: the 32 k of
-// a half k-tile are 3 consecutive word rows of the column).  fp16 activations.  Requires K % 128 == 0 (even number of k-tiles), N % 128 == 0, power-of-two group size >= 32, no g_idx.
+// a half k-tile are 3 consecutive word rows of the column).  fp16 activations.  Requires K % 64 == 0, N % 128 == 0, power-of-two group size >= 32, no g_idx.
 // MW: matrix waves, 4 (one per SIMD, 128x64 each) or 8 (two per SIMD, 64x64 each: 8 fragment reads per 8 MFMAs instead of 6,
 // but the two waves cover each other's LDS / barrier waits); always 4 dequant waves behind them.
 template <int LAYOUT, int MW, bool PRIO = true>
@@ -82,7 +82,7 @@ __global__ __launch_bounds__((MW + 4) * 64) void gemm3_kernel(const GemmParams p
   const int tm = p.raster ? (bid / tiles_n) : (bid % tiles_m);
   const int tn = p.raster ? (bid % tiles_n) : (bid / tiles_m);
   const int m0 = tm * BM, n0 = tn * BN;
-  const int KT = p.K / BK / S;   // this block's k-tiles (even: launch_gemm3 only splits when K / 64 is a multiple of 2 S)
+  const int KT = p.K / BK / S;   // this block's k-tiles (launch_gemm3 only splits when K / 64 is a multiple of S)
   const int KT0 = ksplit * KT;  // ... starting at this one
 
   if (wave >= MW) {
@@ -192,16 +192,17 @@ __global__ __launch_bounds__((MW + 4) * 64) void gemm3_kernel(const GemmParams p
     __builtin_amdgcn_sched_barrier(0);
     load_b(2, bset[0]);
     __syncthreads();  // prologue barrier: B stage 0 holds tile 0
-    for (int kt = 0; kt < KT; kt += 2) {
+    for (int kt = 0; kt + 1 < KT; kt += 2) {  // two k-tiles per trip: the register sets alternate by name, no branch between them
       store_b(1, bset[1]);
       __syncthreads();  // barrier #kt
       load_b(kt + 3, bset[1]);
       __builtin_amdgcn_sched_barrier(0);
-      store_b(0, bset[0]);  // (KT is even -- gemm3_ok -- so the two halves need no branch between them)
+      store_b(0, bset[0]);
       __syncthreads();  // barrier #kt+1
       load_b(kt + 4, bset[0]);
       __builtin_amdgcn_sched_barrier(0);
     }
+    if (KT & 1) __syncthreads();  // odd number of k-tiles: barrier #KT-1 (the tile it would publish does not exist)
     __syncthreads();  // matches the matrix waves' barrier in front of their epilogue
     if (S > 1) {          // ... and the two around the split-K ticket
       __syncthreads();
@@ -394,7 +395,7 @@ bool gemm3_ok(const GemmParams &p, int layout) {
   // 3 bits: every prefill size -- the alternative there is the dequant kernel + a dense GEMM
   static const int min_m = getenv("QLLM_GEMM3_MIN_M") ? atoi(getenv("QLLM_GEMM3_MIN_M")) : 1024;
   static const int min_m3 = getenv("QLLM_GEMM3_MIN_M_3BIT") ? atoi(getenv("QLLM_GEMM3_MIN_M_3BIT")) : 65;
-  if (!on || p.g_idx || p.K % 128 != 0 || p.N % 128 != 0) return false;  // K % 128: an even number of k-tiles
+  if (!on || p.g_idx || p.K % 64 != 0 || p.N % 128 != 0) return false;
   if (p.M < (layout == kGemm3Rows3Bit ? min_m3 : min_m)) return false;
   // fp16 activations only: the activation tile goes to LDS by DMA, which cannot convert bf16 on the way (gemm2 does);
   // 32-bit byte offsets into x and the packed weights
@@ -414,11 +415,11 @@ static int launch_gemm3_b(const GemmParams &p, hipStream_t stream) {
   return QLLM_OK;
 }
 
-// split-K factor for gemm3: gemm2's rule (largest S <= 8 with tiles * S <= CUs and >= 8 k-tiles per block), kept only when every
-// block then owns an EVEN number of k-tiles (the staging loop runs two per trip); 1 otherwise
+// split-K factor for gemm3: gemm2's rule (largest S <= 8 with tiles * S <= CUs and >= 8 k-tiles per block), reduced until every
+// block owns the same number of k-tiles
 int gemm3_split_k(int M, int N, int K) {
   int s = gemm2_split_k(M, N, K);
-  while (s > 1 && (K / 64) % (2 * s) != 0) s /= 2;
+  while (s > 1 && (K / 64) % s != 0) s /= 2;
   return s;
 }
 

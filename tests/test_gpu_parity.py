@@ -528,6 +528,8 @@ GEMM3_CASES = [
     ("HQQ", 64, 4096, 4096, "f16", False),
     ("GPTQ", 128, 1024, 1280, "sym", True),        # small: every k-tile boundary case within a few tiles
     ("GPTQ", 32, 256, 128, "asym", True),          # 4 k-tiles, a new group every half k-tile, one column tile
+    ("GPTQ", 64, 4096 + 64, 4096, "asym", True),   # 65 k-tiles: odd (the staging loop's tail barrier)
+    ("GEMM", 64, 1024 + 192, 1280, "asym", False), # 19 k-tiles, AWQ layout in place
 ]
 
 
