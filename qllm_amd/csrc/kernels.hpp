@@ -63,7 +63,7 @@ struct StripProblem {
 struct StripParams {
   // the words every wave needs first, in ONE 64-byte line at the head of the argument block (one s_load_dwordx8 instead of eight
   // loads from seven lines in two dependent batches): the first weight load leaves after 2 scalar waits instead of 6; measured
-  // +0.7 % on the whole decode step (864 -> 871 tok/s, gpurun_out/r02q_hdr.log)
+  // +0.7 % on the whole decode step (864 -> 871 tok/s, profiles/logs/r02q_hdr.log)
   int block_begin8[kMaxProblems];
   StripProblem prob[kMaxProblems];
   const void *x;
