@@ -1,0 +1,34 @@
+"""bench.py's arithmetic (no GPU): the algorithmic bytes / flops the roofline line is computed from must be the figures of
+SURVEY.md 8(d) / DESIGN.md section 4, and the command line must keep the driver's contract (defaults N=1, quick K / W)."""
+import importlib
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+bench = importlib.import_module("bench")
+
+
+def test_algorithmic_bytes_and_flops():
+    # packed words + scales + packed zeros + x + y for one w4 g128 linear at M = 1
+    assert bench.alg_bytes(4096, 4096, 1) == 4096 * 4096 // 2 + 32 * 4096 * 2 + 32 * 4096 // 2 + 2 * 4096 + 2 * 4096 == 8_732_672
+    assert bench.alg_bytes(4096, 11008, 1) == bench.alg_bytes(11008, 4096, 1) == 23_455_232
+    assert bench.bytes_per_token() == 32 * (4 * 8_732_672 + 3 * 23_455_232) == 3_369_484_288
+    assert bench.bytes_per_token() // 128 == 26_324_096                                             # roofline.bytes_per_launch
+    assert bench.flops_per_pass(4, 2048) == 4 * 2.0 * 2048 * (4 * 4096 * 4096 + 3 * 4096 * 11008)
+    # fp16 zero points (HQQ) cost 2 bytes per group and column instead of half a byte
+    assert bench.alg_bytes(4096, 4096, 16, 64, "f16") - bench.alg_bytes(4096, 4096, 16, 64) == 64 * 4096 * 2 - 64 * 4096 // 2
+    assert bench.HBM_PEAK_GBPS == 8000.0 and bench.MFMA_PEAK_TFLOPS == 2500.0                       # MI355X_MICROARCH.md peaks
+
+
+def test_command_line_contract():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    for flag in ("--gpus", "--steps", "--warmup"):
+        assert f'"{flag}"' in src
+    assert 'add_argument("--gpus", type=int, default=1)' in src
+    for key in ('"metric"', '"value"', '"unit"', '"n_gpus"', '"ms_per_step"', '"higher_is_better"', '"scaling"', '"vs_baseline"', '"dtype"',
+                '"data"', '"config"', '"roofline"', '"cpu_baseline"', '"traffic"', '"frac"', '"workload"'):
+        assert key in src, key
+    # the oracle appears in bench.py only inside the cpu_baseline leg
+    lines = [l for l in src.splitlines() if "from oracle" in l or "import oracle" in l]
+    assert len(lines) == 1 and "ref_torch" in lines[0]
