@@ -7,12 +7,12 @@ Workload (config.workload = "llama2-7b-awq-w4-g128-decode-b1"): BASELINE.json co
 linears of Llama-2-7B in the AWQ "GEMM" pack mode, w4 g128 asymmetric zeros, batch 1.  ONE STEP = one decode token
 through the whole linear stack, driven through the q_layer MODULES exactly as a loaded model drives them
 (`q_proj(h)`, `k_proj(h)`, `v_proj(h)`, `o_proj(q)`, `gate_proj(o)`, `up_proj(o)`, `down_proj(gate)` per layer; every
-launch is fed by the previous one like in the model), replayed from a hipGraph.  The modules carry the sibling groups
-the loader installs (q/k/v and gate/up -> one grouped launch each: 4 launches per layer) and the step runs inside an
-`ops.DecodeChain` (links alternate between two streams; link i+1 streams its weights while link i computes; DESIGN.md
-section 3.4).  `--chain 0` / `--fused 0` give the single-stream and the 7-launch forms.  Weights are synthetic (no
-network: random packed int4 words, random fp16 scales sized to keep activations O(1)) and RESIDENT IN HBM before the
-timed region; 3.5 GB of weights per pass means nothing is served from the 256 MB Infinity Cache.
+launch is fed by the previous one like in the model), replayed from a hipGraph on one stream.  The modules carry the sibling
+groups the loader installs (q/k/v and gate/up -> one grouped launch each: 4 launches per layer; `--fused 0` gives the 7-launch
+form) and decode from the library's native strip-major copy of their integers, built once on the device at first use
+(qllm_repack_native).  Weights are synthetic (no network: random packed int4 words, random fp16 scales
+sized to keep activations O(1)) and RESIDENT IN HBM before the timed region; 3.5 GB of weights per pass means nothing is
+served from the 256 MB Infinity Cache.
 
 value = decode tokens/s over all ranks (rank r runs an independent replica: batch elements are independent units,
 no data-path collective -> "scaling": "weak").  `--tp N` instead runs the Llama-2-70B column/row-parallel layer stack
@@ -22,11 +22,10 @@ Extra objects on the JSON line:
   roofline     dominant kernel = the decode matvec (one kernel function serves every launch of the step).
                achieved = algorithmic bytes per launch (packed weights + scales + zeros + x + y,
                3,369,484,288 B per token / launches) / average launch duration, the latter measured here with HIP events
-               on the launch stream over the K timed steps (= event time / launches: inter-kernel gaps included, and with
-               the chain the links overlap pairwise, so this is the wall-clock share of a launch, not its residency).
+               on the launch stream over the K timed steps (= event time / launches: inter-kernel gaps included).
                traffic = HBM bytes per launch from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate passes,
-               FETCH doubled per MI355X_MICROARCH.md) that THIS run spawns on itself (`--pmc-child`, 8 layers, links
-               serialised on one stream because counter collection serialises dispatches); null if rocprofv3 is absent.
+               FETCH doubled per MI355X_MICROARCH.md) that THIS run spawns on itself (`--pmc-child`, 8 layers, the same
+               kernels); null if rocprofv3 is absent.
   cpu_baseline the reference's CPU torch formulation (oracle/ref_torch.py: shift/mask dequant + fp16 torch.matmul,
                bit-identical to the oracle) timed on this host's cores over one decoder layer (3 warm + 5 timed calls per
                shape, thread count picked by a short sweep and stated), extrapolated x32.
@@ -160,15 +159,9 @@ def time_events(fn, iters):
     return e0.elapsed_time(e1) / iters  # ms
 
 
-def decode_step_fn(stack, h0, chain):
-    """One decode token through the stack's modules; inside the chain when one is given."""
-    if chain is None:
-        return lambda: stack(h0)
-
-    def step():
-        with chain:
-            return stack(h0)
-    return step
+def decode_step_fn(stack, h0):
+    """One decode token through the stack's modules."""
+    return lambda: stack(h0)
 
 
 def cpu_baseline_leg(dev):
@@ -241,7 +234,8 @@ def hqq_leg(dev):
     x16 = torch.randn(16, HIDDEN, device=dev, dtype=torch.float16)
     for bits_sel, tag in ((4, "hqq_w4_g64_m16"), (3, "hqq_w3_g64_m16")):
         hs = Stack(QuantLinearHQQ, 4, dev, seed=7 + bits_sel, bits=bits_sel, group=64)
-        nbytes = 4 * sum(alg_bytes(K, N, 16, 64, "f16") * bits_sel // 4
+        # (only the packed words scale with the bit width: scales, fp16 zero points, x and y do not)
+        nbytes = 4 * sum(alg_bytes(K, N, 16, 64, "f16") - K * N // 2 + K * N * bits_sel // 8
                          for (K, N) in [(HIDDEN, HIDDEN)] * 4 + [(HIDDEN, INTER)] * 2 + [(INTER, HIDDEN)])
         res = {}
         for fz in (True, False):
@@ -264,10 +258,10 @@ def pmc_traffic(args):
     per = {}
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="qllm_pmc_", dir="/tmp")
-        env = dict(os.environ, TMPDIR="/tmp", QLLM_CHAIN_SERIAL="1")
+        env = dict(os.environ, TMPDIR="/tmp")
         cmd = [rocprof, "--kernel-trace", "--pmc", ctr, "-d", d, "-o", "p", "--output-format", "csv", "--",
                sys.executable, os.path.abspath(__file__), "--pmc-child", "--steps", "2", "--warmup", "1", "--no-extra",
-               "--chain", str(args.chain), "--fused", str(args.fused), "--chain-mode", args.chain_mode]
+               "--fused", str(args.fused)]
         try:
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
             f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
@@ -278,9 +272,6 @@ def pmc_traffic(args):
                 if "qllm::strip_kernel" in r["Kernel_Name"]:
                     tot += float(r["Counter_Value"])
                     n += 1
-                elif "qllm::engine_kernel" in r["Kernel_Name"]:  # one dispatch = a whole step of the child (8 layers)
-                    tot += float(r["Counter_Value"])
-                    n += 8 * (4 if args.fused else 7)
             per[ctr] = tot / max(n, 1)
         except Exception as e:  # noqa: BLE001
             shutil.rmtree(d, ignore_errors=True)
@@ -289,7 +280,7 @@ def pmc_traffic(args):
     # FETCH_SIZE / WRITE_SIZE are in KB; FETCH counts 64 B per 128-B request on gfx950 for wide coalesced reads (x2)
     return int((2.0 * per["FETCH_SIZE"] + per["WRITE_SIZE"]) * 1024), (
         "this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `bench.py --pmc-child` "
-        "(8 layers, same kernels, links serialised on one stream); bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024, averaged over "
+        "(8 layers, same kernels); bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024, averaged over "
         "the decode-kernel dispatches")
 
 
@@ -298,12 +289,6 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--chain", type=int, default=int(os.environ.get("QLLM_BENCH_CHAIN", "0")),
-                    help="1: the step runs inside ops.DecodeChain (flag-synchronised links, --chain-mode).  Default 0: since the 64-byte "
-                         "argument header the plain grouped graph is as fast (profiles/r02_chain_experiments.md); the chained and the "
-                         "engine form of the same step are reported under extra")
-    ap.add_argument("--chain-mode", default=os.environ.get("QLLM_CHAIN_MODE", "streams"), choices=["engine", "streams"],
-                    help="engine: the step's links as one persistent launch (loader wave + LDS ring); streams: one launch per link on two streams")
     ap.add_argument("--fused", type=int, default=int(os.environ.get("QLLM_BENCH_FUSED", "1")),
                     help="1: sibling groups (q/k/v and gate/up as one grouped launch each: 4 launches per layer instead of 7)")
     ap.add_argument("--tp", type=int, default=0, help="Llama-2-70B tensor-parallel leg (BASELINE configs[4]); 1 = shard shapes on one GPU")
@@ -325,7 +310,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from qllm_amd import _lib, ops
+    from qllm_amd import _lib
     from qllm_amd.modeling.q_layers import QuantLinearGPTQ, WQLinear_GEMM
 
     info = _lib.device_info(local_rank)  # raises unless gfx950 + library present: no fallback is ever benchmarked
@@ -338,14 +323,10 @@ def main():
     fused = bool(args.fused)
     stack = Stack(WQLinear_GEMM, n_layers, dev, seed=1234 + rank, fused=fused)
     h0 = torch.randn(1, HIDDEN, device=dev, dtype=torch.float16)
-    chain = ops.DecodeChain(dev, mode=args.chain_mode) if args.chain else None
-    graph, out = capture(decode_step_fn(stack, h0, chain))
+    graph, out = capture(decode_step_fn(stack, h0))
     torch.cuda.synchronize()
     assert torch.isfinite(out.float()).all(), "synthetic stack diverged"
     launches = n_layers * (4 if fused else 7)
-    if chain is not None:
-        chain.check()
-        assert chain.links == launches and chain.fallbacks == 0, (chain.links, chain.fallbacks)
     if fused:
         assert stack.groups == 2 * n_layers
 
@@ -367,8 +348,6 @@ def main():
     barrier()
     wall = time.perf_counter() - t0
     ev_ms = e0.elapsed_time(e1)
-    if chain is not None:
-        chain.check()  # no link timed out during the timed region
     if world > 1:
         t = torch.tensor([wall, ev_ms], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -395,11 +374,10 @@ def main():
         "config": {"workload": "llama2-7b-awq-w4-g128-decode-b1", "pack_mode": "GEMM", "bits": 4, "group_size": GROUP,
                    "layers": LAYERS, "linears_per_layer": 7, "batch": 1, "launches_per_step": launches,
                    "driven_through": "q_layer modules (sibling groups installed by the loader)", "grouped_qkv_gateup": fused,
-                   "decode_chain": (args.chain_mode if args.chain else False), "graph": True, "parallelism": f"replicas x{world}",
+                   "weight_layout": "native strip-major copy built on device at first use (qllm_repack_native)" if os.environ.get("QLLM_NATIVE_LAYOUT", "1") != "0" else "reference buffers in place",
+                   "graph": True, "parallelism": f"replicas x{world}",
                    "device": info["arch"], "compute_units": info["compute_units"]},
-        "roofline": {"bound": "hbm", "kernel": ("qllm::engine_kernel (persistent decode engine: the step's %d links in one launch)" % launches
-                                                 if (args.chain and args.chain_mode == "engine") else
-                                                 "qllm::strip_kernel (decode matvec; serves every launch of the step)"),
+        "roofline": {"bound": "hbm", "kernel": "qllm::strip_kernel (decode matvec; serves every launch of the step)",
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_source,
                      "bytes_per_launch": bpt // launches, "avg_launch_us": round(avg_launch_us, 3)},
@@ -416,28 +394,27 @@ def main():
             g, _ = capture(lambda: [l(x) for l in ls])
             ms = time_events(g.replay, 20) / len(ls)
             extra[f"decode_{name}"] = {"us": round(ms * 1e3, 2), "GBps": round(alg_bytes(K, N, 1) / ms / 1e6, 1)}
-        # the other launch forms of the same step (all through the modules)
-        other_mode = "streams" if args.chain_mode == "engine" else "engine"
-        for tag, fz, ch in (("fused_single_stream", True, None), ("ungrouped_single_stream", False, None),
-                            ("fused_chain_" + other_mode, True, ops.DecodeChain(dev, mode=other_mode)),
-                            ("fused_chain_" + args.chain_mode, True, chain if chain is not None else ops.DecodeChain(dev, mode=args.chain_mode))):
-            if fz == fused and ch is chain and chain is not None:
-                continue  # the headline form
-            if ch is None and not args.chain and fz == fused:
-                continue
+        # the other launch forms of the same step (all through the modules): 7 launches per layer; the reference buffers in place
+        for tag, fz, native in (("ungrouped", False, True), ("fused_reference_layout_in_place", True, False)):
             stack.set_fused(fz)
+            old = os.environ.get("QLLM_NATIVE_LAYOUT")
+            if not native:
+                os.environ["QLLM_NATIVE_LAYOUT"] = "0"
             try:
-                gg, _ = capture(decode_step_fn(stack, h0, ch))
+                gg, _ = capture(decode_step_fn(stack, h0))
                 ms = time_events(gg.replay, 20)
                 del gg
-                if ch is not None:
-                    ch.check()  # a link that timed out waiting for its input invalidates the number
+                extra["decode_stack_" + tag] = {"ms_per_token": round(ms, 4), "tokens_per_s": round(1e3 / ms, 1),
+                                                "GBps": round(bpt / ms / 1e6, 1), "frac_of_hbm_peak": round(bpt / ms / 1e6 / HBM_PEAK_GBPS, 4)}
             except Exception as e:  # noqa: BLE001  (a side leg must not take the headline down with it)
                 extra["decode_stack_" + tag] = {"error": f"{type(e).__name__}: {e}"}
                 torch.cuda.synchronize()
-                continue
-            extra["decode_stack_" + tag] = {"ms_per_token": round(ms, 4), "tokens_per_s": round(1e3 / ms, 1),
-                                            "GBps": round(bpt / ms / 1e6, 1), "frac_of_hbm_peak": round(bpt / ms / 1e6 / HBM_PEAK_GBPS, 4)}
+            finally:
+                if not native:
+                    if old is None:
+                        del os.environ["QLLM_NATIVE_LAYOUT"]
+                    else:
+                        os.environ["QLLM_NATIVE_LAYOUT"] = old
         stack.set_fused(fused)
         del stack
         torch.cuda.empty_cache()

@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define QLLM_ABI_VERSION 2
+#define QLLM_ABI_VERSION 3
 
 typedef enum qllm_status {
   QLLM_OK = 0,
@@ -62,7 +62,11 @@ typedef enum qllm_status {
 typedef enum qllm_layout {
   QLLM_LAYOUT_GPTQ = 0,     /* QuantLinearGPTQ   quant_linear_gptq.py:92-117 */
   QLLM_LAYOUT_AWQ_GEMM = 1, /* WQLinear_GEMM     quant_linear_awq.py:38-68   */
-  QLLM_LAYOUT_HQQ = 2       /* QuantLinearHQQ    quant_linear_hqq.py:47-68   */
+  QLLM_LAYOUT_HQQ = 2,      /* QuantLinearHQQ    quant_linear_hqq.py:47-68   */
+  /* the library's own strip-major layout (no reference counterpart; see "native layout" below): built once at load time
+   * from any of the three layouts above with qllm_repack_native(), converted back bit-exactly with qllm_unpack_native() */
+  QLLM_LAYOUT_NATIVE = 3,      /* packed integer (or no) zero points: from GPTQ / AWQ_GEMM */
+  QLLM_LAYOUT_NATIVE_F16Z = 4  /* fp16 zero points: from HQQ */
 } qllm_layout_t;
 
 typedef enum qllm_dtype {
@@ -126,51 +130,10 @@ int qllm_linear_forward_grouped(const qllm_weight_t *w, void *const *y, int32_t 
                                 int32_t M, int32_t act_dtype, void *workspace, size_t workspace_bytes,
                                 void *stream);
 
-/* Chained decode link (no reference counterpart).  Same arithmetic as qllm_linear_forward_grouped at
- * M <= 4 on row-stream layouts, but the launch is one link of a chain whose links the caller issues ALTERNATELY on two
- * streams: link i+1 is then resident and has its weight loads in flight while link i still computes, and the small activation
- * vector is handed over in-band:
- *   QLLM_CHAIN_PUBLISH_Y  y[i] are written write-through; the caller must have filled them with 0xFF bytes (every half = 0xFFFF,
- *                         "not written yet") before the link's CONSUMER can start -- e.g. one memset of the activation arena at
- *                         the head of every decode step; a result that is exactly 0xFFFF is stored as another NaN pattern;
- *   QLLM_CHAIN_POLL_X     x is such a buffer, produced by a link on the OTHER stream (or earlier on this one): every wave
- *                         re-reads its slice of x until no 0xFFFF half is left, then computes.
- * Deadlock rule, enforced here: a link's blocks are at most half a CU and its grid <= 448 blocks, so two adjacent links are
- * always co-resident; at most two streams may carry links of one chain.  Every poll loop is bounded (~10 ms): on expiry the
- * kernel raises bit 0 of *err_word (device memory, zeroed by the caller) and finishes with whatever x held.
- * QLLM_ERR_UNSUPPORTED when the shape has no chained plan (run it as an ordinary launch ordered after both streams). */
-#define QLLM_CHAIN_POLL_X 1
-#define QLLM_CHAIN_PUBLISH_Y 2
-int qllm_linear_forward_chained(const qllm_weight_t *w, void *const *y, int32_t n_weights, const void *x, int32_t M,
-                                int32_t act_dtype, int32_t chain_flags, void *err_word, void *stream);
-/* Text description of the chained plan ("chained strip nw=.. cpl=.. spw=.. round=.. blocks=..") or "not chainable"; pure host. */
-int qllm_chain_plan_describe(const qllm_weight_t *w, int32_t n_weights, int32_t M, char *buf, size_t buflen);
-
-/* Persistent decode engine (no reference counterpart): a whole chain of batch-1 linears -- every
- * launch of a decode step -- as ONE launch.  Per CU one resident workgroup: a loader wave streams the packed weights of the
- * block's share of every link through an LDS ring without ever waiting for an activation; eight consumer waves take each slab
- * from the ring, wait (in-band 0xFFFF hand-off, as for qllm_linear_forward_chained) only for the activation slice they need,
- * and publish finished outputs write-through.
- *   qllm_engine_link_init   host only: validates one layer of the chain and fills its record.  x / y: the layer's input and
- *                           output (1 row); x_poll != 0: x is the output of an EARLIER link of the same program (its buffer
- *                           must be 0xFF-filled before the run); strip0: running sum of N/32 over the preceding links (deals
- *                           the 32-column strips to the workgroups round-robin).  QLLM_ERR_UNSUPPORTED unless M = 1, fp16
- *                           activations, 4 bits, group size 128, row-stream layout (GPTQ / HQQ), N % 32 == 0, K % 128 == 0.
- *   qllm_engine_run         launches the program: `links_device` = the records, in chain order, in DEVICE memory.  Links may
- *                           only read outputs of links before them.  Bounded spins: bit 0 of *err_word = an activation never
- *                           arrived, bits 1-2 = internal ring hand-off timed out. */
-typedef struct qllm_engine_link {
-  const void *qweight, *scales, *qzeros, *bias, *x;
-  void *y;
-  int32_t N, K, n_strips, strip0, slabs, zero_kind, add_zero_bias, x_poll;
-} qllm_engine_link_t;
-int qllm_engine_link_init(const qllm_weight_t *w, const void *x, void *y, int32_t M, int32_t act_dtype, int32_t x_poll,
-                          int32_t strip0, qllm_engine_link_t *out);
-int qllm_engine_run(const qllm_engine_link_t *links_device, int32_t n_links, void *err_word, void *stream);
-
-/* Diagnostics (process-global, not thread-safe; NULL switches it off): the next chained launches each take one 64-byte slot
- * of `buf` (device memory, n_slots x 8 x u64, in launch order) and record 100 MHz device timestamps of their first and last
- * block: [entry, weight loads issued, input complete, exit] x 2.  A launch captured into a hipGraph keeps its slot. */
+/* Diagnostics (process-global, not thread-safe; NULL switches it off): the next native-layout decode launches (lds-slab form,
+ * 4 bits, g128) each take one 192-byte slot of `buf` (device memory, n_slots x 24 x u64, in launch order) and record 100 MHz
+ * device timestamps of wave 0 of their first, middle and last block: [entry, loads issued, x staged, rounds done, after the
+ * block barrier, exit, -, -] x 3.  A launch captured into a hipGraph keeps its slot.  tools/lab/cbench.cpp --timeline. */
 int qllm_debug_timeline(void *buf, int32_t n_slots);
 
 /* W[K,N] (out_transposed = 0) or W[N,K] (out_transposed = 1) in `out_dtype`, bit-identical to
@@ -217,6 +180,27 @@ int qllm_awq_gemm_forward(const void *x, const void *qweight, const void *scales
  * GPU.  No reference counterpart. */
 int qllm_plan_describe(const qllm_weight_t *w, int32_t n_weights, int32_t M, int32_t have_workspace, char *buf,
                        size_t buflen);
+
+/* ---- native layout ------------------------------------------------------------------------------------------ */
+/* The reference's layouts are shaped for ITS kernels: GPTQ / HQQ store [K*bits/32][N] words (a 16-column strip of a layer is
+ * K/8 separate 64-byte segments), AWQ stores [K][N/8] words (a row is N/2 bytes).  A batch-1 matvec on MI355X is fastest when
+ * every workgroup streams ONE contiguous region (tools/lab/memlab2.hip: one Llama-2-7B decoder layer's four launches read
+ * 25.96 us in the row-stream forms, 21.45 us strip-major), so the library has a layout of its own, built once at load time:
+ *     qweight i32 [N/16][K*bits/32][16]   word (s, r, i) = GPTQ word (r, 16 s + i)
+ *     scales  f16 [N/16][G][16]           G = K / group_size
+ *     qzeros  NATIVE:      i32 [N/16][G][2]  4 bits: nibble e of word j = stored zero point of column 16 s + 8 j + e;
+ *                                            3 bits: column 16 s + i at bit 3 i of the 64-bit little-endian pair;  or NULL
+ *             NATIVE_F16Z: f16 [N/16][G][16]
+ *     bias f16 [N] (natural order); g_idx must be NULL (act-order layers: sort the rows by group first, qllm_gather_columns)
+ * Shapes: bits 3 or 4, K % 32 == 0, N % 16 == 0 (3-bit packed zero points: N % 32 == 0), group_size % 32 == 0, K % group_size == 0.
+ * A descriptor with layout = QLLM_LAYOUT_NATIVE[_F16Z] is accepted by qllm_linear_forward / _grouped (M <= 64 with group size
+ * 64 / 128; larger M: see qllm_plan_describe) and by qllm_dequant.  Pure integer permutations: repack then unpack is the
+ * identity.  Counterpart in the reference: the load-time repacks of its own kernel formats (quant_linear_awq.py:95-140). */
+int qllm_native_sizes(const qllm_weight_t *src, size_t *qweight_bytes, size_t *scales_bytes, size_t *qzeros_bytes);
+int qllm_repack_native(const qllm_weight_t *src, void *qweight_out, void *scales_out, void *qzeros_out, void *stream);
+/* dst_layout: QLLM_LAYOUT_GPTQ / _AWQ_GEMM (from NATIVE) or QLLM_LAYOUT_HQQ (from NATIVE_F16Z); outputs are the reference's buffers */
+int qllm_unpack_native(const qllm_weight_t *native, int32_t dst_layout, void *qweight_out, void *scales_out, void *qzeros_out,
+                       void *stream);
 
 /* ---- layout conversion on device (repack) ----------------------------------- */
 /* Integer grid q[K,N] (i32, natural order) <-> packed qweight of `layout`/`bits`.

@@ -8,13 +8,15 @@ csrc/awq_cuda/quantization/gemm_cuda.h:3-4:
 
 Decode (M <= 64): an AWQ row is only N/2 bytes, so no column strip of that layout covers all of K with whole cache lines and
 the in-place kernel has to split K (11-16 us per Llama-7B linear at M = 1).  The first decode call on a weight therefore builds
-a row-stream copy of the SAME integers (bit-exact, on device, with the library's unpack / pack kernels; +0.5 byte per weight),
-cached on the identity and version of the caller's tensors, and later calls stream that through the full-K strip kernel
-(5-8 us).  QLLM_AWQ_DECODE_SHADOW=0 keeps every call on the in-place layout.
+the library's native strip-major copy of the SAME integers (`qllm_repack_native`: bit-exact, on device, +0.5 byte per weight),
+cached per qweight tensor OBJECT (weak references to the caller's three tensors plus their versions: a freed model's entry dies
+with its tensors and can never be served to another model that happens to get the same addresses), and later calls stream that
+through the full-K strip kernel (3-6 us).  QLLM_AWQ_DECODE_SHADOW=0 keeps every call on the in-place layout.
 tests/test_integration_level1_gpu.py runs exactly this file against the oracle.
 """
 import ctypes
 import os
+import weakref
 
 import torch
 
@@ -27,18 +29,18 @@ class _Weight(ctypes.Structure):  # qllm_weight_t
                 ("group_size", _i32), ("bits", _i32), ("layout", _i32), ("add_zero_bias", _i32)]
 
 
-_GPTQ, _AWQ = 0, 1
+_GPTQ, _AWQ, _NATIVE = 0, 1, 3
 _lib.qllm_awq_gemm_forward.argtypes = [_vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _sz, _vp]
 _lib.qllm_awq_gemm_forward.restype = ctypes.c_int
 _lib.qllm_linear_forward.argtypes = [ctypes.POINTER(_Weight), _vp, _vp, _i32, _i32, _vp, _sz, _vp]
 _lib.qllm_linear_forward.restype = ctypes.c_int
-_lib.qllm_unpack_qweight.argtypes = [_vp, _i32, _i32, _i32, _i32, _vp, _vp]
-_lib.qllm_unpack_qweight.restype = ctypes.c_int
-_lib.qllm_pack_qweight.argtypes = [_vp, _i32, _i32, _i32, _i32, _vp, _vp]
-_lib.qllm_pack_qweight.restype = ctypes.c_int
+_lib.qllm_native_sizes.argtypes = [ctypes.POINTER(_Weight), ctypes.POINTER(_sz), ctypes.POINTER(_sz), ctypes.POINTER(_sz)]
+_lib.qllm_native_sizes.restype = ctypes.c_int
+_lib.qllm_repack_native.argtypes = [ctypes.POINTER(_Weight), _vp, _vp, _vp, _vp]
+_lib.qllm_repack_native.restype = ctypes.c_int
 _lib.qllm_last_error.restype = ctypes.c_char_p
 _ws = {}
-_rows = {}  # identity + version of (qweight, scales, qzeros) -> (descriptor, tensors it points into)
+_native = {}  # id(qweight) -> (weakrefs of (qweight, scales, qzeros), their versions, descriptor, tensors it points into)
 _DECODE_MAX_M = 64
 
 
@@ -47,26 +49,31 @@ def _check(rc):
         raise RuntimeError(_lib.qllm_last_error().decode())
 
 
-def _row_stream(qweight, s16, qzeros, K, N, g, stream):
-    """The same 4-bit integers as [K/8, N] words (8 consecutive k of one column per word) + zero points in natural column order."""
-    key = tuple((t.data_ptr(), t._version) for t in (qweight, s16, qzeros)) + (K, N)
-    hit = _rows.get(key)
-    if hit is None:
-        dev = qweight.device
-        q = torch.empty((K, N), dtype=torch.int32, device=dev)
-        _check(_lib.qllm_unpack_qweight(qweight.data_ptr(), _AWQ, 4, K, N, q.data_ptr(), stream))
-        qw = torch.empty((K // 8, N), dtype=torch.int32, device=dev)
-        _check(_lib.qllm_pack_qweight(q.data_ptr(), _GPTQ, 4, K, N, qw.data_ptr(), stream))
-        groups = qzeros.shape[0]
-        z = torch.empty((groups, N), dtype=torch.int32, device=dev)  # zero points share the weights' column interleave
-        _check(_lib.qllm_unpack_qweight(qzeros.contiguous().data_ptr(), _AWQ, 4, groups, N, z.data_ptr(), stream))
-        shifts = torch.arange(0, 32, 4, device=dev, dtype=torch.int64)
-        qz = (z.to(torch.int64).view(groups, N // 8, 8) << shifts).sum(-1).to(torch.int32).contiguous()  # (wraps into the sign bit)
-        desc = _Weight(qw.data_ptr(), s16.data_ptr(), qz.data_ptr(), None, None, K, N, g, 4, _GPTQ, 0)
-        if len(_rows) > 4096:  # weights that were re-created many times: do not grow without bound
-            _rows.clear()
-        hit = _rows[key] = (desc, (qw, qz, s16))
-    return hit[0]
+def _ver(t):
+    return 0 if t.is_inference() else t._version
+
+
+def _native_copy(qweight, scales, s16, qzeros, K, N, g, stream):
+    """The same 4-bit integers, scales and zero points in the library's native layout ([N/16][K/8][16] words: one contiguous
+    region per 16-column strip), or None when the shape cannot be held in it."""
+    srcs = (qweight, scales, qzeros)
+    hit = _native.get(id(qweight))
+    if hit is not None and all(r() is t for r, t in zip(hit[0], srcs)) and hit[1] == tuple(_ver(t) for t in srcs):
+        return hit[2]
+    src = _Weight(qweight.data_ptr(), s16.data_ptr(), qzeros.data_ptr(), None, None, K, N, g, 4, _AWQ, 0)
+    bw, bs, bz = _sz(0), _sz(0), _sz(0)
+    if _lib.qllm_native_sizes(ctypes.byref(src), ctypes.byref(bw), ctypes.byref(bs), ctypes.byref(bz)):
+        return None
+    dev = qweight.device
+    nq = torch.empty(bw.value // 4, dtype=torch.int32, device=dev)
+    ns = torch.empty(bs.value // 2, dtype=torch.float16, device=dev)
+    nz = torch.empty(bz.value // 4, dtype=torch.int32, device=dev)
+    _check(_lib.qllm_repack_native(ctypes.byref(src), nq.data_ptr(), ns.data_ptr(), nz.data_ptr(), stream))
+    desc = _Weight(nq.data_ptr(), ns.data_ptr(), nz.data_ptr(), None, None, K, N, g, 4, _NATIVE, 0)
+    key = id(qweight)
+    _native[key] = (tuple(weakref.ref(t) for t in srcs), tuple(_ver(t) for t in srcs), desc, (nq, ns, nz))
+    weakref.finalize(qweight, _native.pop, key, None)  # the entry dies with the caller's tensor
+    return desc
 
 
 def gemm_forward_cuda(x, qweight, scales, qzeros, split_k_iters):
@@ -87,7 +94,10 @@ def gemm_forward_cuda(x, qweight, scales, qzeros, split_k_iters):
         g = K // scales.shape[0] if scales.shape[0] and K % scales.shape[0] == 0 else 0
         if (0 < M <= _DECODE_MAX_M and g > 0 and K % 32 == 0 and N % 16 == 0 and qweight.shape[0] == K and scales.dtype == torch.float16
                 and os.environ.get("QLLM_AWQ_DECODE_SHADOW", "1") != "0"):
-            w = _row_stream(qweight, s16, qzeros, K, N, g, stream)
+            w = _native_copy(qweight, scales, s16, qzeros.contiguous(), K, N, g, stream)
+        else:
+            w = None
+        if w is not None:
             rc = _lib.qllm_linear_forward(ctypes.byref(w), xc.data_ptr(), y.data_ptr(), M, act, ws.data_ptr(), ws.numel(), stream)
         else:
             rc = _lib.qllm_awq_gemm_forward(xc.data_ptr(), qweight.data_ptr(), s16.data_ptr(), qzeros.data_ptr(), split_k_iters, y.data_ptr(),

@@ -422,6 +422,33 @@ def ort_is_act_order(g_idx) -> bool:
 # ----------------------------------------------------------------------------------------------
 # parity metric
 # ----------------------------------------------------------------------------------------------
+# ---- the library's native (strip-major) layout, restated (no reference counterpart: it is THIS repo's load-time layout) ------
+# include/qllm_mi355x.h "native layout": pins what qllm_repack_native must produce from the integer grids the functions above
+# recover from the reference's buffers.
+def native_layout(q_kn, scales_gn, zeros_gn, bits: int, zeros_f16: bool = False):
+    """(qweight i32 [N/16, K*bits/32, 16], scales f16 [N/16, G, 16], qzeros) from q[K, N] ints, scales [G, N], zeros [G, N]
+    (stored integer zero points, fp16 zero points when `zeros_f16`, or None).  Packed zero points: u32 [N/16, G, 2] -- the
+    64-bit little-endian pair holds column 16 s + i at bit `bits` * i."""
+    q = np.asarray(q_kn)
+    k, n = q.shape
+    assert n % 16 == 0 and (k * bits) % 32 == 0
+    rows = pack_along_rows(q, bits)                                   # [K*bits/32, N]: the GPTQ row stream
+    qweight = np.ascontiguousarray(rows.reshape(rows.shape[0], n // 16, 16).transpose(1, 0, 2))
+    sc = np.asarray(scales_gn, dtype=np.float16)
+    scales = np.ascontiguousarray(sc.reshape(sc.shape[0], n // 16, 16).transpose(1, 0, 2))
+    if zeros_gn is None:
+        return qweight, scales, None
+    if zeros_f16:
+        z = np.asarray(zeros_gn, dtype=np.float16)
+        return qweight, scales, np.ascontiguousarray(z.reshape(z.shape[0], n // 16, 16).transpose(1, 0, 2))
+    z = np.asarray(zeros_gn).astype(np.uint64).reshape(-1, n // 16, 16)
+    pair = np.zeros(z.shape[:2], dtype=np.uint64)
+    for i in range(16):
+        pair |= (z[:, :, i] & np.uint64((1 << bits) - 1)) << np.uint64(bits * i)
+    qz = np.stack([(pair & np.uint64(0xFFFFFFFF)).astype(np.uint32), (pair >> np.uint64(32)).astype(np.uint32)], axis=-1)
+    return qweight, scales, np.ascontiguousarray(qz.transpose(1, 0, 2)).view(np.int32)
+
+
 def rel_err(y, y_ref) -> float:
     """max_abs(y - y_ref) / max_abs(y_ref)"""
     a = np.asarray(y, dtype=np.float64)

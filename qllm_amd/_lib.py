@@ -14,18 +14,16 @@ LIB_NAME = "libqllm_mi355x.so"
 LIB_PATH = os.environ.get("QLLM_MI355X_LIB") or os.path.join(_HERE, LIB_NAME)  # override: A/B-testing kernel builds
 
 QLLM_OK, QLLM_ERR_INVALID, QLLM_ERR_UNSUPPORTED, QLLM_ERR_WORKSPACE, QLLM_ERR_LAUNCH, QLLM_ERR_DEVICE = range(6)
-LAYOUT_GPTQ, LAYOUT_AWQ_GEMM, LAYOUT_HQQ = 0, 1, 2
+LAYOUT_GPTQ, LAYOUT_AWQ_GEMM, LAYOUT_HQQ, LAYOUT_NATIVE, LAYOUT_NATIVE_F16Z = 0, 1, 2, 3, 4
 DT_F16, DT_BF16 = 0, 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 EXPORTS = (
     "qllm_abi_version", "qllm_last_error", "qllm_device_info", "qllm_workspace_bytes", "qllm_workspace_init",
     "qllm_linear_forward", "qllm_linear_forward_grouped", "qllm_dequant", "qllm_ort_gemv", "qllm_ort_dequant",
     "qllm_awq_gemm_forward", "qllm_unpack_qweight", "qllm_pack_qweight", "qllm_gather_columns", "qllm_ort_dequantize4bits",
-    "qllm_plan_describe", "qllm_linear_forward_chained", "qllm_chain_plan_describe",
-    "qllm_debug_timeline", "qllm_engine_link_init", "qllm_engine_run",
+    "qllm_plan_describe", "qllm_debug_timeline", "qllm_native_sizes", "qllm_repack_native", "qllm_unpack_native",
 )
-CHAIN_POLL_X, CHAIN_PUBLISH_Y = 1, 2
 
 
 class QllmWeight(C.Structure):
@@ -36,14 +34,6 @@ class QllmWeight(C.Structure):
         ("K", C.c_int32), ("N", C.c_int32), ("group_size", C.c_int32), ("bits", C.c_int32),
         ("layout", C.c_int32), ("add_zero_bias", C.c_int32),
     ]
-
-
-class QllmEngineLink(C.Structure):
-    """struct qllm_engine_link (include/qllm_mi355x.h)."""
-    _fields_ = [("qweight", C.c_void_p), ("scales", C.c_void_p), ("qzeros", C.c_void_p), ("bias", C.c_void_p),
-                ("x", C.c_void_p), ("y", C.c_void_p),
-                ("N", C.c_int32), ("K", C.c_int32), ("n_strips", C.c_int32), ("strip0", C.c_int32), ("slabs", C.c_int32),
-                ("zero_kind", C.c_int32), ("add_zero_bias", C.c_int32), ("x_poll", C.c_int32)]
 
 
 class QllmDeviceInfo(C.Structure):
@@ -100,16 +90,14 @@ def _declare(lib):
     lib.qllm_gather_columns.argtypes = [vp, vp, vp, i32, i32, i32, vp]
     lib.qllm_plan_describe.restype = C.c_int
     lib.qllm_plan_describe.argtypes = [wp, i32, i32, i32, C.c_char_p, sz]
-    lib.qllm_linear_forward_chained.restype = C.c_int
-    lib.qllm_linear_forward_chained.argtypes = [wp, C.POINTER(vp), i32, vp, i32, i32, i32, vp, vp]
-    lib.qllm_chain_plan_describe.restype = C.c_int
-    lib.qllm_chain_plan_describe.argtypes = [wp, i32, i32, C.c_char_p, sz]
-    lib.qllm_engine_link_init.restype = C.c_int
-    lib.qllm_engine_link_init.argtypes = [wp, vp, vp, i32, i32, i32, i32, C.POINTER(QllmEngineLink)]
-    lib.qllm_engine_run.restype = C.c_int
-    lib.qllm_engine_run.argtypes = [vp, i32, vp, vp]
     lib.qllm_debug_timeline.restype = C.c_int
     lib.qllm_debug_timeline.argtypes = [vp, i32]
+    lib.qllm_native_sizes.restype = C.c_int
+    lib.qllm_native_sizes.argtypes = [wp, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]
+    lib.qllm_repack_native.restype = C.c_int
+    lib.qllm_repack_native.argtypes = [wp, vp, vp, vp, vp]
+    lib.qllm_unpack_native.restype = C.c_int
+    lib.qllm_unpack_native.argtypes = [wp, i32, vp, vp, vp, vp]
     lib.qllm_ort_dequantize4bits.restype = C.c_int
     lib.qllm_ort_dequantize4bits.argtypes = [vp, vp, vp, i32, vp, i32, i32, i32, vp, vp]
 

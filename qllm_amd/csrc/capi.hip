@@ -28,6 +28,19 @@ static int env_int(const char *name, int dflt) {
   const char *v = getenv(name);
   return (v && *v) ? atoi(v) : dflt;
 }
+// CUs of the current device (launch heuristics only); 256 (MI355X) when no device is reachable, so that the pure-host
+// planners (qllm_plan_describe, qllm_workspace_bytes) stay deterministic without a GPU.  QLLM_NUM_CU overrides.
+static int compute_units() {
+  static int v = [] {
+    int e = env_int("QLLM_NUM_CU", 0);
+    if (e > 0) return e;
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) return n;
+    (void)hipGetLastError();
+    return kNumCU;
+  }();
+  return v;
+}
 static int skinny_target_waves() {
   static int v = env_int("QLLM_SKINNY_WAVES", 2048);
   return v;
@@ -45,16 +58,26 @@ constexpr size_t kCounterBytes = 16384;  // 4096 column-tile arrival counters at
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // ---- validation ----------------------------------------------------------------------------------------------
+static bool is_native(const qllm_weight_t &w) { return w.layout == QLLM_LAYOUT_NATIVE || w.layout == QLLM_LAYOUT_NATIVE_F16Z; }
 static int zero_kind_of(const qllm_weight_t &w) {
-  if (w.layout == QLLM_LAYOUT_HQQ) return ZK_F16;
+  if (w.layout == QLLM_LAYOUT_HQQ || w.layout == QLLM_LAYOUT_NATIVE_F16Z) return ZK_F16;
   if (w.qzeros == nullptr) return ZK_SYM;
   return ZK_PACKED;
+}
+
+// shapes the strip-major native layout can hold (include/qllm_mi355x.h)
+static int native_shape_ok(int bits, int K, int N, int group_size, bool packed_zeros) {
+  if (bits != 4 && bits != 3) return set_error(QLLM_ERR_UNSUPPORTED, "the native layout holds 3- and 4-bit weights (got %d)", bits);
+  if (K % 32 != 0 || N % 16 != 0) return set_error(QLLM_ERR_UNSUPPORTED, "the native layout needs K %% 32 == 0 and N %% 16 == 0 (K=%d N=%d)", K, N);
+  if (group_size % 32 != 0) return set_error(QLLM_ERR_UNSUPPORTED, "the native layout needs group_size %% 32 == 0 (got %d)", group_size);
+  if (bits == 3 && packed_zeros && N % 32 != 0) return set_error(QLLM_ERR_UNSUPPORTED, "3-bit packed zero points need N %% 32 == 0 (N=%d)", N);
+  return QLLM_OK;
 }
 
 static int validate_weight(const qllm_weight_t *w) {
   if (!w) return set_error(QLLM_ERR_INVALID, "weight descriptor is NULL");
   if (!w->qweight || !w->scales) return set_error(QLLM_ERR_INVALID, "qweight/scales must not be NULL");
-  if (w->layout < QLLM_LAYOUT_GPTQ || w->layout > QLLM_LAYOUT_HQQ) return set_error(QLLM_ERR_INVALID, "unknown layout %d", w->layout);
+  if (w->layout < QLLM_LAYOUT_GPTQ || w->layout > QLLM_LAYOUT_NATIVE_F16Z) return set_error(QLLM_ERR_INVALID, "unknown layout %d", w->layout);
   if (w->bits < 2 || w->bits > 8) return set_error(QLLM_ERR_INVALID, "bits must be >= 2 and <= 8 (got %d)", w->bits);
   if (w->K <= 0 || w->N <= 0) return set_error(QLLM_ERR_INVALID, "in_features/out_features must be >= 1 (K=%d N=%d)", w->K, w->N);
   if (w->group_size < 8) return set_error(QLLM_ERR_INVALID, "groupsize must be >= 8 (got %d)", w->group_size);
@@ -64,6 +87,10 @@ static int validate_weight(const qllm_weight_t *w) {
     if (w->K % w->group_size != 0) return set_error(QLLM_ERR_INVALID, "IC is not multiple of group size (K=%d g=%d)", w->K, w->group_size);
     if (!w->qzeros) return set_error(QLLM_ERR_INVALID, "AWQ GEMM layout needs qzeros");
     if (w->g_idx) return set_error(QLLM_ERR_INVALID, "AWQ GEMM layout has no act-order (g_idx must be NULL)");
+  } else if (is_native(*w)) {
+    if (int rc = native_shape_ok(w->bits, w->K, w->N, w->group_size, w->layout == QLLM_LAYOUT_NATIVE && w->qzeros)) return rc;
+    if (w->g_idx) return set_error(QLLM_ERR_INVALID, "the native layout has no act-order (g_idx must be NULL: sort the rows by group first)");
+    if (w->layout == QLLM_LAYOUT_NATIVE_F16Z && !w->qzeros) return set_error(QLLM_ERR_INVALID, "NATIVE_F16Z layout needs fp16 qzeros");
   } else {
     if ((w->K * w->bits) % 32 != 0) return set_error(QLLM_ERR_INVALID, "in_features*bits must be a multiple of 32 (K=%d bits=%d)", w->K, w->bits);
     if (w->layout == QLLM_LAYOUT_HQQ && !w->qzeros) return set_error(QLLM_ERR_INVALID, "HQQ layout needs fp16 qzeros");
@@ -76,7 +103,7 @@ static int validate_weight(const qllm_weight_t *w) {
 }
 
 static bool fused_common_ok(const qllm_weight_t &w) {
-  return w.bits == 4 && w.N % 8 == 0 && w.group_size % 8 == 0 && ((uintptr_t)w.qweight % 16 == 0) &&
+  return !is_native(w) && w.bits == 4 && w.N % 8 == 0 && w.group_size % 8 == 0 && ((uintptr_t)w.qweight % 16 == 0) &&
          ((uintptr_t)w.scales % 16 == 0) && (!w.qzeros || (uintptr_t)w.qzeros % 8 == 0);
 }
 static bool skinny_ok(const qllm_weight_t &w, int M) {
@@ -91,31 +118,23 @@ static int strip_min_strips() {
 // full-K strip kernel: row-stream layouts, M <= 64 (17..64: several 16-row tiles per block), enough 16-column strips to
 // cover the 256 CUs
 struct StripPlan {
-  int cpl, nw, spw, ra;
+  int cpl, nw, spw, ra, sm;
 };
-// diagnostics: timeline buffer handed to chained launches (8 x u64 per launch), see qllm_debug_timeline()
+// diagnostics: timeline buffer handed to the native-layout decode launches (24 x u64 per launch), see qllm_debug_timeline()
 static uint64_t *g_timeline = nullptr;
 static int g_timeline_slots = 0, g_timeline_next = 0;
 
-constexpr int kChainMaxGrid = 448;          // blocks of a chained link: all co-resident beside the neighbouring link's
-constexpr int kChainMinGrid = 120;          // fewer blocks than about half the CUs: not worth a link (ordinary launch instead)
-constexpr size_t kChainMaxLds = 80 * 1024;  // half a CU
-static int chain_max_m() {
-  static int v = env_int("QLLM_CHAIN_MAX_M", 4);
-  return v;
-}
-// chain != 0: plan for a chained decode link (strip.hip, CH): lds-slab form, 4 bits, at most half a CU per block, grid <= 448
-static bool strip_plan(const qllm_weight_t *w, int n, int M, StripPlan *plan, int chain = 0) {
-  if (chain && (M > chain_max_m() || w[0].bits != 4)) return false;
+static bool strip_plan(const qllm_weight_t *w, int n, int M, StripPlan *plan) {
   // measured (graph replay, us; split-K kernel -> strips with 2 / 4 row tiles): M=32: 4096x4096 28.3 -> 13.4, 4096x11008 54.9 -> 36.3,
   // 11008x4096 50.1 -> 30.3; M=64: 33.8 -> 22.6, 52.5 -> 61.5, 48.1 -> 53.9 -- four row tiles only pay on the small shape
   // M = 33..64 (four row tiles), us per linear, split-K kernel -> strips (profiles/r02_mid_m.md): 4096x4096 26.8/31.4/33.5 ->
   // 17.6/19.8/22.6 at M = 33/48/64; on the 11008-wide shapes the strips lose at M >= 48 (43.9 -> 55.1, 41.2 -> 49.8): small shape only
   static int max_m = env_int("QLLM_STRIP_MAX_M", 0);
+  const bool sm = is_native(w[0]);
   {
     int cols_all = 0;
     for (int i = 0; i < n; ++i) cols_all += w[i].N;
-    const int lim = max_m ? max_m : ((w[0].K <= 4096 && cols_all <= 4096) ? 64 : 32);
+    const int lim = max_m ? max_m : (sm ? (w[0].bits == 3 ? 32 : 64) : ((w[0].K <= 4096 && cols_all <= 4096) ? 64 : 32));
     if (M > lim) return false;
   }
   if (M > 64 || strip_min_strips() <= 0) return false;
@@ -123,9 +142,9 @@ static bool strip_plan(const qllm_weight_t *w, int n, int M, StripPlan *plan, in
   const int bits = w[0].bits;
   if (bits != 4 && bits != 3) return false;
   for (int i = 0; i < n; ++i) {
-    if (w[i].bits != bits || w[i].K % 32 != 0 || w[i].g_idx) return false;
+    if (w[i].bits != bits || w[i].K % 32 != 0 || w[i].g_idx || is_native(w[i]) != sm) return false;
     // 3-bit: fp16 (HQQ), symmetric, or packed zero points (a column's field may straddle two words of the N*3/32-word row)
-    if (bits == 3 && !(w[i].layout == QLLM_LAYOUT_HQQ || w[i].layout == QLLM_LAYOUT_GPTQ)) return false;
+    if (bits == 3 && !sm && !(w[i].layout == QLLM_LAYOUT_HQQ || w[i].layout == QLLM_LAYOUT_GPTQ)) return false;
     if (bits == 3 && w[i].layout == QLLM_LAYOUT_GPTQ && w[i].qzeros && w[i].N % 32 != 0) return false;
     if ((uintptr_t)w[i].qweight % 16 || (uintptr_t)w[i].scales % 16 || (w[i].qzeros && (uintptr_t)w[i].qzeros % 8)) return false;
   }
@@ -137,70 +156,86 @@ static bool strip_plan(const qllm_weight_t *w, int n, int M, StripPlan *plan, in
     m64 = m64 && (w[i].N % 64 == 0);
     m32 = m32 && (w[i].N % 32 == 0);
   }
-  static int force_cpl_env = env_int("QLLM_STRIP_CPL", 0);
-  int force_cpl = force_cpl_env;
-  static int nw4 = env_int("QLLM_STRIP_NW4", 0);
   // rows from which the activation slab in LDS (staged once per block: M*K/8 chunk operations) loses to per-lane
-  // fragment loads + two bookkeeping MFMAs per k-step (strip.hip, RA)
+  // fragment loads + two bookkeeping MFMAs per k-step (strip_kernel.hpp, RA)
   // measured (graph replay, us; slab -> RA): 4096x4096 M=4 5.3 -> 6.2, M=8 9.6 -> 7.1, M=16 9.9 -> 8.5; 4096x11008 M=4 9.8 -> 9.3,
   // M=8 10.0 -> 9.7, M=16 25.7 -> 11.9; 11008x4096 M=4 13.6 -> 13.0, M=8 20.2 -> 14.6, M=16 26.4 (split-K fallback) -> 18.9
   static int ra_min = env_int("QLLM_STRIP_RA_MIN", 5);
   // long K with 64-wide groups or 3 bits: the one-round slab variant (24 loads + 12 scale/zero pairs per lane) spills
-  // 17-21 registers in a 16-wave block; the register-A variant (rounds of 8 with next-round prefetch) does not
+  // 17-21 registers in a 16-wave block; the register-A variant (rounds of 8) does not
   static int ra_longk = env_int("QLLM_STRIP_RA_LONGK", 1);
   const bool longk = ra_longk && (w[0].group_size == 64 || bits == 3) && strip_spw(w[0].K, w[0].group_size, 16) > 8;
   const int ra_base = (M >= ra_min) ? 1 : 0;
-  int first = (bits == 3 || M > 16) ? 1 : strip_cpl(cols, m64, m32 && M <= 4);
+  if (sm) {
+    // strip-major: 16-column strips only (every wave-load is 256 contiguous bytes whatever the width; narrow strips balance best)
+    const int strips = cols / 16;
+    if (strips < 1) return false;
+    const int slab_nw = ra_base ? 0 : strip_sm_nw(w[0].K, M, w[0].group_size, bits);  // 0: no slab form for this shape
+    int nw = (M > 16) ? 8 : (slab_nw ? slab_nw : 16);
+    for (int tries = 0; tries < 2; ++tries) {
+      const int spw = strip_spw(w[0].K, w[0].group_size, nw);
+      const int ra = (slab_nw == 0 || (longk && nw == 16)) ? 1 : 0;
+      if (!ra && w[0].K / 32 < strip_maxs(nw, spw, 1, 0, 1)) return false;  // a round's window must fit into the strip
+      if ((ra || strip_x_ok(M, spw, nw, 1, 1)) && strip_lds_bytes(M, spw, nw, 1, w[0].group_size, ra, 1) <= 156 * 1024) {
+        plan->cpl = 1;
+        plan->nw = nw;
+        plan->spw = spw;
+        plan->ra = ra;
+        plan->sm = 1;
+        return true;
+      }
+      if (nw == 16 || M > 16) break;
+      nw = 16;  // shorter per-wave chunks
+    }
+    return false;
+  }
+  static int force_cpl_env = env_int("QLLM_STRIP_CPL", 0);
+  int force_cpl = force_cpl_env;
+  const int cus = compute_units();
+  int first = (bits == 3 || M > 16) ? 1 : strip_cpl(cols, m64, m32 && M <= 4, cus);
   if (M > 16) force_cpl = 1;  // several row tiles per block: 16-column strips, 8-wave blocks, register-A
   if (force_cpl == 4 && m64 && bits == 4) first = 4;
   if (force_cpl == 2 && m32 && bits == 4) first = 2;
   if (force_cpl == 1) first = 1;
   // candidates: the measured-best strip width first; if its activation slab does not fit in LDS (many rows), narrower
   // strips with 16 waves (each wave stages a shorter K chunk)
-  const int chain_arg = chain ? 1 : 0;
-  const int cand_cpl[3] = {first, 1, (chain && m64) ? 4 : 1};
-  for (int ci = 0; ci < 3; ++ci) {
+  const int cand_cpl[2] = {first, 1};
+  for (int ci = 0; ci < 2; ++ci) {
     const int cpl = cand_cpl[ci];
     if (ci >= 1 && cpl == cand_cpl[ci - 1]) continue;
-    if (ci == 2 && cpl == first) break;
     const int strips = cols / (16 * cpl);
     if (cpl == 1 && strips < strip_min_strips()) continue;
-    if (chain && (strips > kChainMaxGrid || strips < kChainMinGrid)) continue;
     // 64-column strips use 128 VGPRs -> 16 waves per CU: 8-wave blocks keep two strips co-resident per CU (one
     // round) instead of 16-wave blocks in two rounds (gate/up 15.6 -> 13.8 us, q/k/v 8.5 -> 8.3 us)
-    int nw = cpl == 4 ? ((nw4 && !chain) ? nw4 : 8) : ((cpl == 2 || bits == 3) ? 16 : strip_nw(w[0].K, strips));
+    int nw = cpl == 4 ? 8 : ((cpl == 2 || bits == 3) ? 16 : strip_nw(w[0].K, strips, cus));
     if (M > 16) nw = 8;
-    if (chain) {  // half a CU per block: 64-column strips (g128) as 8-wave blocks; 16-column strips as 16 waves x one round of 8
-      if (cpl == 2 || (cpl == 4 && w[0].group_size != 128)) continue;  // k-steps when K is short, else 8 waves x rounds of <= 24
-      if (cpl == 1) nw = strip_spw(w[0].K, w[0].group_size, 16) <= 8 ? 16 : 8;
-    }
     for (int tries = 0; tries < 2; ++tries) {
       const int spw = strip_spw(w[0].K, w[0].group_size, nw);
-      const int ra = (ra_base || (!chain && longk && cpl == 1 && nw == 16)) ? 1 : 0;
-      if (chain && (ra || tries > 0)) break;
-      if ((ra || strip_x_ok(M, spw, nw, cpl, chain_arg)) &&
-          strip_lds_bytes(M, spw, nw, cpl, w[0].group_size, ra, chain_arg) <= (chain ? kChainMaxLds : 156 * 1024)) {
+      const int ra = (ra_base || (longk && cpl == 1 && nw == 16)) ? 1 : 0;
+      if ((ra || strip_x_ok(M, spw, nw, cpl, 0)) && strip_lds_bytes(M, spw, nw, cpl, w[0].group_size, ra, 0) <= 156 * 1024) {
         plan->cpl = cpl;
         plan->nw = nw;
         plan->spw = spw;
         plan->ra = ra;
+        plan->sm = 0;
         return true;
       }
-      if (nw == 16 || M > 16) break;
+      if (nw == 16 || M > 16 || cpl == 4) break;  // (64-column strips exist as 8-wave blocks only)
       nw = 16;  // shorter per-wave chunks
     }
   }
   return false;
 }
+// layouts that may share a grouped launch: reference row-stream (GPTQ / HQQ), AWQ, native
+static int layout_family(const qllm_weight_t &w) { return is_native(w) ? 2 : (w.layout == QLLM_LAYOUT_AWQ_GEMM ? 1 : 0); }
 static bool strip_ok(const qllm_weight_t *w, int n, int M) {
   StripPlan pl;
   return strip_plan(w, n, M, &pl);
 }
 
-static int run_strip(const qllm_weight_t *w, void *const *y, int n, const void *x, int M, int act_dtype, hipStream_t stream,
-                     int chain = 0, uint32_t *err = nullptr) {
+static int run_strip(const qllm_weight_t *w, void *const *y, int n, const void *x, int M, int act_dtype, hipStream_t stream) {
   StripPlan pl;
-  if (!strip_plan(w, n, M, &pl, chain != 0)) return set_error(QLLM_ERR_INVALID, "internal: strip plan");
+  if (!strip_plan(w, n, M, &pl)) return set_error(QLLM_ERR_INVALID, "internal: strip plan");
   StripParams p;
   memset(&p, 0, sizeof(p));
   p.x = x;
@@ -213,13 +248,14 @@ static int run_strip(const qllm_weight_t *w, void *const *y, int n, const void *
   p.nw = pl.nw;
   p.spw = pl.spw;
   p.ra = pl.ra;
+  p.sm = pl.sm;
+  p.n_groups = (w[0].K + w[0].group_size - 1) / w[0].group_size;
   p.group_size = w[0].group_size;
   p.add_zero_bias = w[0].add_zero_bias;
   p.act_bf16 = (act_dtype == QLLM_BF16);
-  p.chain = chain;
-  p.lw = strip_lw(pl.nw, pl.spw, pl.cpl, w[0].group_size, chain != 0) ? 1 : 0;
-  p.err = err;
-  p.dbg = (chain && g_timeline && g_timeline_next < g_timeline_slots) ? g_timeline + 8 * (g_timeline_next++) : nullptr;
+  // diagnostics: only the lds-slab 4-bit g128 native-layout form has a timeline instantiation
+  p.dbg = (pl.sm && !pl.ra && p.bits == 4 && p.group_size == 128 && g_timeline && g_timeline_next < g_timeline_slots)
+              ? g_timeline + 24 * (g_timeline_next++) : nullptr;
   int block = 0;
   for (int i = 0; i < n; ++i) {
     StripProblem &q = p.prob[i];
@@ -306,6 +342,14 @@ static int check_io(const void *x, const void *y, int M, int act_dtype) {
   return QLLM_OK;
 }
 
+// prefill-sized calls (M > 64) on native-layout layers
+static int native_prefill(const qllm_weight_t *w, const void *x, void *y, int M, int act_dtype, void *workspace, size_t workspace_bytes,
+                          hipStream_t stream) {
+  (void)x; (void)y; (void)act_dtype; (void)workspace; (void)workspace_bytes; (void)stream;
+  return set_error(QLLM_ERR_UNSUPPORTED, "native-layout layer: no fused kernel for M=%d K=%d N=%d g=%d bits=%d (decode sizes, M <= 64, g in {64,128}, are served)",
+                   M, w->K, w->N, w->group_size, w->bits);
+}
+
 }  // namespace qllm
 
 using namespace qllm;
@@ -365,82 +409,16 @@ int qllm_linear_forward_grouped(const qllm_weight_t *w, void *const *y, int32_t 
     if (rc) return rc;
     rc = check_io(x, y[i], M, act_dtype);
     if (rc) return rc;
-    const bool rows0 = w[0].layout != QLLM_LAYOUT_AWQ_GEMM, rowsi = w[i].layout != QLLM_LAYOUT_AWQ_GEMM;
-    if (w[i].K != w[0].K || w[i].group_size != w[0].group_size || w[i].bits != w[0].bits || rows0 != rowsi ||
+    if (w[i].K != w[0].K || w[i].group_size != w[0].group_size || w[i].bits != w[0].bits || layout_family(w[0]) != layout_family(w[i]) ||
         w[i].add_zero_bias != w[0].add_zero_bias)
       return set_error(QLLM_ERR_INVALID, "grouped weights must agree on K, group_size, bits, layout family and add_zero_bias");
-    if (w[i].bits == 3) continue;  // decided as a group by strip_ok below
+    if (w[i].bits == 3 || is_native(w[i])) continue;  // decided as a group by strip_ok below
     if (!skinny_ok(w[i], M)) return set_error(QLLM_ERR_UNSUPPORTED, "grouped forward needs the decode kernel (4-bit, M<=%d, K%%32==0, no act-order)", skinny_max_m());
   }
   if (strip_ok(w, n_weights, M)) return run_strip(w, y, n_weights, x, M, act_dtype, (hipStream_t)stream);
+  if (is_native(w[0])) return set_error(QLLM_ERR_UNSUPPORTED, "grouped forward: native-layout layers are served for M <= 64 with group size 64 / 128 (M=%d g=%d)", M, w[0].group_size);
   if (w[0].bits != 4) return set_error(QLLM_ERR_UNSUPPORTED, "grouped forward: no fused kernel for %d-bit weights in this shape", w[0].bits);
   return run_skinny(w, y, n_weights, x, M, act_dtype, workspace, workspace_bytes, (hipStream_t)stream);
-}
-
-int qllm_linear_forward_chained(const qllm_weight_t *w, void *const *y, int32_t n_weights, const void *x, int32_t M,
-                                int32_t act_dtype, int32_t chain_flags, void *err_word, void *stream) {
-  clear_error();
-  if (!w || !y) return set_error(QLLM_ERR_INVALID, "w / y arrays must not be NULL");
-  if (n_weights < 1 || n_weights > kMaxProblems) return set_error(QLLM_ERR_INVALID, "n_weights must be 1..%d (got %d)", kMaxProblems, n_weights);
-  if (chain_flags < 1 || chain_flags > 3) return set_error(QLLM_ERR_INVALID, "chain_flags must be POLL_X | PUBLISH_Y (1..3), got %d", chain_flags);
-  if (!err_word || (uintptr_t)err_word % 4) return set_error(QLLM_ERR_INVALID, "err_word must be a 4-byte aligned device word");
-  for (int i = 0; i < n_weights; ++i) {
-    int rc = validate_weight(&w[i]);
-    if (rc) return rc;
-    rc = check_io(x, y[i], M, act_dtype);
-    if (rc) return rc;
-    if ((uintptr_t)y[i] % 4 || w[i].N % 2) return set_error(QLLM_ERR_INVALID, "chained links store y in 4-byte pairs: y must be 4-byte aligned, N even");
-    const bool rows0 = w[0].layout != QLLM_LAYOUT_AWQ_GEMM, rowsi = w[i].layout != QLLM_LAYOUT_AWQ_GEMM;
-    if (w[i].K != w[0].K || w[i].group_size != w[0].group_size || w[i].bits != w[0].bits || rows0 != rowsi ||
-        w[i].add_zero_bias != w[0].add_zero_bias)
-      return set_error(QLLM_ERR_INVALID, "grouped weights must agree on K, group_size, bits, layout family and add_zero_bias");
-    if (!skinny_ok(w[i], M)) return set_error(QLLM_ERR_UNSUPPORTED, "chained link needs the decode kernel (4-bit, K%%32==0, no act-order)");
-  }
-  StripPlan pl;
-  if (!strip_plan(w, n_weights, M, &pl, 1))
-    return set_error(QLLM_ERR_UNSUPPORTED, "no chained-link plan for this shape (M=%d): run it as an ordinary launch", M);
-  return run_strip(w, y, n_weights, x, M, act_dtype, (hipStream_t)stream, chain_flags, (uint32_t *)err_word);
-}
-
-int qllm_engine_link_init(const qllm_weight_t *w, const void *x, void *y, int32_t M, int32_t act_dtype, int32_t x_poll,
-                          int32_t strip0, qllm_engine_link_t *out) {
-  clear_error();
-  if (!out) return set_error(QLLM_ERR_INVALID, "out is NULL");
-  int rc = validate_weight(w);
-  if (rc) return rc;
-  rc = check_io(x, y, M, act_dtype);
-  if (rc) return rc;
-  if ((uintptr_t)y % 4) return set_error(QLLM_ERR_INVALID, "y must be 4-byte aligned");
-  if (!engine_link_ok(*w, M, act_dtype))
-    return set_error(QLLM_ERR_UNSUPPORTED, "decode engine serves M=1, fp16, 4-bit g128 row-stream layers with N%%32==0, K%%128==0");
-  static_assert(sizeof(qllm_engine_link_t) == sizeof(EngineLink), "C struct and device struct must agree");
-  EngineLink e;
-  e.qweight = (const uint32_t *)w->qweight;
-  e.scales = (const half_t *)w->scales;
-  e.qzeros = w->qzeros;
-  e.bias = (const half_t *)w->bias;
-  e.x = (const uint16_t *)x;
-  e.y = (uint16_t *)y;
-  e.N = w->N;
-  e.K = w->K;
-  e.n_strips = w->N / 32;
-  e.strip0 = strip0;
-  e.slabs = (w->K + 1023) / 1024;
-  e.zero_kind = zero_kind_of(*w);
-  e.add_zero_bias = w->add_zero_bias;
-  e.x_poll = x_poll ? 1 : 0;
-  memcpy(out, &e, sizeof(e));
-  return QLLM_OK;
-}
-
-int qllm_engine_run(const qllm_engine_link_t *links_device, int32_t n_links, void *err_word, void *stream) {
-  clear_error();
-  if (!links_device || n_links < 1) return set_error(QLLM_ERR_INVALID, "links_device must hold >= 1 link");
-  if (!err_word || (uintptr_t)err_word % 4) return set_error(QLLM_ERR_INVALID, "err_word must be a 4-byte aligned device word");
-  static int grid = env_int("QLLM_ENGINE_GRID", kNumCU);
-  // diagnostics (qllm_debug_timeline): the buffer must hold (grid * n_links + 2 * grid) * 4 u64, i.e. n_slots * 8 >= that
-  uint64_t *dbg = (g_timeline && (size_t)g_timeline_slots * 8 >= ((size_t)grid * n_links + 2 * grid) * 4) ? g_timeline : nullptr;
-  return launch_engine((const EngineLink *)links_device, n_links, (uint32_t *)err_word, grid, (hipStream_t)stream, dbg);
 }
 
 int qllm_gather_columns(const void *x, const int32_t *perm, void *out, int32_t M, int32_t K, int32_t act_dtype, void *stream) {
@@ -455,35 +433,11 @@ int qllm_gather_columns(const void *x, const int32_t *perm, void *out, int32_t M
   return launch_gather_columns(x, perm, out, M, K, (hipStream_t)stream);
 }
 
-int qllm_debug_timeline(void *buf, int32_t n_slots) {
+int qllm_debug_timeline(void *buf, int32_t n_slots) {  // n_slots x 24 x u64
   clear_error();
   g_timeline = (uint64_t *)buf;
   g_timeline_slots = buf ? n_slots : 0;
   g_timeline_next = 0;
-  return QLLM_OK;
-}
-
-int qllm_chain_plan_describe(const qllm_weight_t *w, int32_t n_weights, int32_t M, char *buf, size_t buflen) {
-  clear_error();
-  if (!w || !buf || buflen < 64) return set_error(QLLM_ERR_INVALID, "w / buf must not be NULL (buf >= 64 bytes)");
-  if (n_weights < 1 || n_weights > kMaxProblems) return set_error(QLLM_ERR_INVALID, "n_weights must be 1..%d (got %d)", kMaxProblems, n_weights);
-  if (M <= 0) return set_error(QLLM_ERR_INVALID, "M must be >= 1 (got %d)", M);
-  bool ok = true;
-  for (int i = 0; i < n_weights; ++i) {
-    const int rc = validate_weight(&w[i]);
-    if (rc) return rc;
-    ok = ok && skinny_ok(w[i], M) && w[i].N % 2 == 0;
-  }
-  StripPlan pl;
-  if (ok && strip_plan(w, n_weights, M, &pl, 1)) {
-    int cols = 0;
-    for (int i = 0; i < n_weights; ++i) cols += w[i].N;
-    snprintf(buf, buflen, "chained strip nw=%d cpl=%d spw=%d round=%d%s blocks=%d", pl.nw, pl.cpl, pl.spw,
-             strip_maxs(pl.nw, pl.spw, pl.cpl, 0, 1), strip_lw(pl.nw, pl.spw, pl.cpl, w[0].group_size, 1) ? "+lds" : "",
-             cols / (16 * pl.cpl));
-  } else {
-    snprintf(buf, buflen, "not chainable");
-  }
   return QLLM_OK;
 }
 
@@ -508,10 +462,11 @@ int qllm_linear_forward(const qllm_weight_t *w, const void *x, void *y, int32_t 
   if (rc) return rc;
   rc = check_io(x, y, M, act_dtype);
   if (rc) return rc;
-  if (w->bits == 3 && strip_ok(w, 1, M)) {
+  if ((w->bits == 3 || is_native(*w)) && strip_ok(w, 1, M)) {
     void *ys[1] = {y};
     return run_strip(w, ys, 1, x, M, act_dtype, (hipStream_t)stream);
   }
+  if (is_native(*w)) return native_prefill(w, x, y, M, act_dtype, workspace, workspace_bytes, (hipStream_t)stream);
   if (skinny_ok(*w, M)) {
     void *ys[1] = {y};
     if (strip_ok(w, 1, M)) return run_strip(w, ys, 1, x, M, act_dtype, (hipStream_t)stream);
@@ -595,6 +550,7 @@ int qllm_dequant(const qllm_weight_t *w, void *out, int32_t out_dtype, int32_t o
   if (rc) return rc;
   if (!out) return set_error(QLLM_ERR_INVALID, "out must not be NULL");
   if (out_dtype != QLLM_F16 && out_dtype != QLLM_BF16) return set_error(QLLM_ERR_INVALID, "out_dtype must be f16 or bf16");
+  if (is_native(*w)) return set_error(QLLM_ERR_UNSUPPORTED, "qllm_dequant reads the reference layouts: convert with qllm_unpack_native first");
   return launch_dequant(*w, zero_kind_of(*w), out, out_dtype, out_transposed ? 1 : 0, (hipStream_t)stream);
 }
 
@@ -643,10 +599,14 @@ int qllm_plan_describe(const qllm_weight_t *w, int32_t n_weights, int32_t M, int
   }
   StripPlan pl;
   bool decode_ok = true;
-  for (int i = 0; i < n_weights; ++i) decode_ok = decode_ok && (w[i].bits == 3 || skinny_ok(w[i], M));
-  if ((n_weights > 1 || w[0].bits == 3 || skinny_ok(w[0], M)) && decode_ok && strip_plan(w, n_weights, M, &pl)) {
-    snprintf(buf, buflen, "strip nw=%d cpl=%d spw=%d form=%s row_tiles=%d", pl.nw, pl.cpl, pl.spw, pl.ra ? "register-A" : "lds-slab",
-             M > 32 ? 4 : (M > 16 ? 2 : 1));
+  for (int i = 0; i < n_weights; ++i) decode_ok = decode_ok && (w[i].bits == 3 || is_native(w[i]) || skinny_ok(w[i], M));
+  if ((n_weights > 1 || w[0].bits == 3 || is_native(w[0]) || skinny_ok(w[0], M)) && decode_ok && strip_plan(w, n_weights, M, &pl)) {
+    snprintf(buf, buflen, "strip nw=%d cpl=%d spw=%d form=%s row_tiles=%d%s", pl.nw, pl.cpl, pl.spw, pl.ra ? "register-A" : "lds-slab",
+             M > 32 ? 4 : (M > 16 ? 2 : 1), pl.sm ? " layout=strip-major" : "");
+    return QLLM_OK;
+  }
+  if (is_native(w[0])) {
+    snprintf(buf, buflen, "unsupported (native layout: decode sizes only)");
     return QLLM_OK;
   }
   if (decode_ok && w[0].bits == 4 && skinny_ok(w[0], M)) {
@@ -696,6 +656,45 @@ int qllm_plan_describe(const qllm_weight_t *w, int32_t n_weights, int32_t M, int
   }
   snprintf(buf, buflen, "unsupported (dequant + GEMM)");
   return QLLM_OK;
+}
+
+int qllm_native_sizes(const qllm_weight_t *src, size_t *qweight_bytes, size_t *scales_bytes, size_t *qzeros_bytes) {
+  clear_error();
+  if (!src || !qweight_bytes || !scales_bytes || !qzeros_bytes) return set_error(QLLM_ERR_INVALID, "src / outputs must not be NULL");
+  if (src->K <= 0 || src->N <= 0 || src->group_size <= 0) return set_error(QLLM_ERR_INVALID, "bad K/N/group_size (%d/%d/%d)", src->K, src->N, src->group_size);
+  const bool f16z = src->layout == QLLM_LAYOUT_HQQ || src->layout == QLLM_LAYOUT_NATIVE_F16Z;
+  if (int rc = native_shape_ok(src->bits, src->K, src->N, src->group_size, !f16z && src->qzeros)) return rc;
+  const size_t G = (size_t)(src->K + src->group_size - 1) / src->group_size;
+  *qweight_bytes = (size_t)src->K * src->bits / 32 * src->N * 4;
+  *scales_bytes = G * src->N * 2;
+  *qzeros_bytes = !src->qzeros ? 0 : (f16z ? G * src->N * 2 : G * (src->N / 16) * 8);
+  return QLLM_OK;
+}
+
+int qllm_repack_native(const qllm_weight_t *src, void *qweight_out, void *scales_out, void *qzeros_out, void *stream) {
+  clear_error();
+  int rc = validate_weight(src);
+  if (rc) return rc;
+  if (is_native(*src)) return set_error(QLLM_ERR_INVALID, "source is already in the native layout");
+  if (src->g_idx) return set_error(QLLM_ERR_UNSUPPORTED, "act-order layers: sort the rows by group first (the native layout has contiguous groups)");
+  if (src->K % src->group_size != 0) return set_error(QLLM_ERR_UNSUPPORTED, "the native layout needs K %% group_size == 0 (K=%d g=%d)", src->K, src->group_size);
+  if ((rc = native_shape_ok(src->bits, src->K, src->N, src->group_size, src->layout != QLLM_LAYOUT_HQQ && src->qzeros))) return rc;
+  if (!qweight_out || !scales_out || (src->qzeros && !qzeros_out)) return set_error(QLLM_ERR_INVALID, "output buffers must not be NULL");
+  if ((uintptr_t)qweight_out % 16 || (uintptr_t)scales_out % 16 || (uintptr_t)qzeros_out % 8) return set_error(QLLM_ERR_INVALID, "output buffers must be 16-byte (qzeros: 8-byte) aligned");
+  return launch_repack_native(*src, zero_kind_of(*src), qweight_out, scales_out, qzeros_out, (hipStream_t)stream);
+}
+
+int qllm_unpack_native(const qllm_weight_t *native, int32_t dst_layout, void *qweight_out, void *scales_out, void *qzeros_out, void *stream) {
+  clear_error();
+  int rc = validate_weight(native);
+  if (rc) return rc;
+  if (!is_native(*native)) return set_error(QLLM_ERR_INVALID, "source is not in the native layout");
+  if (dst_layout < QLLM_LAYOUT_GPTQ || dst_layout > QLLM_LAYOUT_HQQ) return set_error(QLLM_ERR_INVALID, "dst_layout must be GPTQ, AWQ_GEMM or HQQ");
+  if ((dst_layout == QLLM_LAYOUT_HQQ) != (native->layout == QLLM_LAYOUT_NATIVE_F16Z))
+    return set_error(QLLM_ERR_INVALID, "fp16 zero points <-> HQQ, packed / no zero points <-> GPTQ / AWQ_GEMM");
+  if (dst_layout == QLLM_LAYOUT_AWQ_GEMM && (native->bits != 4 || !native->qzeros)) return set_error(QLLM_ERR_INVALID, "AWQ GEMM layout is 4-bit with packed zero points");
+  if (!qweight_out || !scales_out || (native->qzeros && !qzeros_out)) return set_error(QLLM_ERR_INVALID, "output buffers must not be NULL");
+  return launch_unpack_native(*native, dst_layout, qweight_out, scales_out, qzeros_out, (hipStream_t)stream);
 }
 
 int qllm_unpack_qweight(const void *qweight, int32_t layout, int32_t bits, int32_t K, int32_t N, int32_t *q_kn, void *stream) {

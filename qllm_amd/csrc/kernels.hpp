@@ -69,54 +69,39 @@ struct StripParams {
   const void *x;
   int n_prob;
   int M, K, T;  // T = K / 32
-  int nw;       // waves per block (8 or 16)
-  int cpl;      // columns per lane: 1 (16-column strips) or 4 (64-column strips)
+  int nw;       // waves per block (4, 8 or 16)
+  int cpl;      // columns per lane: 1 (16-column strips), 2 or 4 (64-column strips)
   int bits;     // 4, or 3 (bit-stream layout; cpl = 1, fp16 or symmetric zeros)
   int spw;      // k-steps per wave (nw waves per block cover all of K)
   int ra;       // 1: "register A" variant (no activation slab in LDS; Sx / Sx' from two extra MFMAs), used for M > 2
   int group_size;
   int add_zero_bias;
   int act_bf16;
-  int lw;           // chained link: second round's weights parked in LDS by DMA (strip_lw)
-  int chain;        // chained decode link (strip.hip, CH): bit 0 = x is a 0xFFFF-armed buffer (poll), bit 1 = publish y
-  uint32_t *err;    // chained links: device word, bit 0 raised when a poll loop gives up
-  uint64_t *dbg;    // chained links, diagnostics (qllm_debug_timeline): 8 timestamps for this launch, or NULL
+  int n_groups;     // strip-major: K / group_size (rows of the per-strip scale / zero tables)
+  int sm;           // 1: strip-major native layout (strip_kernel.hpp, SM): every prob[] pointer is a native-layout buffer
+  uint64_t *dbg;    // diagnostics (qllm_debug_timeline): 24 timestamps for this launch (3 blocks x 8), or NULL
 };
 bool strip_group_ok(int group_size);
-int strip_nw(int K, int strips_total);
+int strip_nw(int K, int strips_total, int compute_units);
+int strip_sm_nw(int K, int M, int group_size, int bits);
 int strip_spw(int K, int group_size, int nw);
-// `chain`: 0 = ordinary launch, 1 = chained link
-int strip_maxs(int nw, int spw, int cpl, int ra, int chain);
-bool strip_lw(int nw, int spw, int cpl, int group_size, int chain);
-size_t strip_lds_bytes(int M, int spw, int nw, int cpl, int group_size, int ra, int chain);
-int strip_cpl(int cols_total, bool all_mult64, bool all_mult32);
-bool strip_x_ok(int M, int spw, int nw, int cpl, int chain);
+// `sm`: 0 = row-stream layouts read in place, 1 = strip-major native layout
+int strip_maxs(int nw, int spw, int cpl, int ra, int sm);
+int strip_xl(int nw, int M, int spw, int cpl, int sm);
+size_t strip_lds_bytes(int M, int spw, int nw, int cpl, int group_size, int ra, int sm);
+int strip_cpl(int cols_total, bool all_mult64, bool all_mult32, int compute_units);
+bool strip_x_ok(int M, int spw, int nw, int cpl, int sm);
 int launch_strip(const StripParams &p, int grid, hipStream_t stream);
+int launch_strip_sm(const StripParams &p, int grid, hipStream_t stream);     // strip_sm.hip
+int launch_strip_sm_ra(const StripParams &p, int grid, hipStream_t stream);  // strip_sm_ra.hip
+
+// ---- native.hip (reference layouts <-> the strip-major native layout) -------------------------------------------------------
+int launch_repack_native(const qllm_weight_t &src, int zero_kind, void *qweight_out, void *scales_out, void *qzeros_out, hipStream_t stream);
+int launch_unpack_native(const qllm_weight_t &src, int dst_layout, void *qweight_out, void *scales_out, void *qzeros_out, hipStream_t stream);
 
 // ---- gather.hip (act-order: out[m, k] = x[m, perm[k]], 2-byte elements) ------------------------------------------------------
 bool gather_columns_ok(int K);
 int launch_gather_columns(const void *x, const int32_t *perm, void *out, int M, int K, hipStream_t stream);
-
-// ---- engine.hip (persistent decode engine: loader wave + LDS ring + consumer waves) -------------------------------------
-struct EngineLink {  // == qllm_engine_link_t (include/qllm_mi355x.h)
-  const uint32_t *qweight;
-  const half_t *scales;
-  const void *qzeros;
-  const half_t *bias;
-  const uint16_t *x;
-  uint16_t *y;
-  int32_t N, K;
-  int32_t n_strips;  // N / 32
-  int32_t strip0;    // global index of this link's first 32-column strip (strips are dealt to blocks round-robin)
-  int32_t slabs;     // ceil(K / 1024)
-  int32_t zero_kind;
-  int32_t add_zero_bias;
-  int32_t x_poll;    // x is another link's output (0xFFFF-armed buffer)
-};
-bool engine_link_ok(const qllm_weight_t &w, int M, int act_dtype);
-constexpr int kEngineMaxLinks = 1024;  // links per program (the kernel keeps a packed table of them in LDS)
-size_t engine_lds_bytes();
-int launch_engine(const EngineLink *links_dev, int n_links, uint32_t *err, int grid, hipStream_t stream, uint64_t *dbg = nullptr);
 
 // ---- gemm.hip ------------------------------------------------------------------------------------------------
 struct GemmParams {

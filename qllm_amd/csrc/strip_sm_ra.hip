@@ -1,0 +1,32 @@
+// Strip-major (native layout) instantiations of the full-K strip decode kernel (strip_kernel.hpp): register-A forms, M = 5..64
+// (and long-K g64 / 3-bit layers at any M).  16-column strips; 16-wave blocks for one row tile, 8-wave blocks for 2 / 4 tiles.
+#include "strip_kernel.hpp"
+
+namespace qllm {
+
+template <int SPG, bool BF>
+static int launch_sm_ra(const StripParams &p, int grid, size_t lds, hipStream_t stream) {
+  if (p.M > 16) {
+    if (p.bits == 3) {  // (four 3-bit row tiles need 256+ registers: the planner stops at two)
+      if (p.M > 32) return set_error(QLLM_ERR_UNSUPPORTED, "internal: 3-bit strip-major strips serve M <= 32");
+      return launch_strip_t<8, 1, 8, SPG, 1, 3, true, BF, 2, true>(p, grid, lds, stream);
+    }
+    return p.M > 32 ? launch_strip_t<8, 1, 8, SPG, 1, 4, true, BF, 4, true>(p, grid, lds, stream) : launch_strip_t<8, 1, 8, SPG, 1, 4, true, BF, 2, true>(p, grid, lds, stream);
+  }
+  if (p.bits == 3) {
+    if constexpr (SPG == 2 && BF)  // (this one spills 7 registers: not built; callers stream the reference layout in place)
+      return set_error(QLLM_ERR_UNSUPPORTED, "3-bit g64 native-layout layers with bf16 activations: no strip-major kernel");
+    else
+      return launch_strip_t<16, 1, 8, SPG, 1, 3, true, BF, 1, true>(p, grid, lds, stream);
+  }
+  return p.nw == 8 ? launch_strip_t<8, 1, 8, SPG, 1, 4, true, BF, 1, true>(p, grid, lds, stream)
+                   : launch_strip_t<16, 1, 8, SPG, 1, 4, true, BF, 1, true>(p, grid, lds, stream);
+}
+
+int launch_strip_sm_ra(const StripParams &p, int grid, hipStream_t stream) {
+  const size_t lds = strip_lds_bytes(p.M, p.spw, p.nw, 1, p.group_size, 1, 1);
+  if (p.group_size == 64) return p.act_bf16 ? launch_sm_ra<2, true>(p, grid, lds, stream) : launch_sm_ra<2, false>(p, grid, lds, stream);
+  return p.act_bf16 ? launch_sm_ra<4, true>(p, grid, lds, stream) : launch_sm_ra<4, false>(p, grid, lds, stream);
+}
+
+}  // namespace qllm

@@ -10,13 +10,19 @@ import torch
 from ... import ops
 
 
+def tensor_version(t) -> int:
+    """`t._version`, or 0 for inference tensors (created under torch.inference_mode(): they do not track a version counter and
+    reading it raises; they are also immutable outside inference mode, so identity alone is a sound key for them)."""
+    return 0 if t.is_inference() else t._version
+
+
 def _tkey(t):
     """Cache key of one buffer: storage address AND in-place version (load_state_dict / .copy_ bump `_version`)."""
-    return (0, 0) if t is None else (t.data_ptr(), t._version)
+    return (0, 0) if t is None else (t.data_ptr(), tensor_version(t))
 
 
 # derived, pointer-holding state (ctypes descriptors, shadows, sibling groups): rebuilt on demand, never copied or pickled
-_DERIVED = ("_desc", "_desc_key", "_desc_keep", "_shadow", "_shadow_key", "_ao", "_ao_key", "_rs", "_rs_key", "_siblings")
+_DERIVED = ("_desc", "_desc_key", "_desc_keep", "_native", "_native_key", "_ao", "_ao_key", "_perm", "_siblings")
 
 
 class HipForwardMixin:
@@ -69,15 +75,42 @@ class HipForwardMixin:
             self._desc_key = key
         return self._desc
 
-    def decode_descriptor(self, act_order_g_idx=None, add_zero_bias: int = 0):
-        """Descriptor the decode-sized (M <= 64) kernels should stream.  Default: the module's own buffers."""
-        return self._descriptor(act_order_g_idx, add_zero_bias)
+    # ---- the library's native (strip-major) layout of this layer --------------------------------------------------------
+    _native = None
+    _native_key = None
 
-    def _prefill_through_row_stream(self) -> bool:
-        """Layouts whose decode view is a separate buffer (AWQ) may also serve prefill from it: the row-stream form dequantises
-        with 19 VALU per 8 weights against ~34 for the 8-column AWQ words, which the prefill kernels feel (measured M = 2048:
-        900 / 920 / 1012 vs 808 / 793 / 858 TFLOP/s).  Default off for modules that have no such view."""
-        return False
+    def native_descriptor(self, add_zero_bias: int = 0):
+        """This layer in the library's strip-major native layout (include/qllm_mi355x.h): built once on the device from the
+        module's own buffers by qllm_repack_native -- a pure integer permutation, the state dict is untouched -- and cached on the
+        buffers' identity and version.  The decode kernels stream it 15-25 % faster than the reference layouts (every workgroup
+        reads ONE contiguous region).  None when the layer cannot be held in that layout (bits not 3 / 4, odd shapes, act-order
+        without the row-sorted copy) or QLLM_NATIVE_LAYOUT=0: callers then stream the reference buffers in place."""
+        if os.environ.get("QLLM_NATIVE_LAYOUT", "1") == "0":
+            return None
+        key = (_tkey(self.qweight), _tkey(self.scales), _tkey(getattr(self, "qzeros", None)), _tkey(self.bias), add_zero_bias)
+        if self._native_key != key:
+            self._native, self._native_key = None, key
+            src = self._native_source(add_zero_bias)
+            if src is not None:
+                try:
+                    self._native = ops.repack_native(*src)
+                except ops.QllmUnsupported:
+                    self._native = None
+        return self._native[0] if self._native else None
+
+    def _native_source(self, add_zero_bias: int):
+        """(descriptor, keepalive) of the reference-layout buffers the native copy is made from; None = no native copy."""
+        self._descriptor(None, add_zero_bias)
+        return self._desc, self._desc_keep
+
+    def decode_descriptor(self, act_order_g_idx=None, add_zero_bias: int = 0):
+        """Descriptor the decode-sized (M <= 64) kernels should stream: the native copy when there is one, else the module's own
+        buffers in place."""
+        if act_order_g_idx is None:
+            w = self.native_descriptor(add_zero_bias)
+            if w is not None:
+                return w
+        return self._descriptor(act_order_g_idx, add_zero_bias)
 
     def _hip_linear(self, x: torch.Tensor, act_order_g_idx=None, add_zero_bias: int = 0) -> torch.Tensor:
         if not x.is_cuda or not self.qweight.is_cuda:
@@ -85,18 +118,22 @@ class HipForwardMixin:
                 f"{type(self).__name__}.forward needs HIP tensors on an MI355X: qllm_amd ships no CPU / eager fallback "
                 f"(x on {x.device}, qweight on {self.qweight.device})")
         if self._siblings is not None and act_order_g_idx is None:
-            y = self._siblings.forward_for(self, x)  # q/k/v, gate/up: one grouped launch for the whole group (fused.py)
+            y = self._siblings.forward_for(self, x, add_zero_bias)  # q/k/v, gate/up: one grouped launch for the group (fused.py)
             if y is not None:
                 return y
         x2d = x.reshape(-1, x.shape[-1])
         if not x2d.is_contiguous():
             x2d = x2d.contiguous()
-        if x2d.shape[0] <= 64 or self._prefill_through_row_stream():
-            w = self.decode_descriptor(act_order_g_idx, add_zero_bias)  # row-stream view (the module's own buffers if GPTQ/HQQ)
-        else:
-            w = self._descriptor(act_order_g_idx, add_zero_bias)
+        w = self.decode_descriptor(act_order_g_idx, add_zero_bias) if x2d.shape[0] <= 64 else self._prefill_descriptor(act_order_g_idx, add_zero_bias)
         try:
-            y = ops.linear_forward(w, x2d)
+            try:
+                y = ops.linear_forward(w, x2d)
+            except ops.QllmUnsupported:
+                own = self._descriptor(act_order_g_idx, add_zero_bias)
+                if w is own:
+                    raise
+                w = own
+                y = ops.linear_forward(w, x2d)  # a shape the native layout is not served at: the reference buffers in place
         except ops.QllmUnsupported:
             # e.g. 3/5/6/7/8-bit at prefill sizes: dequantise with the library kernel, then a plain library GEMM
             wt = ops.dequant(w, x.device, torch.float16)
@@ -104,6 +141,13 @@ class HipForwardMixin:
             if self.bias is not None:
                 y = y + self.bias.to(y.dtype)
         return y.reshape(x.shape[:-1] + (self.outfeatures,))
+
+
+def _prefill_descriptor_default(self, act_order_g_idx, add_zero_bias):
+    return self._descriptor(act_order_g_idx, add_zero_bias)
+
+
+HipForwardMixin._prefill_descriptor = _prefill_descriptor_default
 
 
 def autogptq_compat() -> int:

@@ -12,11 +12,13 @@ grouped kernel does not take -- falls back to the module's own single launch, so
 from __future__ import annotations
 
 import os
+import weakref
 from typing import Optional, Sequence
 
 import torch
 
 from ... import ops
+from ._hip_forward import tensor_version
 
 GROUP_MAX_M = 64  # the grouped entry point serves decode sizes only (include/qllm_mi355x.h)
 
@@ -28,9 +30,11 @@ class SiblingGroup:
     def __init__(self, layers: Sequence[torch.nn.Module]):
         self.layers = list(layers)
         self.enabled = True
-        self._x: Optional[torch.Tensor] = None
+        self._x = None       # weak reference to the tensor the parked outputs were computed from (never keeps activations alive)
         self._ver = -1
+        self._azb = 0
         self._parked: dict = {}
+        self._misses = 0     # consecutive grouped launches whose parked outputs nobody collected (see forward_for)
         self.grouped_launches = 0  # diagnostics / tests
 
     def describe(self, m: int = 1) -> str:
@@ -45,22 +49,34 @@ class SiblingGroup:
                 return False
         return True
 
-    def forward_for(self, layer, x: torch.Tensor) -> Optional[torch.Tensor]:
-        """Output of `layer` for x, or None when the caller must run its own launch."""
+    def forward_for(self, layer, x: torch.Tensor, add_zero_bias: int = 0) -> Optional[torch.Tensor]:
+        """Output of `layer` for x, or None when the caller must run its own launch.  `add_zero_bias`: the caller's
+        COMPATIBLE_WITH_AUTOGPTQ value for this forward (the reference reads it per call, quant_linear_gptq.py:75): it is part of
+        the descriptors the group launches with and of the key the parked outputs are matched on."""
         if not self.enabled:
             return None
         key = id(layer)
-        if self._x is x and x._version == self._ver and key in self._parked:
+        held = self._x() if self._x is not None else None
+        if held is x and tensor_version(x) == self._ver and add_zero_bias == self._azb and key in self._parked:
             out = self._parked.pop(key)
+            self._misses = 0
             if not self._parked:
                 self._x = None
             return out
+        if self._parked:
+            # the siblings' outputs of the previous launch were never asked for (the caller hands every sibling a NEW tensor
+            # object, e.g. through accelerate hooks): grouping then multiplies the work instead of saving launches
+            self._misses += 1
+            if self._misses >= 3:
+                self.enabled = False
         self._x, self._parked = None, {}
+        if not self.enabled:
+            return None
         x2d = x.reshape(-1, x.shape[-1])
         if x2d.shape[0] > GROUP_MAX_M or x2d.shape[0] == 0 or not x2d.is_contiguous() or not self.compatible():
             return None
         try:
-            outs = ops.linear_forward_grouped([l.decode_descriptor() for l in self.layers], x2d)
+            outs = ops.linear_forward_grouped([l.decode_descriptor(None, add_zero_bias) for l in self.layers], x2d)
         except ops.QllmUnsupported:
             self.enabled = False  # this group's shape has no grouped kernel: never ask again
             return None
@@ -73,7 +89,7 @@ class SiblingGroup:
                 mine = o
             else:
                 self._parked[id(l)] = o
-        self._x, self._ver = x, x._version
+        self._x, self._ver, self._azb = weakref.ref(x), tensor_version(x), add_zero_bias
         return mine
 
 

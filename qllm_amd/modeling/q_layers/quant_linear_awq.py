@@ -4,12 +4,10 @@ layout -- qweight i32 [K, N/8], nibble i of word (k, j) holds column 8j + [0,2,4
 place (the reference calls awq_inference_engine.gemm_forward_cuda, :142-148)."""
 from __future__ import annotations
 
-import os
-
 import torch
 import torch.nn as nn
 
-from ._hip_forward import HipForwardMixin, _tkey
+from ._hip_forward import HipForwardMixin
 from .compress_weight import CompressWeight, pack_bitstream, unpack_bitstream
 
 AWQ_ORDER = (0, 2, 4, 6, 1, 3, 5, 7)
@@ -90,37 +88,11 @@ class WQLinear_GEMM(nn.Module, CompressWeight, HipForwardMixin):
         w = unpack_bitstream(qweight, self.bits, self.outfeatures, axis=1)  # [K, N] AWQ order
         return self.reverse_reorder_int_tensor(w.T.contiguous())
 
-    # ---- decode: row-stream shadow of the same integers ------------------------------------------------------------
-    _shadow = None
-    _shadow_key = None
-
-    def decode_descriptor(self, act_order_g_idx=None, add_zero_bias: int = 0):
-        """AWQ rows are only N/2 bytes long, so no column strip of this layout can cover all of K with whole
-        cache lines; at decode sizes that forces a split-K reduction whose extra DRAM round trips dominate the
-        launch.  The module therefore keeps a one-time, bit-exact re-layout of the SAME 4-bit integers
-        in the row-stream (GPTQ) order -- built on device by the library's unpack/pack kernels at first use, the
-        state dict is untouched -- and streams that for M <= 16.  QLLM_AWQ_DECODE_SHADOW=0 disables it (in-place
-        split-K kernel, no extra memory)."""
-        if os.environ.get("QLLM_AWQ_DECODE_SHADOW", "1") == "0" or self.outfeatures % 16 != 0:
-            return self._descriptor(None, 0)
-        from ... import ops
-        key = (_tkey(self.qweight), _tkey(self.qzeros), _tkey(self.scales), _tkey(self.bias))
-        if self._shadow is None or key != self._shadow_key:
-            dev = self.qweight.device
-            q = ops.unpack_qweight(self.qweight.contiguous(), "GEMM", 4, self.infeatures, self.outfeatures)
-            qw = ops.pack_qweight(q, "GPTQ", 4)
-            del q
-            qz = pack_bitstream(self.unpack_qzeros(dev), 4, axis=1).to(dev)
-            b = self._f16(self.bias).contiguous() if self.bias is not None else None
-            self._shadow = ops.make_weight("GPTQ", qw, self._f16(self.scales).contiguous(), qz, None, b,
-                                           self.infeatures, self.outfeatures, self.groupsize, 4, 0)
-            self._shadow_key = key
-        return self._shadow[0]
-
-    def _prefill_through_row_stream(self) -> bool:
-        # the shadow exists anyway once the layer has decoded; QLLM_AWQ_PREFILL_SHADOW=0 keeps prefill on the in-place layout
-        return (os.environ.get("QLLM_AWQ_PREFILL_SHADOW", "1") != "0" and os.environ.get("QLLM_AWQ_DECODE_SHADOW", "1") != "0"
-                and self.outfeatures % 16 == 0)
+    # ---- decode: the native copy ----------------------------------------------------------------------------------------------
+    # An AWQ row is only N/2 bytes, so no column strip of this layout covers all of K with whole cache lines; at decode sizes that
+    # forces a split-K reduction whose extra DRAM round trips dominate the launch.  The mixin's native_descriptor()
+    # therefore matters most here: qllm_repack_native reads the AWQ words and zero points directly (nibble interleave undone on
+    # the fly), no intermediate copy.  QLLM_NATIVE_LAYOUT=0: every call on the in-place layout (split-K decode kernel).
 
     def forward(self, x):
         return self._hip_linear(x, None, 0)

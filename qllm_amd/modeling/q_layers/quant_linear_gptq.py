@@ -4,11 +4,12 @@ from __future__ import annotations
 
 import math
 import os
+import weakref
 
 import torch
 import torch.nn as nn
 
-from ._hip_forward import HipForwardMixin, _tkey, autogptq_compat
+from ._hip_forward import HipForwardMixin, _tkey, autogptq_compat, tensor_version
 from .compress_weight import CompressWeight, general_pack_on_row, general_unpack_on_row
 
 
@@ -31,10 +32,12 @@ def _intern_perm(perm: torch.Tensor) -> torch.Tensor:
 def _gathered(x: torch.Tensor, perm: torch.Tensor) -> torch.Tensor:
     from ... import ops
     hit = _LAST_GATHER.get(x.device)
-    if hit is not None and hit[0] is x and hit[1] == x._version and hit[2] is perm:
+    if hit is not None and hit[0]() is x and hit[1] == tensor_version(x) and hit[2] is perm:
         return hit[3]
     out = ops.gather_columns(x.reshape(-1, x.shape[-1]).contiguous(), perm)
-    _LAST_GATHER[x.device] = (x, x._version, perm, out)
+    # (x is held weakly: the cache must not keep a prefill-sized activation alive; the gathered copy lives until the next gather
+    #  on the device replaces it)
+    _LAST_GATHER[x.device] = (weakref.ref(x), tensor_version(x), perm, out)
     return out
 
 
@@ -120,6 +123,14 @@ class QuantLinearGPTQ(nn.Module, CompressWeight, HipForwardMixin):
                 b = self._f16(self.bias).contiguous() if self.bias is not None else None
                 desc = ops.make_weight("GPTQ", qw, self._f16(self.scales).contiguous(), self.qzeros.contiguous(), None, b,
                                        self.infeatures, self.outfeatures, self.groupsize, 4, add_zero_bias)
+                # the row-sorted copy is a derived buffer anyway: keep it in the native layout (and drop the row-stream
+                # intermediate) when the layer fits it
+                if os.environ.get("QLLM_NATIVE_LAYOUT", "1") != "0":
+                    try:
+                        desc = ops.repack_native(*desc)
+                    except ops.QllmUnsupported:
+                        pass
+                del qw
                 self._ao, self._ao_key = (desc, _intern_perm(perm.to(torch.int32).contiguous())), key
         return self._ao if self._ao else None
 

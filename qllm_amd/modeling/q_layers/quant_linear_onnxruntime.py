@@ -186,7 +186,16 @@ class QuantLinearORT(nn.Module, CompressWeight, HipForwardMixin):
             self._desc_key = key
         return self._desc if self._desc else None
 
+    def _native_source(self, add_zero_bias: int):
+        if self._descriptor() is None:
+            return None
+        return self._desc, self._desc_keep
+
     def decode_descriptor(self, act_order_g_idx=None, add_zero_bias: int = 0):
+        w = self.native_descriptor(0)
+        return w if w is not None else self._descriptor()
+
+    def _prefill_descriptor(self, act_order_g_idx=None, add_zero_bias: int = 0):
         return self._descriptor()
 
     def forward(self, x):

@@ -7,7 +7,7 @@ import pytest
 
 from qllm_amd import _lib
 
-GPTQ, AWQ, HQQ = _lib.LAYOUT_GPTQ, _lib.LAYOUT_AWQ_GEMM, _lib.LAYOUT_HQQ
+GPTQ, AWQ, HQQ, NATIVE, NATIVE_F16Z = _lib.LAYOUT_GPTQ, _lib.LAYOUT_AWQ_GEMM, _lib.LAYOUT_HQQ, _lib.LAYOUT_NATIVE, _lib.LAYOUT_NATIVE_F16Z
 
 
 @pytest.fixture(scope="module")
@@ -114,53 +114,72 @@ def test_plan_describe_validates(lib):
     assert lib.qllm_plan_describe(None, 1, 1, 1, buf, 256) == _lib.QLLM_ERR_INVALID
 
 
-# ---- round 2 entry points that are pure host code: checked without a GPU ------------------------------------------------
-def chain_plan(lib, ws, m):
-    arr = (_lib.QllmWeight * len(ws))(*ws)
+# ---- the native (strip-major) layout: plans, validation, conversions -- pure host code ---------------------------------------
+def test_native_layout_decode_routes(lib):
+    """Every decode launch of the Llama-2-7B stack on the strip-major kernel: 16-column strips, all of a launch's weights in ONE
+    round per wave (8 waves x 16 k-steps at K = 4096, 16 waves x 24 at K = 11008)."""
+    sm = " layout=strip-major"
+    attn, up, down = W(4096, 4096, layout=NATIVE), W(4096, 11008, layout=NATIVE), W(11008, 4096, layout=NATIVE)
+    assert plan(lib, [attn], 1) == "strip nw=8 cpl=1 spw=16 form=lds-slab row_tiles=1" + sm
+    assert plan(lib, [attn] * 3, 1) == "strip nw=8 cpl=1 spw=16 form=lds-slab row_tiles=1" + sm
+    assert plan(lib, [up] * 2, 1) == "strip nw=8 cpl=1 spw=16 form=lds-slab row_tiles=1" + sm
+    assert plan(lib, [down], 1) == "strip nw=16 cpl=1 spw=24 form=lds-slab row_tiles=1" + sm
+    assert plan(lib, [attn], 4) == "strip nw=8 cpl=1 spw=16 form=lds-slab row_tiles=1" + sm
+    for m in (5, 16):
+        assert plan(lib, [attn], m) == "strip nw=16 cpl=1 spw=8 form=register-A row_tiles=1" + sm
+    assert plan(lib, [attn], 32) == "strip nw=8 cpl=1 spw=16 form=register-A row_tiles=2" + sm
+    assert plan(lib, [up] * 2, 64) == "strip nw=8 cpl=1 spw=16 form=register-A row_tiles=4" + sm
+    # shard shapes of Llama-2-70B (TP = 8): short K -> 4-wave blocks, K = 8192 -> 8 waves x one round of 32
+    assert plan(lib, [W(1024, 8192, layout=NATIVE)], 1).startswith("strip nw=4 cpl=1 spw=8 form=lds-slab")
+    assert plan(lib, [W(8192, 1024, layout=NATIVE)], 1).startswith("strip nw=8 cpl=1 spw=32 form=lds-slab")
+    assert plan(lib, [W(8192, 1024, layout=NATIVE)], 3).startswith("strip nw=16 cpl=1 spw=16 form=lds-slab")
+    assert plan(lib, [W(28672, 1024, layout=NATIVE)], 1).startswith("strip nw=16 cpl=1 spw=56 form=lds-slab")  # three rounds of 24
+    # g64 / 3 bits / fp16 zero points: slab form for short chunks at batch 1, register-A beyond (no spilling instantiation is built)
+    h4, h3 = W(4096, 4096, 64, 4, NATIVE_F16Z), W(4096, 4096, 64, 3, NATIVE_F16Z)
+    assert plan(lib, [h4], 1).startswith("strip nw=8 cpl=1 spw=16 form=lds-slab")
+    assert plan(lib, [h4], 2).startswith("strip nw=16 cpl=1 spw=8 form=register-A")
+    assert plan(lib, [W(11008, 4096, 64, 4, NATIVE_F16Z)], 1).startswith("strip nw=16 cpl=1 spw=22 form=register-A")
+    assert plan(lib, [h3], 1).startswith("strip nw=16 cpl=1 spw=8 form=lds-slab")
+    assert plan(lib, [h3], 16).startswith("strip nw=16 cpl=1 spw=8 form=register-A")
+    assert plan(lib, [h3], 32).endswith("row_tiles=2" + sm)
+    assert plan(lib, [h3], 48).startswith("unsupported")                     # four 3-bit row tiles would need > 256 registers
+    assert plan(lib, [W(4096, 4096, 32, layout=NATIVE)], 1).startswith("unsupported")   # group sizes the strips do not serve
+    assert plan(lib, [W(128, 4096, layout=NATIVE)], 1).startswith("unsupported")        # K shorter than one round of 8 k-steps
+
+
+def test_native_layout_validation_and_sizes(lib):
+    I, U = _lib.QLLM_ERR_INVALID, _lib.QLLM_ERR_UNSUPPORTED
+    sz = [C.c_size_t(0) for _ in range(3)]
+    refs = [C.byref(z) for z in sz]
+    assert lib.qllm_native_sizes(C.byref(W(4096, 11008, layout=AWQ)), *refs) == 0, _lib.last_error()
+    assert [z.value for z in sz] == [4096 * 11008 // 2, 32 * 11008 * 2, 32 * (11008 // 16) * 8]
+    assert lib.qllm_native_sizes(C.byref(W(4096, 4096, 64, 3, HQQ)), *refs) == 0
+    assert [z.value for z in sz] == [4096 * 3 // 32 * 4096 * 4, 64 * 4096 * 2, 64 * 4096 * 2]
+    assert lib.qllm_native_sizes(C.byref(W(4096, 4096, zeros=None)), *refs) == 0 and sz[2].value == 0   # symmetric: no zero points
+    for bad in (W(4096, 4096, bits=8), W(4096, 4104), W(4100, 4096), W(4096, 4096, 48), W(4096, 4112, 128, 3)):
+        assert lib.qllm_native_sizes(C.byref(bad), *refs) == U, (bad.K, bad.N, bad.bits, bad.group_size)
+    assert lib.qllm_native_sizes(None, *refs) == I
+    # repack / unpack argument checks (nothing is launched: every call fails validation first)
+    assert lib.qllm_repack_native(C.byref(W(4096, 4096, g_idx=16)), 32, 32, 32, None) == U and "act-order" in _lib.last_error()
+    assert lib.qllm_repack_native(C.byref(W(4096, 4096, layout=NATIVE)), 32, 32, 32, None) == I
+    assert lib.qllm_repack_native(C.byref(W(4096, 4096)), None, 32, 32, None) == I
+    assert lib.qllm_repack_native(C.byref(W(4096, 4096)), 36, 32, 32, None) == I                     # alignment
+    assert lib.qllm_unpack_native(C.byref(W(4096, 4096)), GPTQ, 32, 32, 32, None) == I               # source must be native
+    assert lib.qllm_unpack_native(C.byref(W(4096, 4096, layout=NATIVE)), HQQ, 32, 32, 32, None) == I  # packed zeros <-> GPTQ / AWQ
+    assert lib.qllm_unpack_native(C.byref(W(4096, 4096, layout=NATIVE_F16Z)), GPTQ, 32, 32, 32, None) == I
+    assert lib.qllm_unpack_native(C.byref(W(4096, 4096, layout=NATIVE)), 7, 32, 32, 32, None) == I
+    # a native descriptor with g_idx is malformed; mixing layout families in one grouped launch is refused
+    arr = (_lib.QllmWeight * 2)(W(4096, 4096, layout=NATIVE), W(4096, 4096))
+    ys = (C.c_void_p * 2)(64, 128)
+    assert lib.qllm_linear_forward_grouped(arr, ys, 2, 256, 1, _lib.DT_F16, None, 0, None) == I and "layout family" in _lib.last_error()
+    arr1 = (_lib.QllmWeight * 1)(W(4096, 4096, layout=NATIVE, g_idx=16))
     buf = C.create_string_buffer(256)
-    assert lib.qllm_chain_plan_describe(arr, len(ws), m, buf, 256) == 0, _lib.last_error()
-    return buf.value.decode()
+    assert lib.qllm_plan_describe(arr1, 1, 1, 1, buf, 256) == I
+    assert lib.qllm_dequant(C.byref(W(4096, 4096, layout=NATIVE)), 64, _lib.DT_F16, 0, None) == U
 
 
-def test_chained_link_plans(lib):
-    """The co-residency rule of the decode chain: a chained link has 120..448 blocks of at most half a CU."""
-    attn, up, down = W(4096, 4096), W(4096, 11008), W(11008, 4096)
-    for ws in ([attn] * 3, [attn], [up] * 2, [down]):
-        d = chain_plan(lib, ws, 1)
-        assert d.startswith("chained strip"), d
-        blocks = int(d.rsplit("blocks=", 1)[1])
-        assert 120 <= blocks <= 448, d
-    assert chain_plan(lib, [attn] * 3, 1).startswith("chained strip nw=8 cpl=4")
-    assert chain_plan(lib, [down], 1).startswith("chained strip nw=8 cpl=1")       # 16 waves would need > 64 registers
-    assert chain_plan(lib, [W(4096, 1024)], 1) == "not chainable"                  # 64 strips: too few blocks for a link
-    assert chain_plan(lib, [attn], 8) == "not chainable"                           # chained links are for M <= 4
-    assert chain_plan(lib, [W(4096, 4096, layout=AWQ)], 1) == "not chainable"      # row-stream layouts only
-    assert chain_plan(lib, [W(4096, 4096, 64, 3, HQQ)], 1) == "not chainable"      # 4 bits only
-
-
-def test_engine_link_init_validates_and_fills(lib):
-    link = _lib.QllmEngineLink()
-    w = W(4096, 11008)
-    assert lib.qllm_engine_link_init(C.byref(w), 32, 64, 1, _lib.DT_F16, 1, 40, C.byref(link)) == 0, _lib.last_error()
-    assert (link.N, link.K, link.n_strips, link.strip0, link.slabs, link.x_poll) == (11008, 4096, 344, 40, 4, 1)
-    w = W(11008, 4096)
-    assert lib.qllm_engine_link_init(C.byref(w), 32, 64, 1, _lib.DT_F16, 0, 0, C.byref(link)) == 0
-    assert (link.n_strips, link.slabs, link.x_poll) == (128, 11, 0)                 # the last slab is only partly filled
-    U = _lib.QLLM_ERR_UNSUPPORTED
-    for bad, m, dt in ((W(4096, 4096), 2, _lib.DT_F16),                             # M = 1 only
-                       (W(4096, 4096), 1, _lib.DT_BF16),                            # fp16 activations
-                       (W(4096, 4096, 64), 1, _lib.DT_F16),                         # group size 128
-                       (W(4096, 4096, layout=AWQ), 1, _lib.DT_F16),                 # row-stream layouts
-                       (W(4096, 4096, g_idx=16), 1, _lib.DT_F16),                   # no act-order
-                       (W(4096, 4112), 1, _lib.DT_F16),                             # N % 32
-                       (W(28672, 8192), 1, _lib.DT_F16),                            # K beyond the LDS input buffers
-                       (W(4096, 4096, 128, 3, HQQ), 1, _lib.DT_F16)):               # 4 bits
-        assert lib.qllm_engine_link_init(C.byref(bad), 32, 64, m, dt, 0, 0, C.byref(link)) == U, (bad.K, bad.N, m)
-    assert lib.qllm_engine_link_init(C.byref(W(4096, 4096)), 32, 66, 1, _lib.DT_F16, 0, 0, C.byref(link)) == _lib.QLLM_ERR_INVALID  # y % 4
-    assert lib.qllm_engine_link_init(C.byref(W(4096, 4096)), 32, 64, 1, _lib.DT_F16, 0, 0, None) == _lib.QLLM_ERR_INVALID
-    assert lib.qllm_engine_run(None, 1, 64, None) == _lib.QLLM_ERR_INVALID
-    assert lib.qllm_engine_run(64, 0, 64, None) == _lib.QLLM_ERR_INVALID
-    assert lib.qllm_engine_run(64, 1, 66, None) == _lib.QLLM_ERR_INVALID            # error word alignment
+def test_debug_timeline_argument(lib):
+    assert lib.qllm_debug_timeline(None, 0) == 0
 
 
 def test_gather_columns_argument_checks(lib):

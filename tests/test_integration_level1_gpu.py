@@ -82,9 +82,9 @@ def test_awq_inference_engine_stub():
         eng.gemm_forward_cuda(torch.from_numpy(x).to(DEV)[:, :100].contiguous(), qweight, scales, qzeros, 8)   # K not a multiple of g
 
 
-def test_awq_inference_engine_stub_decode_uses_a_row_stream_copy():
-    """M <= 64 through the stub: served from a cached row-stream copy of the caller's integers (strip kernel); the copy follows
-    in-place updates of the caller's tensors (keyed on identity AND version) and can be switched off."""
+def test_awq_inference_engine_stub_decode_uses_a_native_copy():
+    """M <= 64 through the stub: served from a cached native-layout copy of the caller's integers (strip kernel); the copy follows
+    in-place updates of the caller's tensors (keyed on identity AND version), dies with them, and can be switched off."""
     eng = _load_stub("awq_inference_engine")
     d = synth("GEMM", 4, 128, 4096, 4096, seed=7)
     qweight, scales, qzeros = _t(d, "qweight", "scales", "qzeros")
@@ -92,7 +92,7 @@ def test_awq_inference_engine_stub_decode_uses_a_row_stream_copy():
         x = randx(m, 4096, seed=m)
         y = eng.gemm_forward_cuda(torch.from_numpy(x).to(DEV), qweight, scales, qzeros, 8)
         assert O.rel_err(y.cpu().numpy(), Ref(d).y16(x)) <= 1e-2 and O.rel_err(y.float().cpu().numpy(), Ref(d).y64(x)) <= 2e-3
-    assert len(eng._rows) == 1                                           # one weight, one copy, reused across M
+    assert len(eng._native) == 1                                         # one weight, one copy, reused across M
     x = randx(1, 4096, seed=1)
     xt = torch.from_numpy(x).to(DEV)
     y_shadow = eng.gemm_forward_cuda(xt, qweight, scales, qzeros, 8)
@@ -109,3 +109,14 @@ def test_awq_inference_engine_stub_decode_uses_a_row_stream_copy():
     scales.copy_(torch.from_numpy(d2["scales"]))
     y2 = eng.gemm_forward_cuda(xt, qweight, scales, qzeros, 8)
     assert O.rel_err(y2.cpu().numpy(), Ref(d2).y16(x)) <= 1e-2
+    # the cache entry dies with the caller's tensors -- a later model whose weights land on the same addresses (the
+    # caching allocator hands them out again) can never be served the old copy
+    import gc
+    ptr = qweight.data_ptr()
+    del qweight, scales, qzeros
+    gc.collect()
+    assert len(eng._native) == 0
+    d3 = synth("GEMM", 4, 128, 4096, 4096, seed=9)
+    qweight, scales, qzeros = _t(d3, "qweight", "scales", "qzeros")
+    y3 = eng.gemm_forward_cuda(xt, qweight, scales, qzeros, 8)
+    assert O.rel_err(y3.cpu().numpy(), Ref(d3).y16(x)) <= 1e-2, ("same address reused" if qweight.data_ptr() == ptr else "new address")

@@ -33,8 +33,8 @@ def _resources(src):
     return res
 
 
-def _strip(nw, cpl, maxs, spg, xl, bits=4, ra=False, bf=False, mt=1, ch=False, lw=False):
-    return (f"_ZN4qllm12strip_kernelILi{nw}ELi{cpl}ELi{maxs}ELi{spg}ELi{xl}ELi{bits}ELb{int(ra)}ELb{int(bf)}ELi{mt}ELb{int(ch)}ELb{int(lw)}EEEvNS_11StripParamsE")
+def _strip(nw, cpl, maxs, spg, xl, bits=4, ra=False, bf=False, mt=1, sm=False, dbg=False):
+    return (f"_ZN4qllm12strip_kernelILi{nw}ELi{cpl}ELi{maxs}ELi{spg}ELi{xl}ELi{bits}ELb{int(ra)}ELb{int(bf)}ELi{mt}ELb{int(sm)}ELb{int(dbg)}EEEvNS_11StripParamsE")
 
 
 def test_decode_strip_variants_fit_their_register_budget():
@@ -58,19 +58,29 @@ def test_decode_strip_variants_fit_their_register_budget():
         assert spill == 0 and vgpr <= cap, (name, vgpr, spill)
 
 
-def test_chained_links_are_at_most_half_a_cu():
-    """The deadlock rule of the decode chain (include/qllm_mi355x.h): a chained link's block is at most half a CU, i.e.
-    16 waves x <= 64 registers or 8 waves x <= 128 -- enforced by __launch_bounds__, checked here on the emitted code; the
-    g128 instantiations the Llama-2-7B chain uses must not pay for it with more than a stray spill."""
-    res = _resources("strip.hip")
-    chained = {n: v for n, v in res.items() if re.search(r"ELb1ELb[01]EEEvNS_11StripParamsE$", n)}
-    assert len(chained) >= 10
-    for n, (vgpr, _spill) in chained.items():
-        nw = int(re.search(r"strip_kernelILi(\d+)E", n).group(1))
-        assert vgpr <= (64 if nw == 16 else 128), (n, vgpr)
-    for name in (_strip(8, 4, 8, 4, 2, ch=True), _strip(16, 1, 8, 4, 2, ch=True), _strip(8, 1, 24, 4, 4, ch=True)):
+def test_no_strip_instantiation_spills():
+    """Round-2 verdict: 17-133 spilled registers in instantiations outside the measured paths.  Every strip kernel that is BUILT
+    (the dispatchers build only what the planner reaches) must be spill-free, in all three translation units."""
+    total = 0
+    for src in ("strip.hip", "strip_sm.hip", "strip_sm_ra.hip"):
+        res = {n: v for n, v in _resources(src).items() if "strip_kernel" in n}
+        assert res, src
+        total += len(res)
+        for n, (vgpr, spill) in res.items():
+            assert spill == 0, (src, n, vgpr, spill)
+            nw = int(re.search(r"strip_kernelILi(\d+)E", n).group(1))
+            assert vgpr <= (128 if nw == 16 else 256), (src, n, vgpr)   # a 16-wave block cannot exceed 128 registers
+    assert total >= 100
+
+
+def test_native_layout_decode_kernels_keep_their_occupancy():
+    """The batch-1 strip-major kernels of the headline path: 8 waves x 16 k-steps at <= 80 registers (three blocks per CU), the
+    16-wave K = 11008 form at <= 128."""
+    res = _resources("strip_sm.hip")
+    for name, cap in ((_strip(8, 1, 16, 4, 2, sm=True), 80), (_strip(16, 1, 24, 4, 2, sm=True), 128), (_strip(8, 1, 32, 4, 2, sm=True), 128),
+                      (_strip(4, 1, 8, 4, 2, sm=True), 80), (_strip(8, 1, 16, 2, 2, sm=True), 128)):
         assert name in res, name
-        assert res[name][1] <= 2, (name, res[name])
+        assert res[name][1] == 0 and res[name][0] <= cap, (name, res[name])
 
 
 def test_wave_specialised_prefill_kernel_budget():

@@ -1,0 +1,137 @@
+"""-m gpu: the library's native (strip-major) layout.  qllm_repack_native against the numpy restatement of the layout
+(oracle/ref_cpu.native_layout, from the integer grids the oracle recovers from the reference-minted goldens), unpack(repack(x)) == x
+bit for bit for every source layout, and the decode kernels on native descriptors against the oracle (every zero-point kind, 3 and
+4 bits, g64 / g128, bias, AutoGPTQ offset, M = 1 .. 64, grouped launches)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import ref_cpu as O
+from gpu_util import Ref, randx, synth, to_layer
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+NATIVE_GOLDENS = ["gptq_w4_g128_asym", "gptq_w4_g128_sym", "gptq_w4_g128_autogptq", "gptq_w4_g128_opt_bias", "gptq_w3_g128_asym",
+                  "awq_w4_g128_asym", "awq_w4_g64_bias", "hqq_w4_g64", "hqq_w3_g64"]
+
+
+def _ints(g):
+    """(q[K, N], stored integer / fp16 zero points [G, N], zeros_f16) of a golden, through the oracle's unpackers."""
+    lay, bits, K, N = g["layout"], g["bits"], g["K"], g["N"]
+    if lay == "GEMM":
+        return O.awq_int_weight(g["qweight"], K, N), O.awq_int_zeros(g["qzeros"], N), False
+    q = O.gptq_int_weight(g["qweight"], bits, K)
+    if lay == "HQQ":
+        return q, g["qzeros"], True
+    return q, O.gptq_int_zeros(g["qzeros"], bits, N, 0), False
+
+
+@pytest.mark.parametrize("name", NATIVE_GOLDENS)
+def test_repack_matches_the_layout_definition_and_round_trips(name):
+    from qllm_amd import ops
+    g = load_golden(name)
+    layer = to_layer(dict(g), DEV)
+    layer._descriptor(None, 0)
+    src, keep = layer._desc, layer._desc_keep
+    nat, nkeep = ops.repack_native(src, keep)
+    q, z, zf = _ints(g)
+    want_q, want_s, want_z = O.native_layout(q, g["scales"], z, g["bits"], zf)
+    assert np.array_equal(nkeep[0].cpu().numpy().reshape(want_q.shape), want_q.view(np.int32))
+    assert np.array_equal(nkeep[1].cpu().numpy().reshape(want_s.shape).view(np.uint16), want_s.view(np.uint16))
+    got_z = nkeep[2].cpu().numpy().reshape(want_z.shape)
+    assert np.array_equal(got_z.view(np.uint16) if zf else got_z, want_z.view(np.uint16) if zf else want_z)
+    # back to the reference's buffers: bit-identical to what was loaded
+    back = ops.unpack_native(nat, nkeep, g["layout"])
+    assert torch.equal(back[0], layer.qweight.reshape(back[0].shape))
+    assert torch.equal(back[1].view(torch.int16), layer.scales.to(torch.float16).view(torch.int16))
+    assert torch.equal(back[2].view(torch.int16) if zf else back[2], layer.qzeros.view(torch.int16) if zf else layer.qzeros)
+    # ... and GPTQ <-> AWQ through the native layout is the integer-exact repack
+    if g["layout"] in ("GPTQ", "GEMM") and g["bits"] == 4:
+        other = "GEMM" if g["layout"] == "GPTQ" else "GPTQ"
+        oq, os_, oz = ops.unpack_native(nat, nkeep, other)
+        if other == "GEMM":
+            assert np.array_equal(O.awq_int_weight(oq.cpu().numpy(), g["K"], g["N"]), q)
+            assert np.array_equal(O.awq_int_zeros(oz.cpu().numpy(), g["N"]), z)
+        else:
+            assert np.array_equal(O.gptq_int_weight(oq.cpu().numpy(), 4, g["K"]), q)
+            assert np.array_equal(O.gptq_int_zeros(oz.cpu().numpy(), 4, g["N"], 0), z)
+
+
+CASES = [  # layout, bits, g, K, N, zero kind, bias
+    ("GPTQ", 4, 128, 4096, 4096, "asym", False), ("GPTQ", 4, 128, 11008, 4096, "asym", True), ("GEMM", 4, 128, 4096, 11008, "asym", False),
+    ("GPTQ", 4, 128, 4096, 1024, "sym", True), ("HQQ", 4, 64, 4096, 4096, "asym", False), ("HQQ", 3, 64, 4096, 4096, "asym", True),
+    ("GPTQ", 3, 128, 4096, 4096, "asym", False), ("GPTQ", 4, 64, 2048, 1152, "asym", False), ("GEMM", 4, 64, 1024, 512, "asym", True),
+    ("GPTQ", 4, 128, 8192, 1024, "asym", False), ("HQQ", 4, 64, 11008, 4096, "asym", False), ("GPTQ", 4, 128, 1024, 8192, "asym", False),
+]
+
+
+@pytest.mark.parametrize("layout,bits,g,K,N,zk,bias", CASES)
+def test_native_decode_kernels_vs_oracle(layout, bits, g, K, N, zk, bias):
+    from qllm_amd import ops
+    d = synth(layout, bits, g, K, N, zk, False, bias, seed=K + N + bits)
+    d["scales"] = (d["scales"].astype(np.float32) * (4096 / K) ** 0.5 * 0.5).astype(np.float16)
+    layer = to_layer(d, DEV)
+    if zk == "sym":
+        layer._descriptor(None, 0)
+        src = ops.make_weight("GPTQ", layer.qweight, layer.scales, None, None, layer.bias, K, N, g, bits, 0)  # no qzeros buffer: 2^(bits-1)
+        nat = ops.repack_native(*src)[0:2]
+        w, keep = nat
+    else:
+        w = layer.native_descriptor(0)
+        assert w is not None
+    ref = Ref(d)
+    for m in (1, 2, 4, 5, 16, 17, 32, 33, 64):
+        if bits == 3 and m > 32:
+            continue
+        x = randx(m, K, seed=m)
+        assert "layout=strip-major" in ops.plan_describe([w], m), (m, ops.plan_describe([w], m))
+        y = ops.linear_forward(w, torch.from_numpy(x).to(DEV)).cpu().numpy()
+        assert np.isfinite(y.astype(np.float32)).all()
+        assert O.rel_err(y, ref.y16(x)) <= 1e-2, (m, ops.plan_describe([w], m))
+        assert O.rel_err(y.astype(np.float64), ref.y64(x)) <= 2e-3, (m, ops.plan_describe([w], m))
+    # bf16 activations on the same descriptor
+    xb = torch.from_numpy(randx(3, K, seed=9)).to(DEV).to(torch.bfloat16)
+    if not (bits == 3 and g == 64):
+        yb = ops.linear_forward(w, xb).float().cpu().numpy()
+        assert O.rel_err(yb, ref.y64(xb.float().cpu().numpy().astype(np.float16))) <= 2e-2
+
+
+def test_native_grouped_launch_and_autogptq_offset():
+    """q/k/v-like group (unequal widths) in one launch on native descriptors; add_zero_bias = 1 (COMPATIBLE_WITH_AUTOGPTQ)."""
+    from qllm_amd import ops
+    ds = [synth("GPTQ", 4, 128, 4096, n, seed=80 + i, bias=(i == 2)) for i, n in enumerate((4096, 1024, 512))]
+    layers = [to_layer(d, DEV) for d in ds]
+    for compat in (0, 1):
+        ws = [l.native_descriptor(compat) for l in layers]
+        assert "layout=strip-major" in ops.plan_describe(ws, 1)
+        for m in (1, 4, 16):
+            x = randx(m, 4096, seed=3 + m)
+            outs = ops.linear_forward_grouped(ws, torch.from_numpy(x).to(DEV))
+            for o, d in zip(outs, ds):
+                assert O.rel_err(o.cpu().numpy(), Ref(dict(d, compat=compat)).y16(x)) <= 1e-2, (compat, m)
+
+
+def test_native_layout_is_what_the_modules_decode_from():
+    """The module path: decode-sized forwards stream the native copy (plan text), prefill-sized ones the reference buffers; the
+    state dict is untouched and QLLM_NATIVE_LAYOUT=0 keeps everything in place."""
+    import os
+    from qllm_amd import ops
+    d = synth("GEMM", 4, 128, 4096, 4096, seed=5)
+    layer = to_layer(d, DEV)
+    before = {k: v.clone() for k, v in layer.state_dict().items()}
+    x = torch.from_numpy(randx(1, 4096)).to(DEV)
+    y = layer(x)
+    assert "layout=strip-major" in ops.plan_describe([layer.decode_descriptor()], 1)
+    assert O.rel_err(y.cpu().numpy(), Ref(d).y16(x.cpu().numpy())) <= 1e-2
+    for k, v in layer.state_dict().items():
+        assert torch.equal(v, before[k]), k
+    os.environ["QLLM_NATIVE_LAYOUT"] = "0"
+    try:
+        l2 = to_layer(d, DEV)
+        assert ops.plan_describe([l2.decode_descriptor()], 1).startswith("skinny")   # AWQ in place: the split-K kernel
+        assert O.rel_err(l2(x).cpu().numpy(), y.cpu().numpy()) <= 2e-3
+    finally:
+        del os.environ["QLLM_NATIVE_LAYOUT"]
