@@ -114,6 +114,9 @@ class Stack(torch.nn.Module):
         gen = torch.Generator(device=dev).manual_seed(seed)
         self.blocks = torch.nn.ModuleList([Block(cls, dev, gen, act_order, bits=bits, group=group) for _ in range(n_layers)])
         self.groups = install_sibling_groups(self, [cls]) if fused else 0
+        # the loader's memory policy (modeling/base.load_quantized): one copy of every layer on the device, in the native layout
+        from qllm_amd.modeling.base import release_reference_layouts
+        release_reference_layouts(self)
 
     def set_fused(self, on: bool):
         for m in self.modules():
@@ -419,9 +422,12 @@ def main():
         del stack
         torch.cuda.empty_cache()
         # prefill M=2048 (BASELINE configs[2]: GPTQ act-order) and AWQ, one layer's 7 linears x 4 layers
-        for tag, cls, act in (("awq", WQLinear_GEMM, False), ("gptq_actorder", QuantLinearGPTQ, True)):
+        # (awq_bf16: bf16 activations on the same kernel -- x converted to fp16 by a pre-pass, the result rounded to bf16, the
+        #  arithmetic of the reference's shim, quant_linear_awq.py:29-36)
+        for tag, cls, act, xdt in (("awq", WQLinear_GEMM, False, torch.float16), ("gptq_actorder", QuantLinearGPTQ, True, torch.float16),
+                                   ("awq_bf16", WQLinear_GEMM, False, torch.bfloat16)):
             ps = Stack(cls, 4, dev, seed=99, act_order=act)
-            xp = torch.randn(2048, HIDDEN, device=dev, dtype=torch.float16)
+            xp = torch.randn(2048, HIDDEN, device=dev, dtype=xdt)
             gp, _ = capture(lambda: ps(xp))  # graph replay, like the headline leg: kernel time, not Python / allocator time
             ms = time_events(gp.replay, 10)
             del gp

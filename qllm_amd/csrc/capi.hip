@@ -171,20 +171,24 @@ static bool strip_plan(const qllm_weight_t *w, int n, int M, StripPlan *plan) {
     const int strips = cols / 16;
     if (strips < 1) return false;
     const int slab_nw = ra_base ? 0 : strip_sm_nw(w[0].K, M, w[0].group_size, bits);  // 0: no slab form for this shape
-    int nw = (M > 16) ? 8 : (slab_nw ? slab_nw : 16);
+    // register-A form at M = 5..16, 4 bits, every layer a multiple of 64 wide and enough of them: blocks of four adjacent strips
+    // (a register-A block re-reads all of x from L2; 64 columns share it instead of 16)
+    static int sm_ra_cpl4 = env_int("QLLM_SM_RA_CPL4", 1);
+    const int cpl = (sm_ra_cpl4 && slab_nw == 0 && M >= 5 && M <= 16 && bits == 4 && m64 && cols / 64 >= compute_units() / 2) ? 4 : 1;
+    int nw = (M > 16 || cpl == 4) ? 8 : (slab_nw ? slab_nw : 16);
     for (int tries = 0; tries < 2; ++tries) {
       const int spw = strip_spw(w[0].K, w[0].group_size, nw);
       const int ra = (slab_nw == 0 || (longk && nw == 16)) ? 1 : 0;
       if (!ra && w[0].K / 32 < strip_maxs(nw, spw, 1, 0, 1)) return false;  // a round's window must fit into the strip
-      if ((ra || strip_x_ok(M, spw, nw, 1, 1)) && strip_lds_bytes(M, spw, nw, 1, w[0].group_size, ra, 1) <= 156 * 1024) {
-        plan->cpl = 1;
+      if ((ra || strip_x_ok(M, spw, nw, 1, 1)) && strip_lds_bytes(M, spw, nw, cpl, w[0].group_size, ra, 1) <= 156 * 1024) {
+        plan->cpl = cpl;
         plan->nw = nw;
         plan->spw = spw;
         plan->ra = ra;
         plan->sm = 1;
         return true;
       }
-      if (nw == 16 || M > 16) break;
+      if (nw == 16 || M > 16 || cpl == 4) break;
       nw = 16;  // shorter per-wave chunks
     }
     return false;
@@ -342,12 +346,100 @@ static int check_io(const void *x, const void *y, int M, int act_dtype) {
   return QLLM_OK;
 }
 
-// prefill-sized calls (M > 64) on native-layout layers
+// gemm3 over K-split blocks when the 256x128 tiling leaves CUs idle and the caller's workspace can hold the partial tiles.
+// true: p.split_k / slabs / counters are set (split_k > 1); false: p untouched (callers then run unsplit or pick gemm2)
+static bool gemm3_use_split(GemmParams &p, void *workspace, size_t workspace_bytes) {
+  const int S = gemm3_split_k(p.M, p.N, p.K);
+  if (S <= 1) return false;
+  const size_t need = kCounterBytes + gemm2_slab_bytes(p.M, p.N, S);
+  const int tiles = ((p.M + 255) / 256) * (p.N / 128);
+  if (!workspace || workspace_bytes < need || (uintptr_t)workspace % 256 != 0 || tiles > (int)(kCounterBytes / sizeof(int))) return false;
+  p.split_k = S;
+  p.counters = (int *)workspace;
+  p.slabs = (float *)((char *)workspace + kCounterBytes);
+  return true;
+}
+
+static void fill_gemm_params(GemmParams &p, const qllm_weight_t *w, const void *x, void *y, int M, int act_dtype) {
+  memset(&p, 0, sizeof(p));
+  p.x = x;
+  p.qweight = (const uint32_t *)w->qweight;
+  p.scales = (const half_t *)w->scales;
+  p.qzeros = w->qzeros;
+  p.g_idx = w->g_idx;
+  p.bias = (const half_t *)w->bias;
+  p.y = y;
+  p.M = M;
+  p.K = w->K;
+  p.N = w->N;
+  p.group_size = w->group_size;
+  p.gs_shift = ((w->group_size & (w->group_size - 1)) == 0) ? __builtin_ctz((unsigned)w->group_size) : -1;
+  p.add_zero_bias = w->add_zero_bias;
+  p.zero_kind = zero_kind_of(*w);
+  p.act_bf16 = (act_dtype == QLLM_BF16);
+  p.n_groups = (w->K + w->group_size - 1) / w->group_size;
+  p.sm = is_native(*w) ? 1 : 0;
+  p.split_k = 1;
+}
+
+// the 256-row-tile GEMMs on a row-stream (or strip-major) 4-bit layer / AWQ layer: gemm3 from M = 1024 or when it can split K,
+// gemm2 below; `layout` = the kernels' layout selector (GPTQ for every row-stream storage, AWQ_GEMM)
+// bytes of the fp16 copy of bf16 activations gemm3 reads (0 for fp16 activations), and where it sits in the workspace
+static size_t bf16_copy_bytes(int M, int K, int act_bf16) { return act_bf16 ? align_up((size_t)M * K * 2, 256) : 0; }
+
+static int run_tile_gemm(GemmParams &p, int layout, void *workspace, size_t workspace_bytes, hipStream_t stream) {
+  // large M: the wave-specialised 256x128 kernel (no split-K needed: every CU has at least one tile).  bf16 activations: its
+  // activation tiles travel by LDS-DMA, which cannot convert, so x is converted to fp16 once into the workspace (the reference's
+  // own shim does the same cast, quant_linear_awq.py:29-36) and the epilogue rounds the fp16 result to bf16
+  {
+    GemmParams q = p;
+    q.act_bf16 = 0;
+    const size_t copy = bf16_copy_bytes(p.M, p.K, p.act_bf16);
+    if (gemm3_ok(q, layout) && (gemm2_split_k(p.M, p.N, p.K) == 1 || gemm3_use_split(q, workspace, workspace_bytes))) {
+      const size_t used = kCounterBytes + (q.split_k > 1 ? align_up(gemm2_slab_bytes(p.M, p.N, q.split_k), 256) : 0);
+      if (!copy) return launch_gemm3(q, layout, stream);
+      if (workspace && (uintptr_t)workspace % 256 == 0 && workspace_bytes >= used + copy) {
+        void *xh = (char *)workspace + used;
+        if (int rc = launch_bf16_to_f16(p.x, xh, (size_t)p.M * p.K, stream)) return rc;
+        q.x = xh;
+        q.out_bf16 = 1;
+        return launch_gemm3(q, layout, stream);
+      }
+    }
+  }
+  p.split_k = 1;
+  p.slabs = nullptr;
+  p.counters = nullptr;
+  // split-K when the tiling leaves CUs idle and the caller's workspace can hold the partial tiles (else: no split)
+  const int S = gemm2_split_k(p.M, p.N, p.K);
+  const size_t need = kCounterBytes + gemm2_slab_bytes(p.M, p.N, S);
+  const int tiles = ((p.M + 255) / 256) * (p.N / 128);
+  if (S > 1 && workspace && workspace_bytes >= need && (uintptr_t)workspace % 256 == 0 && tiles <= (int)(kCounterBytes / sizeof(int))) {
+    p.split_k = S;
+    p.counters = (int *)workspace;
+    p.slabs = (float *)((char *)workspace + kCounterBytes);
+  }
+  return launch_gemm2(p, layout, stream);
+}
+
+// prefill-sized calls (M > 64) on native-layout layers: the same tile GEMMs, their staging waves reading the strip-major words
+static bool native_prefill_ok(const qllm_weight_t *w, GemmParams &p) {
+  if ((uintptr_t)w->qweight % 16 || (uintptr_t)w->scales % 16 || (w->qzeros && (uintptr_t)w->qzeros % 8)) return false;
+  if (w->bits == 3) return gemm3_ok(p, kGemm3Rows3Bit);
+  return w->bits == 4 && gemm2_ok(p, QLLM_LAYOUT_GPTQ);
+}
 static int native_prefill(const qllm_weight_t *w, const void *x, void *y, int M, int act_dtype, void *workspace, size_t workspace_bytes,
                           hipStream_t stream) {
-  (void)x; (void)y; (void)act_dtype; (void)workspace; (void)workspace_bytes; (void)stream;
-  return set_error(QLLM_ERR_UNSUPPORTED, "native-layout layer: no fused kernel for M=%d K=%d N=%d g=%d bits=%d (decode sizes, M <= 64, g in {64,128}, are served)",
-                   M, w->K, w->N, w->group_size, w->bits);
+  GemmParams p;
+  fill_gemm_params(p, w, x, y, M, act_dtype);
+  if (!native_prefill_ok(w, p))
+    return set_error(QLLM_ERR_UNSUPPORTED, "native-layout layer: no fused kernel for M=%d K=%d N=%d g=%d bits=%d (decode sizes, and M > 64 with "
+                     "K %% 64 == 0, N %% 128 == 0 and a power-of-two group size, are served)", M, w->K, w->N, w->group_size, w->bits);
+  if (w->bits == 3) {
+    gemm3_use_split(p, workspace, workspace_bytes);
+    return launch_gemm3(p, kGemm3Rows3Bit, stream);
+  }
+  return run_tile_gemm(p, QLLM_LAYOUT_GPTQ, workspace, workspace_bytes, stream);
 }
 
 }  // namespace qllm
@@ -387,8 +479,8 @@ int qllm_device_info(int device, qllm_device_info_t *out) {
 
 size_t qllm_workspace_bytes(const qllm_weight_t *w, int32_t M) {
   if (!w || M <= 0) return kCounterBytes;
-  if (M > 64)  // prefill: fp32 partial tiles of the split-K GEMM (mid-size M only)
-    return kCounterBytes + align_up(gemm2_slab_bytes(M, w->N, gemm2_split_k(M, w->N, w->K)), 256);
+  if (M > 64)  // prefill: fp32 partial tiles of the split-K GEMM (mid-size M only) + the fp16 copy of bf16 activations (gemm3)
+    return kCounterBytes + align_up(gemm2_slab_bytes(M, w->N, gemm2_split_k(M, w->N, w->K)), 256) + bf16_copy_bytes(M, w->K, 1);
   return kCounterBytes + align_up((size_t)skinny_max_split(M) * M * w->N * sizeof(float), 256);
 }
 
@@ -441,20 +533,6 @@ int qllm_debug_timeline(void *buf, int32_t n_slots) {  // n_slots x 24 x u64
   return QLLM_OK;
 }
 
-// gemm3 over K-split blocks when the 256x128 tiling leaves CUs idle and the caller's workspace can hold the partial tiles.
-// true: p.split_k / slabs / counters are set (split_k > 1); false: p untouched (callers then run unsplit or pick gemm2)
-static bool gemm3_use_split(GemmParams &p, void *workspace, size_t workspace_bytes) {
-  const int S = gemm3_split_k(p.M, p.N, p.K);
-  if (S <= 1) return false;
-  const size_t need = kCounterBytes + gemm2_slab_bytes(p.M, p.N, S);
-  const int tiles = ((p.M + 255) / 256) * (p.N / 128);
-  if (!workspace || workspace_bytes < need || (uintptr_t)workspace % 256 != 0 || tiles > (int)(kCounterBytes / sizeof(int))) return false;
-  p.split_k = S;
-  p.counters = (int *)workspace;
-  p.slabs = (float *)((char *)workspace + kCounterBytes);
-  return true;
-}
-
 int qllm_linear_forward(const qllm_weight_t *w, const void *x, void *y, int32_t M, int32_t act_dtype, void *workspace,
                         size_t workspace_bytes, void *stream) {
   clear_error();
@@ -475,23 +553,9 @@ int qllm_linear_forward(const qllm_weight_t *w, const void *x, void *y, int32_t 
   if (w->bits == 3 && M > 64 && w->layout != QLLM_LAYOUT_AWQ_GEMM && !w->g_idx && (uintptr_t)w->qweight % 16 == 0 &&
       (uintptr_t)w->scales % 16 == 0 && (!w->qzeros || (uintptr_t)w->qzeros % 8 == 0)) {
     // 3-bit row-stream layers at prefill sizes: the wave-specialised kernel with 3-bit staging waves (gemm3.hip, LAYOUT 2)
-    GemmParams p = {};
-    p.x = x;
-    p.qweight = (const uint32_t *)w->qweight;
-    p.scales = (const half_t *)w->scales;
-    p.qzeros = w->qzeros;
-    p.bias = (const half_t *)w->bias;
-    p.y = y;
-    p.M = M;
-    p.K = w->K;
-    p.N = w->N;
-    p.group_size = w->group_size;
-    p.gs_shift = ((w->group_size & (w->group_size - 1)) == 0) ? __builtin_ctz((unsigned)w->group_size) : -1;
-    p.add_zero_bias = w->add_zero_bias;
-    p.zero_kind = zero_kind_of(*w);
-    p.act_bf16 = (act_dtype == QLLM_BF16);
-    p.n_groups = (w->K + w->group_size - 1) / w->group_size;
-    p.split_k = 1;
+    GemmParams p;
+    fill_gemm_params(p, w, x, y, M, act_dtype);
+    p.g_idx = nullptr;
     if (gemm3_ok(p, kGemm3Rows3Bit)) {
       gemm3_use_split(p, workspace, workspace_bytes);
       return launch_gemm3(p, kGemm3Rows3Bit, (hipStream_t)stream);
@@ -499,45 +563,8 @@ int qllm_linear_forward(const qllm_weight_t *w, const void *x, void *y, int32_t 
   }
   if (gemm_ok(*w)) {
     GemmParams p;
-    p.x = x;
-    p.qweight = (const uint32_t *)w->qweight;
-    p.scales = (const half_t *)w->scales;
-    p.qzeros = w->qzeros;
-    p.g_idx = w->g_idx;
-    p.bias = (const half_t *)w->bias;
-    p.y = y;
-    p.M = M;
-    p.K = w->K;
-    p.N = w->N;
-    p.group_size = w->group_size;
-    p.gs_shift = ((w->group_size & (w->group_size - 1)) == 0) ? __builtin_ctz((unsigned)w->group_size) : -1;
-    p.add_zero_bias = w->add_zero_bias;
-    p.zero_kind = zero_kind_of(*w);
-    p.act_bf16 = (act_dtype == QLLM_BF16);
-    p.n_groups = (w->K + w->group_size - 1) / w->group_size;
-    p.raster = 0;
-    p.stagger = 0;
-    p.split_k = 1;
-    p.slabs = nullptr;
-    p.counters = nullptr;
-    if (gemm2_ok(p, w->layout)) {
-      // large M: the wave-specialised 256x128 kernel (no split-K needed: every CU has at least one tile)
-      if (gemm3_ok(p, w->layout) && (gemm2_split_k(M, w->N, w->K) == 1 || gemm3_use_split(p, workspace, workspace_bytes)))
-        return launch_gemm3(p, w->layout, (hipStream_t)stream);
-      p.split_k = 1;
-      p.slabs = nullptr;
-      p.counters = nullptr;
-      // split-K when the tiling leaves CUs idle and the caller's workspace can hold the partial tiles (else: no split)
-      const int S = gemm2_split_k(M, w->N, w->K);
-      const size_t need = kCounterBytes + gemm2_slab_bytes(M, w->N, S);
-      const int tiles = ((M + 255) / 256) * (w->N / 128);
-      if (S > 1 && workspace && workspace_bytes >= need && (uintptr_t)workspace % 256 == 0 && tiles <= (int)(kCounterBytes / sizeof(int))) {
-        p.split_k = S;
-        p.counters = (int *)workspace;
-        p.slabs = (float *)((char *)workspace + kCounterBytes);
-      }
-      return launch_gemm2(p, w->layout, (hipStream_t)stream);
-    }
+    fill_gemm_params(p, w, x, y, M, act_dtype);
+    if (gemm2_ok(p, w->layout)) return run_tile_gemm(p, w->layout, workspace, workspace_bytes, (hipStream_t)stream);
     return launch_gemm(p, w->layout, (hipStream_t)stream);
   }
   return set_error(QLLM_ERR_UNSUPPORTED, "no fused kernel for bits=%d K=%d N=%d g=%d layout=%d act_order=%d; use qllm_dequant + GEMM",
@@ -606,7 +633,24 @@ int qllm_plan_describe(const qllm_weight_t *w, int32_t n_weights, int32_t M, int
     return QLLM_OK;
   }
   if (is_native(w[0])) {
-    snprintf(buf, buflen, "unsupported (native layout: decode sizes only)");
+    GemmParams p;
+    fill_gemm_params(p, &w[0], nullptr, nullptr, M, QLLM_F16);
+    if (n_weights != 1 || !native_prefill_ok(&w[0], p)) {
+      snprintf(buf, buflen, "unsupported (native layout: decode sizes, or M > 64 with K %% 64 == 0, N %% 128 == 0)");
+    } else if (w[0].bits == 3) {
+      const int S = have_workspace ? gemm3_split_k(M, w[0].N, w[0].K) : 1;
+      if (S > 1) snprintf(buf, buflen, "gemm3 tile=256x128 matrix-waves=8 staging-waves=4 bits=3 split_k=%d layout=strip-major", S);
+      else snprintf(buf, buflen, "gemm3 tile=256x128 matrix-waves=8 staging-waves=4 bits=3 layout=strip-major");
+    } else {
+      const int S2 = gemm2_split_k(M, w[0].N, w[0].K), S3 = gemm3_split_k(M, w[0].N, w[0].K);
+      if (gemm3_ok(p, QLLM_LAYOUT_GPTQ) && (S2 == 1 || (have_workspace && S3 > 1))) {
+        if (S2 > 1) snprintf(buf, buflen, "gemm3 tile=256x128 matrix-waves=8 staging-waves=4 split_k=%d layout=strip-major", S3);
+        else snprintf(buf, buflen, "gemm3 tile=256x128 matrix-waves=8 staging-waves=4 layout=strip-major");
+      } else {
+        const int S = have_workspace ? S2 : 1;
+        snprintf(buf, buflen, "gemm2 tile=256x%d split_k=%d layout=strip-major", gemm2_tile_n(M, w[0].N, S), S);
+      }
+    }
     return QLLM_OK;
   }
   if (decode_ok && w[0].bits == 4 && skinny_ok(w[0], M)) {

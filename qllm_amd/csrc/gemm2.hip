@@ -124,8 +124,17 @@ __global__ __launch_bounds__(512) void gemm2_kernel(const GemmParams p) {
   // zero points, branch-free addressing (see strip.hip): packed -> word (G, n/8); fp16 -> dword holding half (G, n)
   const int zk = p.zero_kind;
   const uint32_t *zbase = (zk == ZK_SYM) ? (const uint32_t *)p.scales : (const uint32_t *)p.qzeros;
-  const int zmul = (zk == ZK_PACKED) ? (p.N >> 3) : (p.N >> 1);
-  const int zoff = (zk == ZK_PACKED) ? (nB >> 3) : (nB >> 1);
+  // p.sm (row-stream layouts): the same words stored strip-major (native layout): word (r, n) at ((n / 16) * K/8 + r) * 16 + n % 16,
+  // scale / zero group rows hold the strip's 16 columns only
+  const bool sm = (LAYOUT == 0) && p.sm;
+  const int Gn = (p.K + (1 << p.gs_shift) - 1) >> p.gs_shift;
+  const int ncs = sm ? (nB & 15) : nB;
+  const int zmul = sm ? ((zk == ZK_PACKED) ? 2 : 8) : ((zk == ZK_PACKED) ? (p.N >> 3) : (p.N >> 1));
+  const int zoff = ((zk == ZK_PACKED) ? (ncs >> 3) : (ncs >> 1)) + (sm ? (nB >> 4) * Gn * zmul : 0);
+  const int wstride = sm ? 16 : p.N;                                         // words per packed row
+  const size_t wcol = sm ? (size_t)(nB >> 4) * (size_t)(p.K >> 3) * 16 + ncs : (size_t)nB;
+  const int sstride = sm ? 16 : p.N;                                         // halves per group row of the scale table
+  const size_t scol = sm ? (size_t)(nB >> 4) * Gn * 16 + ncs : (size_t)nB;
 
   // One register set = everything this thread needs to dequantise its share of one k-tile: WPT packed words plus the
   // RAW scale / zero words of their group (a thread's rows span <= 32 k: one group, group_size % 32 == 0).  Two sets:
@@ -143,13 +152,13 @@ __global__ __launch_bounds__(512) void gemm2_kernel(const GemmParams p) {
 #pragma unroll
     for (int r = 0; r < WPT; ++r) {
       if constexpr (LAYOUT == 0)
-        bs.w[r] = p.qweight[(size_t)(ktc * 8 + brow + r) * p.N + nB];
+        bs.w[r] = p.qweight[(size_t)(ktc * 8 + brow + r) * wstride + wcol];
       else
         bs.w[r] = p.qweight[(size_t)(ktc * BK + brow + r) * (p.N >> 3) + (nB >> 3)];
     }
     const int G = group_of(ktc * BK + ((LAYOUT == 0) ? 8 * brow : brow));
     if constexpr (LAYOUT == 0) {
-      bs.sraw = ((const uint16_t *)p.scales)[(size_t)G * p.N + nB];
+      bs.sraw = ((const uint16_t *)p.scales)[(size_t)G * sstride + scol];
     } else {
       bs.s8 = *(const half8_t *)(p.scales + (size_t)G * p.N + nB);
     }

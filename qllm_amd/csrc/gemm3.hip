@@ -49,7 +49,9 @@ __device__ __forceinline__ int tile_off(int row, int slot) { return row * BK + (
 }  // namespace g3
 
 // LAYOUT 0 = GPTQ/HQQ row stream (4 bits), 1 = AWQ GEMM, 2 = GPTQ/HQQ row stream with 3-bit weights (bit stream: the 32 k of
-// a half k-tile are 3 consecutive word rows of the column).  fp16 activations.  Requires K % 64 == 0, N % 128 == 0, power-of-two group size >= 32, no g_idx.
+// a half k-tile are 3 consecutive word rows of the column).  p.sm (LAYOUT 0 / 2): the same words stored strip-major (the native
+// layout, include/qllm_mi355x.h): only the loop-constant per-lane offsets and the row strides change -- a thread's four words are
+// 4 x 64 B apart inside its strip instead of 4 x 4N B apart.  fp16 activations.  Requires K % 64 == 0, N % 128 == 0, power-of-two group size >= 32, no g_idx.
 // MW: matrix waves, 4 (one per SIMD, 128x64 each) or 8 (two per SIMD, 64x64 each: 8 fragment reads per 8 MFMAs instead of 6,
 // but the two waves cover each other's LDS / barrier waits); always 4 dequant waves behind them.
 template <int LAYOUT, int MW, bool PRIO = true>
@@ -100,9 +102,15 @@ __global__ __launch_bounds__((MW + 4) * 64) void gemm3_kernel(const GemmParams p
     const uint32_t nibmask = nib_mask_vgpr();
     const int zk = p.zero_kind;
     const uint32_t *zbase = (zk == ZK_SYM) ? (const uint32_t *)p.scales : (const uint32_t *)p.qzeros;
-    const int zmul = (zk == ZK_PACKED) ? (LAYOUT == 2 ? (p.N * 3) >> 5 : (p.N >> 3)) : (p.N >> 1);
-    const int zoff = (zk == ZK_PACKED) ? (LAYOUT == 2 ? (nB * 3) >> 5 : (nB >> 3)) : (nB >> 1);
-    const int zoff2 = (LAYOUT == 2 && zk == ZK_PACKED && zoff + 1 < zmul) ? 1 : 0;  // packed 3-bit zero points may straddle two words
+    // zero points: words per group row (zmul), this column's word inside the row (zoff), and -- strip-major storage (p.sm, row-stream
+    // layouts only) -- the word offset of the column's strip (zstrip; group rows then hold the strip's 16 columns only: 2 or 8 words)
+    const int Gn = (p.K + (1 << p.gs_shift) - 1) >> p.gs_shift;
+    const bool sm = ROWS && p.sm;
+    const int ncs = sm ? (nB & 15) : nB;  // column index inside a row of the scale / zero tables
+    const int zmul_all = (zk == ZK_PACKED) ? (LAYOUT == 2 ? (p.N * 3) >> 5 : (p.N >> 3)) : (p.N >> 1);  // words per group over all columns
+    const int zmul = sm ? ((zk == ZK_PACKED) ? 2 : 8) : zmul_all;
+    const int zoff = ((zk == ZK_PACKED) ? (LAYOUT == 2 ? (ncs * 3) >> 5 : (ncs >> 3)) : (ncs >> 1)) + (sm ? (nB >> 4) * Gn * zmul : 0);
+    const int zoff2 = (LAYOUT == 2 && zk == ZK_PACKED && (sm ? ((ncs * 3) >> 5) == 0 : zoff + 1 < zmul)) ? 1 : 0;  // packed 3-bit zero points may straddle two words
     struct BSet {
       uint32_t w[4];
       half8_t s8;     // AWQ: the 8 columns' scales
@@ -111,14 +119,17 @@ __global__ __launch_bounds__((MW + 4) * 64) void gemm3_kernel(const GemmParams p
     };
     BSet bset[2];
     // buffer loads: per-lane byte offsets are loop constants, the k-tile / group advance is a scalar offset (SALU only)
-    const int Gn = (p.K + (1 << p.gs_shift) - 1) >> p.gs_shift;
     const auto rs_w = __builtin_amdgcn_make_buffer_rsrc((void *)p.qweight, 0, (int)((size_t)p.K * p.N / 2), 0x00020000);
     const auto rs_s = __builtin_amdgcn_make_buffer_rsrc((void *)p.scales, 0, Gn * p.N * 2, 0x00020000);
-    const auto rs_z = __builtin_amdgcn_make_buffer_rsrc((void *)zbase, 0, Gn * zmul * 4, 0x00020000);
-    const int wrow_bytes = ROWS ? p.N * 4 : (p.N >> 3) * 4;                 // bytes per packed row
+    // (strip-major: every strip has whole words of its own -- 3-bit zero points take 2 words per 16 columns, not 1.5)
+    const auto rs_z = __builtin_amdgcn_make_buffer_rsrc((void *)zbase, 0, (sm ? (p.N >> 4) * Gn * zmul : Gn * zmul_all) * 4, 0x00020000);
+    const int wrow_bytes = sm ? 64 : (ROWS ? p.N * 4 : (p.N >> 3) * 4);     // bytes per packed row (strip-major: the strip's 16 words)
     const int ktile_bytes = (LAYOUT == 0 ? 8 : (LAYOUT == 2 ? 6 : BK)) * wrow_bytes;  // packed rows per k-tile: 8 / 6 (3 bits) / 64 (AWQ)
-    const int voff_w = (LAYOUT == 2 ? 3 * (t >> 7) : brow) * wrow_bytes + (ROWS ? nB * 4 : (nB >> 3) * 4);
-    const int voff_s = nB * 2, voff_z = zoff * 4;
+    const int strip_rows = (LAYOUT == 2) ? (p.K * 3) >> 5 : (p.K >> 3);      // word rows of one strip
+    const int voff_w = (LAYOUT == 2 ? 3 * (t >> 7) : brow) * wrow_bytes +
+                       (sm ? (nB >> 4) * strip_rows * 64 + ncs * 4 : (ROWS ? nB * 4 : (nB >> 3) * 4));
+    const int srow_bytes = sm ? 32 : p.N * 2;                                // bytes per group row of the scale table
+    const int voff_s = sm ? (nB >> 4) * Gn * 32 + ncs * 2 : nB * 2, voff_z = zoff * 4;
     const int krow0 = ROWS ? 8 * brow : brow;                               // this thread's first k inside a k-tile
     auto load_b = [&](int kt, BSet &bs) {
       const int ktc = KT0 + min(kt, KT - 1);
@@ -129,9 +140,9 @@ __global__ __launch_bounds__((MW + 4) * 64) void gemm3_kernel(const GemmParams p
       const int G0 = (ktc * BK) >> p.gs_shift, G1 = (ktc * BK + 32) >> p.gs_shift;
       const int G = ROWS ? ((krow0 >= 32) ? G1 : G0) : ((ktc * BK + krow0) >> p.gs_shift);
       if constexpr (ROWS)
-        bs.sraw = __builtin_amdgcn_raw_buffer_load_b16(rs_s, voff_s + G * p.N * 2, 0, 0);
+        bs.sraw = __builtin_amdgcn_raw_buffer_load_b16(rs_s, voff_s + G * srow_bytes, 0, 0);
       else
-        bs.s8 = __builtin_bit_cast(half8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_s, voff_s + G * p.N * 2, 0, 0));
+        bs.s8 = __builtin_bit_cast(half8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_s, voff_s + G * srow_bytes, 0, 0));
       bs.z = __builtin_amdgcn_raw_buffer_load_b32(rs_z, voff_z + G * zmul * 4, 0, 0);
       if constexpr (LAYOUT == 2) bs.z2 = __builtin_amdgcn_raw_buffer_load_b32(rs_z, voff_z + zoff2 * 4 + G * zmul * 4, 0, 0);
     };
@@ -139,7 +150,7 @@ __global__ __launch_bounds__((MW + 4) * 64) void gemm3_kernel(const GemmParams p
       half_t *Bb = Bs + stage * kBTile;
       if constexpr (LAYOUT == 2) {
         // 32 k = 96 bits of the column's bit stream in w[0..2]: four 24-bit fields of 8 values each, natural k order
-        const uint32_t zfield = (uint32_t)(((((uint64_t)bs.z2) << 32) | bs.z) >> ((3 * nB) & 31));
+        const uint32_t zfield = (uint32_t)(((((uint64_t)bs.z2) << 32) | bs.z) >> ((3 * ncs) & 31));
         const half_t zp = (half_t)(float)((zfield + (uint32_t)p.add_zero_bias) & 7u);
         const half_t zf = __builtin_bit_cast(half_t, (uint16_t)((nB & 1) ? (bs.z >> 16) : (bs.z & 0xffffu)));
         const half_t sc = __builtin_bit_cast(half_t, (uint16_t)bs.sraw);
@@ -376,7 +387,10 @@ __global__ __launch_bounds__((MW + 4) * 64) void gemm3_kernel(const GemmParams p
       for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * fs;
         const float v = acc[a][b][r] + bv[b];
-        ep[row * 72 + b * 32 + fr] = (half_t)v;
+        // bf16 activations (x converted to fp16 by the pre-pass): the result is rounded to fp16 and then to bf16, as the
+        // reference's shim does (fp16 kernel output .to(bfloat16), quant_linear_awq.py:29-36, 144-146)
+        if (p.out_bf16) ((uint16_t *)ep)[row * 72 + b * 32 + fr] = f32_to_bf16((float)(half_t)v);
+        else ep[row * 72 + b * 32 + fr] = (half_t)v;
       }
     // 32 rows x 128 B = 256 chunks of 16 B: 4 per lane (wave-private region: no barrier, the wave's own LDS ops are ordered)
 #pragma unroll
@@ -397,10 +411,22 @@ bool gemm3_ok(const GemmParams &p, int layout) {
   static const int min_m3 = getenv("QLLM_GEMM3_MIN_M_3BIT") ? atoi(getenv("QLLM_GEMM3_MIN_M_3BIT")) : 65;
   if (!on || p.g_idx || p.K % 64 != 0 || p.N % 128 != 0) return false;
   if (p.M < (layout == kGemm3Rows3Bit ? min_m3 : min_m)) return false;
-  // fp16 activations only: the activation tile goes to LDS by DMA, which cannot convert bf16 on the way (gemm2 does);
-  // 32-bit byte offsets into x and the packed weights
+  // fp16 activations only: the activation tile goes to LDS by DMA, which cannot convert bf16 on the way (callers convert x with
+  // launch_bf16_to_f16 first and set out_bf16, or use gemm2); 32-bit byte offsets into x and the packed weights
   if (p.act_bf16 || (size_t)p.M * p.K * 2 >= 0x7fffffffull || (size_t)p.K * p.N / 2 >= 0x7fffffffull) return false;
   return p.group_size % 32 == 0 && p.gs_shift >= 5;
+}
+
+__global__ __launch_bounds__(256) void bf16_to_f16_kernel(const uint4_t *__restrict__ src, uint4_t *__restrict__ dst, size_t n8) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n8) dst[i] = __builtin_bit_cast(uint4_t, bf16x8_to_h8(src[i]));
+}
+
+int launch_bf16_to_f16(const void *src, void *dst, size_t n, hipStream_t stream) {
+  const size_t n8 = n / 8;  // callers pass M * K with K % 64 == 0
+  hipLaunchKernelGGL(bf16_to_f16_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, stream, (const uint4_t *)src, (uint4_t *)dst, n8);
+  QLLM_HIP_CHECK(hipGetLastError());
+  return QLLM_OK;
 }
 
 template <int LAYOUT, int MW, bool PRIO = true>

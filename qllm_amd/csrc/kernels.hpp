@@ -115,6 +115,8 @@ struct GemmParams {
   int M, K, N, group_size, gs_shift, add_zero_bias, zero_kind, act_bf16, n_groups;
   int raster;   // gemm2 tile order: 0 = m fastest, 1 = n fastest inside an XCD's run
   int stagger;  // gemm2: waves 4-7 run their VALU phase before their MFMA phase
+  int out_bf16; // gemm3: y is bf16 (x was converted to fp16 by the pre-pass: the reference's bf16 shim, quant_linear_awq.py:29-36)
+  int sm;       // 1: row-stream layout stored strip-major (the native layout): word (r, n) at ((n / 16) * rows + r) * 16 + n % 16
   int split_k;      // gemm2: blocks per output tile along K (1 = none)
   float *slabs;     // gemm2 split-K: [tiles][split_k][256 x 128] fp32 partial tiles
   int *counters;    // gemm2 split-K: one arrival counter per output tile (zero before and after the launch)
@@ -133,5 +135,6 @@ constexpr int kGemm3Rows3Bit = 100;  // `layout` value for launch_gemm3 / gemm3_
 bool gemm3_ok(const GemmParams &p, int layout);
 int gemm3_split_k(int M, int N, int K);
 int launch_gemm3(const GemmParams &p, int layout, hipStream_t stream);
+int launch_bf16_to_f16(const void *src, void *dst, size_t n, hipStream_t stream);  // elementwise RNE conversion (gemm3's bf16 pre-pass)
 
 }  // namespace qllm

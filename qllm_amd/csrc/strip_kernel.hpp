@@ -62,9 +62,11 @@ __device__ __forceinline__ float dpp_add(float v) {
 //       weights before computing a round -- two register sets, loop unrolled by two -- was 8-18 % slower at K=11008.)
 // MT (RA only): 16-row MFMA tiles per block, M <= 16*MT.  Every B fragment built from a packed word is used MT times, so the
 //       per-weight VALU work is amortised over up to 64 rows; each k-step holds MT x 16 B of activations per lane.
-// SM: strip-major native layout (CPL = 1): qweight [N/16][K*BITS/32][16] words, scales [N/16][K/g][16] halves, zero points
+// SM: strip-major native layout: qweight [N/16][K*BITS/32][16] words, scales [N/16][K/g][16] halves, zero points
 //       [N/16][K/g][2] words (packed 4-bit: nibble i%8 of word i/8; packed 3-bit: bit 3i of the 64-bit pair) or [N/16][K/g][16]
-//       halves (fp16).
+//       halves (fp16).  CPL = 1: one strip per block.  CPL = 4 (register-A form only): a block takes FOUR adjacent strips -- lane
+//       (g, i) holds column i of each -- so that the activation fragments a lane loads per k-step (the register-A form's cost:
+//       every block re-reads all of x from L2) are shared by 64 columns instead of 16; each wave-load is still 256 contiguous bytes.
 // DBG: diagnostics instantiation: wave 0 of the first, the middle and the last block record 100 MHz timestamps
 //       [entry, loads issued, x staged, rounds done, after the barrier, exit] into p.dbg (tools/lab/cbench --timeline).
 template <int NW, int CPL, int MAXS, int SPG, int XL, int BITS, bool RA = false, bool RA_BF16 = false, int MT = 1, bool SM = false, bool DBG = false>
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(NW * 64, (SM && !RA && NW <= 8) ? ((NW == 8 && MAXS
   static_assert(BITS == 4 || (BITS == 3 && CPL == 1), "3-bit strips are 16 columns wide");
   static_assert(!RA || MAXS == 8, "register-A rounds are 8 k-steps");
   static_assert(MT == 1 || (RA && CPL == 1), "several row tiles: register-A, 16-column strips");
-  static_assert(!SM || CPL == 1, "strip-major strips are 16 columns wide");
+  static_assert(!SM || CPL == 1 || (RA && BITS == 4 && MT == 1), "strip-major blocks of several 16-column strips: register-A form, 4 bits");
   constexpr int NG = MAXS / SPG;   // groups per round (MAXS is a multiple of SPG; rounds start on a group boundary)
   constexpr int TN = 16 * CPL;     // columns per block
   constexpr int GL = 4 * SPG;      // lanes (16-byte chunks) per group in the staging pass: 8 or 16
@@ -248,7 +250,8 @@ __global__ __launch_bounds__(NW * 64, (SM && !RA && NW <= 8) ? ((NW == 8 && MAXS
   // packed words: row stride WS (words) and this lane's column offset inside a row.  Strip-major: the strip is a [rows][16]
   // matrix of its own at word offset b * rows * 16
   const int WS = SM ? 16 : N;
-  const uint32_t *qw = SM ? pr.qweight + (size_t)b * ((size_t)p.T * WR * 16) : pr.qweight;
+  const size_t strip_words = (size_t)p.T * WR * 16;  // strip-major: words of one strip
+  const uint32_t *qw = SM ? pr.qweight + (size_t)b * CPL * strip_words : pr.qweight;
   const int wcol = SM ? i : n;
   const uint32_t lane_off = (uint32_t)(g * WS + wcol);  // word offset of this lane inside a 4-row group
   // 3-bit: word rows {0,0,1,2}[g] / {0,1,2,2}[g] of the 3-row group, and the funnel shift {0,24,16,8}[g]
@@ -257,7 +260,7 @@ __global__ __launch_bounds__(NW * 64, (SM && !RA && NW <= 8) ? ((NW == 8 && MAXS
   const uint32_t shift3 = (uint32_t)((32 - 8 * g) & 31);
   // scales: row stride (halves) and this lane's pointer to group 0
   const int SS = SM ? 16 : N;
-  const half_t *scp = SM ? pr.scales + (size_t)b * (size_t)(Gmax + 1) * 16 + i : pr.scales + n;
+  const half_t *scp = SM ? pr.scales + (size_t)b * CPL * (size_t)(Gmax + 1) * 16 + i : pr.scales + n;
   // zero points, branch-free addressing: packed -> word (G, n/8) (CPL | 8: one word holds the lane's columns);
   // fp16 -> the dword(s) holding halves (G, n..n+CPL-1); symmetric -> any valid dword (ignored)
   const int zk = pr.zero_kind;
@@ -270,7 +273,7 @@ __global__ __launch_bounds__(NW * 64, (SM && !RA && NW <= 8) ? ((NW == 8 && MAXS
     zmul = (zk == ZK_PACKED) ? 2 : 8;
     zoff = (zk == ZK_PACKED) ? (BITS == 3 ? (i * 3) >> 5 : (i >> 3)) : (i >> 1);
     zoff2 = (BITS == 3 && zk == ZK_PACKED && zoff == 0) ? 1 : 0;
-    zbase += (size_t)b * (size_t)(Gmax + 1) * zmul;
+    zbase += (size_t)b * CPL * (size_t)(Gmax + 1) * zmul;
   } else {
     zmul = (zk == ZK_PACKED) ? (BITS == 3 ? (N * 3) >> 5 : (N >> 3)) : (N >> 1);
     zoff = (zk == ZK_PACKED) ? (BITS == 3 ? (n * 3) >> 5 : (n >> 3)) : (n >> 1);
@@ -293,7 +296,7 @@ __global__ __launch_bounds__(NW * 64, (SM && !RA && NW <= 8) ? ((NW == 8 && MAXS
     // ---- 2. scale / zero of every group this round touches: RAW loads only (tiny; issued first) ----------------------
     const int G0 = base / SPG;
     half_t sc[NG][CPL];
-    uint32_t zraw[NG][2];
+    uint32_t zraw[NG][(SM && CPL > 2) ? CPL : 2];  // strip-major blocks of several strips: one zero-point word per strip
     if constexpr (WIN) {
       // wave-uniform group base + the lane's fixed offset: the loads of the round differ by immediate offsets only
       const half_t *sl = scp + (size_t)G0 * 16;
@@ -308,6 +311,13 @@ __global__ __launch_bounds__(NW * 64, (SM && !RA && NW <= 8) ? ((NW == 8 && MAXS
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
       const int G = min(G0 + j, Gmax);
+      if constexpr (SM && CPL > 1) {
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+          sc[j][c] = scp[((size_t)c * (Gmax + 1) + G) * 16];
+          zraw[j][c] = zbase[((size_t)c * (Gmax + 1) + G) * zmul + zoff];
+        }
+      } else {
       if constexpr (CPL == 4) {
         const half4_t sv = *(const half4_t *)(scp + (size_t)G * SS);
         sc[j][0] = sv.x; sc[j][1] = sv.y; sc[j][2] = sv.z; sc[j][3] = sv.w;
@@ -319,6 +329,7 @@ __global__ __launch_bounds__(NW * 64, (SM && !RA && NW <= 8) ? ((NW == 8 && MAXS
       }
       zraw[j][0] = zbase[(size_t)G * zmul + zoff];
       zraw[j][1] = (CPL == 4 || BITS == 3) ? zbase[(size_t)G * zmul + zoff + zoff2] : 0u;
+      }
     }
     }
     // ---- 2b. RA: this round's activation fragments, raw (16 B per k-step; L2-resident, so they land before the weights)
@@ -348,7 +359,10 @@ __global__ __launch_bounds__(NW * 64, (SM && !RA && NW <= 8) ? ((NW == 8 && MAXS
 #pragma unroll
     for (int s = 0; s < MAXS; ++s) {
       const uint32_t *rowp = qw + (size_t)(WR * min(base + s, tmax)) * WS;
-      if constexpr (BITS == 4) {
+      if constexpr (SM && CPL > 1) {
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) w[s][c] = __builtin_nontemporal_load(rowp + c * strip_words + lane_off);
+      } else if constexpr (BITS == 4) {
         w[s] = __builtin_nontemporal_load((const wvec_t *)(rowp + lane_off));
       } else {
         // 32 k = 3 words: lane group g needs stream bits [24g, 24g+24) = words {0,0,1,2}[g] and {0,1,2,2}[g]
@@ -453,11 +467,12 @@ __global__ __launch_bounds__(NW * 64, (SM && !RA && NW <= 8) ? ((NW == 8 && MAXS
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
           // this group's scale / zero of column n+c, converted to fp32 here (keeps the raw 16/32-bit words live instead)
+          constexpr bool MS = SM && CPL > 1;  // several strips per block: column i of strip c, its own zero-point word
           const uint32_t zfield = (BITS == 3) ? (uint32_t)(((((uint64_t)zraw[j][1]) << 32) | zraw[j][0]) >> ((3 * zcol) & 31))
-                                              : (zraw[j][0] >> (4 * ((zcol + c) & 7)));
+                                              : (MS ? (zraw[j][c] >> (4 * (zcol & 7))) : (zraw[j][0] >> (4 * ((zcol + c) & 7))));
           const float zp = (float)((zfield + (uint32_t)p.add_zero_bias) & (uint32_t)((1 << BITS) - 1));
-          const uint32_t zd = (CPL >= 2) ? zraw[j][c >> 1] : zraw[j][0];
-          const bool hi = (CPL >= 2) ? (c & 1) : (zcol & 1);
+          const uint32_t zd = MS ? zraw[j][c] : ((CPL >= 2) ? zraw[j][c >> 1] : zraw[j][0]);
+          const bool hi = MS ? (zcol & 1) : ((CPL >= 2) ? (c & 1) : (zcol & 1));
           const float zh = (float)__builtin_bit_cast(half_t, (uint16_t)(hi ? (zd >> 16) : (zd & 0xffffu)));
           // branch-free select of the zero kind: with ?: on the wave-uniform zk hipcc may emit real branches around each
           // conversion (a dozen extra basic blocks per round, which also breaks up the load/MFMA schedule)
@@ -487,7 +502,7 @@ __global__ __launch_bounds__(NW * 64, (SM && !RA && NW <= 8) ? ((NW == 8 && MAXS
       const int row = 16 * mt + 4 * g + r;
       if (row < M) {
 #pragma unroll
-        for (int c = 0; c < CPL; ++c) red[(wave * M + row) * TN + i * CPL + c] = yacc[mt][c][r];
+        for (int c = 0; c < CPL; ++c) red[(wave * M + row) * TN + (SM ? c * 16 + i : i * CPL + c)] = yacc[mt][c][r];
       }
     }
   __syncthreads();

@@ -1,5 +1,6 @@
 // Strip-major (native layout) instantiations of the full-K strip decode kernel (strip_kernel.hpp): register-A forms, M = 5..64
-// (and long-K g64 / 3-bit layers at any M).  16-column strips; 16-wave blocks for one row tile, 8-wave blocks for 2 / 4 tiles.
+// (and long-K g64 / 3-bit layers at any M).  16-wave blocks of one 16-column strip, 8-wave blocks for 2 / 4 row tiles, and -- M = 5..16,
+// 4 bits, every layer a multiple of 64 wide -- 8-wave blocks of FOUR adjacent strips (the activation fragments shared by 64 columns).
 #include "strip_kernel.hpp"
 
 namespace qllm {
@@ -19,12 +20,13 @@ static int launch_sm_ra(const StripParams &p, int grid, size_t lds, hipStream_t 
     else
       return launch_strip_t<16, 1, 8, SPG, 1, 3, true, BF, 1, true>(p, grid, lds, stream);
   }
+  if (p.cpl == 4) return launch_strip_t<8, 4, 8, SPG, 1, 4, true, BF, 1, true>(p, grid, lds, stream);  // four strips per 8-wave block
   return p.nw == 8 ? launch_strip_t<8, 1, 8, SPG, 1, 4, true, BF, 1, true>(p, grid, lds, stream)
                    : launch_strip_t<16, 1, 8, SPG, 1, 4, true, BF, 1, true>(p, grid, lds, stream);
 }
 
 int launch_strip_sm_ra(const StripParams &p, int grid, hipStream_t stream) {
-  const size_t lds = strip_lds_bytes(p.M, p.spw, p.nw, 1, p.group_size, 1, 1);
+  const size_t lds = strip_lds_bytes(p.M, p.spw, p.nw, p.cpl, p.group_size, 1, 1);
   if (p.group_size == 64) return p.act_bf16 ? launch_sm_ra<2, true>(p, grid, lds, stream) : launch_sm_ra<2, false>(p, grid, lds, stream);
   return p.act_bf16 ? launch_sm_ra<4, true>(p, grid, lds, stream) : launch_sm_ra<4, false>(p, grid, lds, stream);
 }

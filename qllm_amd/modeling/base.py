@@ -116,8 +116,23 @@ def swap_quantized_linears(model: torch.nn.Module, quantized_names, cfg: QuantCo
     return target
 
 
-def load_quantized(model_dir: str, device: Optional[str] = "cuda", torch_dtype: Optional[torch.dtype] = None):
-    """Local equivalent of AutoQuantizedModelForCausalLM.from_quantized (base.py:226-322)."""
+def release_reference_layouts(model: torch.nn.Module, on: bool = True) -> int:
+    """Memory policy of the q_layers (q_layers/_hip_forward.py): once a layer's native copy exists on the device, drop the packed
+    reference buffers it duplicates (regenerated bit-exactly for state_dict / save_pretrained / unpack / .to()), so that a loaded
+    model costs 1.0x its checkpoint's bytes of HBM instead of 2.0x.  Returns the number of layers the policy was set on."""
+    from .q_layers import QuantLinearGPTQ, QuantLinearHQQ, QuantLinearORT, WQLinear_GEMM
+    n = 0
+    for m in model.modules():
+        if isinstance(m, (QuantLinearGPTQ, QuantLinearHQQ, QuantLinearORT, WQLinear_GEMM)):
+            m.release_reference = bool(on)
+            n += 1
+    return n
+
+
+def load_quantized(model_dir: str, device: Optional[str] = "cuda", torch_dtype: Optional[torch.dtype] = None,
+                   release_reference: bool = True):
+    """Local equivalent of AutoQuantizedModelForCausalLM.from_quantized (base.py:226-322).  `release_reference`: see
+    release_reference_layouts (QLLM_RELEASE_REFERENCE=0 in the environment keeps both copies)."""
     import transformers
 
     hf_cfg = transformers.AutoConfig.from_pretrained(model_dir)
@@ -156,6 +171,8 @@ def load_quantized(model_dir: str, device: Optional[str] = "cuda", torch_dtype: 
     model.load_report = dict(quantized_layers=len(quantized), unexpected_keys=unexpected)
     if device is not None:
         model = model.to(device)
+    if release_reference and os.environ.get("QLLM_RELEASE_REFERENCE", "1") != "0":
+        release_reference_layouts(model)
     return model.eval()
 
 

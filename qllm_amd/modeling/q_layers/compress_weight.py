@@ -104,7 +104,15 @@ class CompressWeight(object):
     def _work_device(self):
         return self.qweight.device
 
+    def _real_buffers(self):
+        """q_layers may hold their packed buffers as placeholders while the native copy serves the forward
+        (HipForwardMixin.release_reference): every accessor below works on the real tensors."""
+        m = getattr(self, "materialize_reference", None)
+        if m is not None:
+            m()
+
     def unpack_qzeros(self, device):
+        self._real_buffers()
         qzeros = self.qzeros.to(device)
         groups = math.ceil(self.infeatures / self.groupsize)
         zeros = torch.zeros((groups, self.outfeatures), dtype=torch.int32, device=device)
@@ -112,6 +120,7 @@ class CompressWeight(object):
         return zeros
 
     def unpack_qweight(self, device):
+        self._real_buffers()
         qweight = self.qweight.to(device)
         if _on_hip(qweight):
             from ... import ops
@@ -121,6 +130,7 @@ class CompressWeight(object):
         return weight
 
     def unpack(self):
+        self._real_buffers()
         """-> (W[N,K] in self.dtype, scales[G,N], zeros[G,N]) on CPU (reference compress_weight.py:136-151).
         The stored zeros are used as-is (no AutoGPTQ offset), exactly like the reference."""
         device = self._work_device()

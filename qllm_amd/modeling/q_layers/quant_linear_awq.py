@@ -7,7 +7,7 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
-from ._hip_forward import HipForwardMixin
+from ._hip_forward import HipForwardMixin, export_module_hooks
 from .compress_weight import CompressWeight, pack_bitstream, unpack_bitstream
 
 AWQ_ORDER = (0, 2, 4, 6, 1, 3, 5, 7)
@@ -19,9 +19,8 @@ def _awq_col_index(n: int, device) -> torch.Tensor:
     return (base + torch.tensor(AWQ_ORDER, device=device).unsqueeze(0)).reshape(-1)
 
 
+@export_module_hooks
 class WQLinear_GEMM(nn.Module, CompressWeight, HipForwardMixin):
-    __getstate__ = HipForwardMixin.__getstate__  # nn.Module precedes the mixin in the MRO
-
     def __init__(self, w_bit, group_size, in_features, out_features, bias, dtype=None):
         super().__init__()
         self.dtype = torch.get_default_dtype() if dtype is None else dtype
@@ -81,6 +80,7 @@ class WQLinear_GEMM(nn.Module, CompressWeight, HipForwardMixin):
         return self.reverse_reorder_int_tensor(zeros.T.contiguous())
 
     def unpack_qweight(self, device):
+        self._real_buffers()
         qweight = self.qweight.to(device)
         if qweight.is_cuda:
             from ... import ops

@@ -9,7 +9,7 @@ import weakref
 import torch
 import torch.nn as nn
 
-from ._hip_forward import HipForwardMixin, _tkey, autogptq_compat, tensor_version
+from ._hip_forward import HipForwardMixin, export_module_hooks, _tkey, autogptq_compat, tensor_version
 from .compress_weight import CompressWeight, general_pack_on_row, general_unpack_on_row
 
 
@@ -41,6 +41,7 @@ def _gathered(x: torch.Tensor, perm: torch.Tensor) -> torch.Tensor:
     return out
 
 
+@export_module_hooks
 class QuantLinearGPTQ(nn.Module, CompressWeight, HipForwardMixin):
     """Buffers (state-dict compatible with the reference / AutoGPTQ-style checkpoints):
         qweight i32 [K//32*bits, N]   column n = bit stream along K
@@ -49,8 +50,6 @@ class QuantLinearGPTQ(nn.Module, CompressWeight, HipForwardMixin):
         g_idx   i32 [K] (registered buffer; default k // g)
         bias    dtype [N] or None
     """
-
-    __getstate__ = HipForwardMixin.__getstate__  # nn.Module precedes the mixin in the MRO
 
 
     def __init__(self, bits, groupsize, infeatures, outfeatures, bias, dtype=None):
@@ -81,6 +80,7 @@ class QuantLinearGPTQ(nn.Module, CompressWeight, HipForwardMixin):
 
     def handle_qzeros_for_autogptq(self):
         """AutoGPTQ checkpoints store zero-1: re-pack as (z+1) & mask (reference quant_linear_gptq.py:119-134)."""
+        self.materialize_reference()
         if self.qzeros.numel() == 0:
             return
         qzeros = self.qzeros
@@ -93,46 +93,46 @@ class QuantLinearGPTQ(nn.Module, CompressWeight, HipForwardMixin):
         self.qzeros = new_q
         self._desc = None
 
-    # ---- act-order: row-sorted shadow ---------------------------------------------------------------------------------
-    _ao = None
-    _ao_key = None
+    # ---- act-order: the native copy holds the rows sorted by group ----------------------------------------------------------
+    # With act-order every k has its own group (g_idx gather per nibble).  GPTQ assigns whole groups of `groupsize` rows, so
+    # sorting the rows by group (perm = argsort(g_idx)) gives a plain contiguous-group layer: the native copy of an act-order
+    # layer is built from that row-permuted arrangement of its own integers (library unpack / pack kernels; bit-exact; the
+    # row-stream intermediate is dropped) and the forward feeds it x[..., perm] (qllm_gather_columns).  The fused kernels then
+    # run at their no-act-order speed plus one gather of x.  Groups that are not uniform, or QLLM_ACTORDER_SHADOW=0: no native
+    # copy -> the in-place gather kernel on the reference buffers.
+    _perm = None
 
-    def _act_order_shadow(self, add_zero_bias: int):
-        """With act-order every k has its own group (g_idx gather per nibble).  GPTQ assigns whole groups of
-        `groupsize` rows, so sorting the rows by group (perm = argsort(g_idx)) gives a plain contiguous-group layer:
-        the module keeps that row-permuted copy of its own 4-bit integers (built once on device with the library's
-        unpack/pack kernels; bit-exact, state dict untouched) and feeds it x[..., perm].  The fused kernels then run
-        at their no-act-order speed plus one gather of x.  Returns (descriptor, perm) or None if the groups are not
-        uniform / the shadow is disabled (QLLM_ACTORDER_SHADOW=0) -> the in-place gather kernel is used."""
+    def _native_source(self):
+        if not self.act_order:
+            return HipForwardMixin._native_source(self)
+        self._perm = None
         if os.environ.get("QLLM_ACTORDER_SHADOW", "1") == "0" or self.bits != 4 or not self.qweight.is_cuda:
             return None
         from ... import ops
-        key = (_tkey(self.qweight), _tkey(self.scales), _tkey(self.qzeros), _tkey(self.g_idx), _tkey(self.bias), add_zero_bias)
-        if self._ao is None or key != self._ao_key:
-            dev = self.qweight.device
-            g = self.g_idx.to(dev).long()
-            groups = math.ceil(self.infeatures / self.groupsize)
-            counts = torch.bincount(g, minlength=groups)
-            if self.infeatures % self.groupsize != 0 or counts.numel() != groups or not bool((counts == self.groupsize).all()):
-                self._ao, self._ao_key = False, key
-            else:
-                perm = torch.argsort(g, stable=True)
-                q = ops.unpack_qweight(self.qweight.contiguous(), "GPTQ", 4, self.infeatures, self.outfeatures)
-                qw = ops.pack_qweight(q.index_select(0, perm).contiguous(), "GPTQ", 4)
-                del q
-                b = self._f16(self.bias).contiguous() if self.bias is not None else None
-                desc = ops.make_weight("GPTQ", qw, self._f16(self.scales).contiguous(), self.qzeros.contiguous(), None, b,
-                                       self.infeatures, self.outfeatures, self.groupsize, 4, add_zero_bias)
-                # the row-sorted copy is a derived buffer anyway: keep it in the native layout (and drop the row-stream
-                # intermediate) when the layer fits it
-                if os.environ.get("QLLM_NATIVE_LAYOUT", "1") != "0":
-                    try:
-                        desc = ops.repack_native(*desc)
-                    except ops.QllmUnsupported:
-                        pass
-                del qw
-                self._ao, self._ao_key = (desc, _intern_perm(perm.to(torch.int32).contiguous())), key
-        return self._ao if self._ao else None
+        dev = self.qweight.device
+        g = self.g_idx.to(dev).long()
+        groups = math.ceil(self.infeatures / self.groupsize)
+        counts = torch.bincount(g, minlength=groups)
+        if self.infeatures % self.groupsize != 0 or counts.numel() != groups or not bool((counts == self.groupsize).all()):
+            return None
+        perm = torch.argsort(g, stable=True)
+        q = ops.unpack_qweight(self.qweight.contiguous(), "GPTQ", 4, self.infeatures, self.outfeatures)
+        qw = ops.pack_qweight(q.index_select(0, perm).contiguous(), "GPTQ", 4)
+        del q
+        b = self._f16(self.bias).contiguous() if self.bias is not None else None
+        self._perm = _intern_perm(perm.to(torch.int32).contiguous())
+        return ops.make_weight("GPTQ", qw, self._f16(self.scales).contiguous(), self.qzeros.contiguous(), None, b,
+                               self.infeatures, self.outfeatures, self.groupsize, 4, 0)
+
+    def _regenerate_reference(self):
+        qweight, scales, qzeros = HipForwardMixin._regenerate_reference(self)
+        if self.act_order and self._perm is not None:   # the native rows are sorted by group: undo the permutation
+            from ... import ops
+            q = ops.unpack_qweight(qweight, "GPTQ", 4, self.infeatures, self.outfeatures)
+            inv = torch.empty_like(self._perm, dtype=torch.long)
+            inv[self._perm.long()] = torch.arange(self._perm.numel(), device=inv.device)
+            qweight = ops.pack_qweight(q.index_select(0, inv).contiguous(), "GPTQ", 4)
+        return qweight, scales, qzeros
 
     def forward(self, x):
         if self.act_order is None:
@@ -141,14 +141,13 @@ class QuantLinearGPTQ(nn.Module, CompressWeight, HipForwardMixin):
         # COMPATIBLE_WITH_AUTOGPTQ is read per forward by the reference (:75); it becomes add_zero_bias here
         azb = autogptq_compat()
         if self.act_order and x.is_cuda:
-            ao = self._act_order_shadow(azb)
-            if ao is not None:
+            w = self.native_descriptor(azb)
+            if w is not None and self._perm is not None:
                 from ... import ops
-                (desc, _keep), perm = ao
-                x2d = _gathered(x, perm)
+                x2d = _gathered(x, self._perm)
                 try:
-                    return ops.linear_forward(desc, x2d).reshape(x.shape[:-1] + (self.outfeatures,))
+                    return ops.linear_forward(w, x2d).reshape(x.shape[:-1] + (self.outfeatures,))
                 except ops.QllmUnsupported:
-                    pass
+                    self._needs_reference = True   # a shape the native kernels do not serve: the in-place gather kernel below
         g_idx = self.g_idx if self.act_order else None
         return self._hip_linear(x, g_idx, azb)

@@ -8,16 +8,15 @@ import math
 import torch
 import torch.nn as nn
 
-from ._hip_forward import HipForwardMixin
+from ._hip_forward import HipForwardMixin, export_module_hooks
 from .compress_weight import CompressWeight
 
 
+@export_module_hooks
 class QuantLinearHQQ(nn.Module, CompressWeight, HipForwardMixin):
     """Buffers: qweight i32 [K//32*bits, N] (column bit streams, as GPTQ); qzeros and scales in the module dtype,
     [ceil(K/g), N] each (the zeros are real numbers: HQQ does not round them); bias [N] or None.  g_idx is a plain
     attribute (never act-order), exactly as in the reference."""
-
-    __getstate__ = HipForwardMixin.__getstate__  # nn.Module precedes the mixin in the MRO
 
 
     SUPPORTED_BITS = (2, 3, 4, 5, 6, 7, 8)
@@ -45,6 +44,7 @@ class QuantLinearHQQ(nn.Module, CompressWeight, HipForwardMixin):
         return "HQQ"
 
     def unpack_qzeros(self, device):
+        self._real_buffers()
         return self.qzeros.to(device)
 
     def pack_qzeros(self, intzeros, device):

@@ -24,7 +24,7 @@ import math
 import torch
 import torch.nn as nn
 
-from ._hip_forward import HipForwardMixin, _tkey
+from ._hip_forward import HipForwardMixin, export_module_hooks, _tkey
 from .compress_weight import CompressWeight
 
 
@@ -56,9 +56,8 @@ def dequantize_blockwise_4bits(quant_values, scale, zero_point, g_idx, rows, col
     return w, zeros, scale2
 
 
+@export_module_hooks
 class QuantLinearORT(nn.Module, CompressWeight, HipForwardMixin):
-    __getstate__ = HipForwardMixin.__getstate__  # nn.Module precedes the mixin in the MRO
-
     def __init__(self, bits, groupsize, infeatures, outfeatures, bias, dtype=None):
         super().__init__()
         self.dtype = torch.get_default_dtype() if dtype is None else dtype
@@ -186,17 +185,25 @@ class QuantLinearORT(nn.Module, CompressWeight, HipForwardMixin):
             self._desc_key = key
         return self._desc if self._desc else None
 
-    def _native_source(self, add_zero_bias: int):
+    _RELEASABLE = ()   # the blob itself stays (its regeneration would need the transposes back); the row-stream VIEW goes
+
+    def _native_source(self):
         if self._descriptor() is None:
             return None
         return self._desc, self._desc_keep
 
+    def native_descriptor(self, add_zero_bias: int = 0):
+        w = HipForwardMixin.native_descriptor(self, 0)
+        if w is not None:   # the transposed view was only the source of the native copy: one derived copy, not two
+            self._desc = self._desc_keep = self._desc_key = None
+        return w
+
+    def materialize_reference(self):
+        pass
+
     def decode_descriptor(self, act_order_g_idx=None, add_zero_bias: int = 0):
         w = self.native_descriptor(0)
         return w if w is not None else self._descriptor()
-
-    def _prefill_descriptor(self, act_order_g_idx=None, add_zero_bias: int = 0):
-        return self._descriptor()
 
     def forward(self, x):
         if self._descriptor() is None:  # irregular act-order: the reference's own two-step path, on device

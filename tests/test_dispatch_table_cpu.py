@@ -127,6 +127,10 @@ def test_native_layout_decode_routes(lib):
     assert plan(lib, [attn], 4) == "strip nw=8 cpl=1 spw=16 form=lds-slab row_tiles=1" + sm
     for m in (5, 16):
         assert plan(lib, [attn], m) == "strip nw=16 cpl=1 spw=8 form=register-A row_tiles=1" + sm
+    # M = 5..16 on wide (grouped) launches: blocks of four adjacent strips share the activation fragments
+    assert plan(lib, [attn] * 3, 16) == "strip nw=8 cpl=4 spw=16 form=register-A row_tiles=1" + sm
+    assert plan(lib, [up] * 2, 8) == "strip nw=8 cpl=4 spw=16 form=register-A row_tiles=1" + sm
+    assert plan(lib, [W(4096, 11008, 64, 4, NATIVE_F16Z)] * 2, 16) == "strip nw=8 cpl=4 spw=16 form=register-A row_tiles=1" + sm
     assert plan(lib, [attn], 32) == "strip nw=8 cpl=1 spw=16 form=register-A row_tiles=2" + sm
     assert plan(lib, [up] * 2, 64) == "strip nw=8 cpl=1 spw=16 form=register-A row_tiles=4" + sm
     # shard shapes of Llama-2-70B (TP = 8): short K -> 4-wave blocks, K = 8192 -> 8 waves x one round of 32

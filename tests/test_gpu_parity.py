@@ -235,7 +235,7 @@ def test_act_order_nonuniform_groups_use_inplace_gather():
     for m in (1, 16, 200):
         x = randx(m, 1024, seed=m)
         y = layer(torch.from_numpy(x).to(DEV)).cpu().numpy()
-        assert layer._ao is False  # shadow rejected
+        assert layer.native_descriptor(0) is None and layer._perm is None  # no row-sorted native copy for such a layer
         assert O.rel_err(y, ref.y16(x)) <= TOL
 
 
@@ -533,13 +533,19 @@ GEMM3_CASES = [
 ]
 
 
+@pytest.mark.parametrize("native", [1, 0])
 @pytest.mark.parametrize("layout,g,K,N,zk,bias", GEMM3_CASES)
-def test_wave_specialised_prefill_kernel_vs_oracle(layout, g, K, N, zk, bias):
+def test_wave_specialised_prefill_kernel_vs_oracle(layout, g, K, N, zk, bias, native, monkeypatch):
+    """native = 1: the staging waves read the strip-major native copy (what the modules do by default); 0: the reference buffers
+    in place (GPTQ / HQQ row stream, AWQ words)."""
     from qllm_amd import ops
+    monkeypatch.setenv("QLLM_NATIVE_LAYOUT", str(native))
     d = synth(layout, 4, g, K, N, zk, False, bias, seed=K + N + 7)
     layer = to_layer(d, DEV)
     ref = Ref(d)
     big = K * N >= 4096 * 4096
+    if native:
+        assert "layout=strip-major" in ops.plan_describe([layer.decode_descriptor()], 2048), ops.plan_describe([layer.decode_descriptor()], 2048)
     for m in ((1024, 2048, 2049) if big else (8192, 8300, 6657)):   # whole tiles, and rows that end inside a 256-row tile
         if m >= 2048:  # (fewer rows: too few tiles for the CUs -> gemm2's split-K form)
             assert ops.plan_describe([layer._descriptor(None, 0)], m).startswith("gemm3"), (layout, K, N, m)
@@ -550,7 +556,7 @@ def test_wave_specialised_prefill_kernel_vs_oracle(layout, g, K, N, zk, bias):
         assert O.rel_err(y, ref.y64(x)) <= 2e-3, (layout, K, N, m)
     if big:
         return
-    # bf16 activations at the same size take gemm2 (the DMA path cannot convert on the way): still exact to tolerance
+    # bf16 activations: the same kernel behind a bf16 -> fp16 pre-pass of x, the fp16 result rounded to bf16 (the reference's shim)
     xb = torch.from_numpy(randx(4096, K, seed=3)).to(torch.bfloat16)
     yb = layer(xb.to(DEV))
     assert yb.dtype == torch.bfloat16
