@@ -479,8 +479,13 @@ int qllm_device_info(int device, qllm_device_info_t *out) {
 
 size_t qllm_workspace_bytes(const qllm_weight_t *w, int32_t M) {
   if (!w || M <= 0) return kCounterBytes;
-  if (M > 64)  // prefill: fp32 partial tiles of the split-K GEMM (mid-size M only) + the fp16 copy of bf16 activations (gemm3)
-    return kCounterBytes + align_up(gemm2_slab_bytes(M, w->N, gemm2_split_k(M, w->N, w->K)), 256) + bf16_copy_bytes(M, w->K, 1);
+  if (M > 64) {  // prefill: fp32 partial tiles of the split-K GEMM (mid-size M only) + the fp16 copy of bf16 activations where
+    GemmParams p;  // the wave-specialised kernel would serve the call (the caller's activation dtype is not known here)
+    fill_gemm_params(p, w, nullptr, nullptr, M, QLLM_F16);
+    p.g_idx = nullptr;
+    const bool g3 = gemm3_ok(p, w->bits == 3 ? kGemm3Rows3Bit : (w->layout == QLLM_LAYOUT_AWQ_GEMM ? QLLM_LAYOUT_AWQ_GEMM : QLLM_LAYOUT_GPTQ));
+    return kCounterBytes + align_up(gemm2_slab_bytes(M, w->N, gemm2_split_k(M, w->N, w->K)), 256) + (g3 ? bf16_copy_bytes(M, w->K, 1) : 0);
+  }
   return kCounterBytes + align_up((size_t)skinny_max_split(M) * M * w->N * sizeof(float), 256);
 }
 

@@ -56,12 +56,13 @@ def test_workspace_bytes_is_pure(lib):
     b1 = lib.qllm_workspace_bytes(ctypes.byref(w), 1)
     b16 = lib.qllm_workspace_bytes(ctypes.byref(w), 16)
     assert b1 >= 16384 and b16 > b1
-    assert lib.qllm_workspace_bytes(ctypes.byref(w), 2048) == 16384  # 256 tiles of 256x128: one block per CU, no split-K
+    # 256 tiles of 256x128: one block per CU, no split-K; + the fp16 copy of x the wave-specialised kernel reads when x is bf16
+    assert lib.qllm_workspace_bytes(ctypes.byref(w), 2048) == 16384 + 2048 * 4096 * 2
     # mid-size M: split-K partial tiles.  M=512: 64 tiles x S=4 (the largest S with tiles*S <= 256 CUs, >= 8 k-tiles each)
     tile = 256 * 128 * 4
     assert lib.qllm_workspace_bytes(ctypes.byref(w), 512) == 16384 + 64 * 4 * tile
     assert lib.qllm_workspace_bytes(ctypes.byref(w), 256) == 16384 + 32 * 8 * tile
-    assert lib.qllm_workspace_bytes(ctypes.byref(w), 1024) == 16384 + 128 * 2 * tile
+    assert lib.qllm_workspace_bytes(ctypes.byref(w), 1024) == 16384 + 128 * 2 * tile + 1024 * 4096 * 2
     wide = _lib.QllmWeight(16, 16, 16, None, None, 4096, 11008, 128, 4, 0, 0)
     assert lib.qllm_workspace_bytes(ctypes.byref(wide), 512) == 16384      # 172 tiles: a split would need two rounds of blocks
     short = _lib.QllmWeight(16, 16, 16, None, None, 512, 4096, 128, 4, 0, 0)
@@ -69,6 +70,8 @@ def test_workspace_bytes_is_pure(lib):
     ragged = _lib.QllmWeight(16, 16, 16, None, None, 4096, 4000, 128, 4, 0, 0)
     assert lib.qllm_workspace_bytes(ctypes.byref(ragged), 512) == 16384    # N % 128 != 0: the 128x128 kernel, no slabs
     assert 16384 + 64 * 4 * tile <= 64 << 20                               # fits the 64 MB the Python wrapper allocates up front
+    down = _lib.QllmWeight(16, 16, 16, None, None, 11008, 4096, 128, 4, 0, 0)
+    assert lib.qllm_workspace_bytes(ctypes.byref(down), 2048) <= 64 << 20  # ... also with the bf16 copy of a [2048, 11008] input
 
 
 def test_device_probe_fails_cleanly_without_gpu(lib):
