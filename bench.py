@@ -295,6 +295,7 @@ def main():
     ap.add_argument("--fused", type=int, default=int(os.environ.get("QLLM_BENCH_FUSED", "1")),
                     help="1: sibling groups (q/k/v and gate/up as one grouped launch each: 4 launches per layer instead of 7)")
     ap.add_argument("--tp", type=int, default=0, help="Llama-2-70B tensor-parallel leg (BASELINE configs[4]); 1 = shard shapes on one GPU")
+    ap.add_argument("--tp-layers", type=int, default=0, help="--tp: decoder layers of the stack (default: all 80)")
     ap.add_argument("--no-extra", action="store_true", help="skip the per-shape / prefill / CPU legs")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 PMC passes behind roofline.traffic")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)

@@ -174,8 +174,9 @@ static bool strip_plan(const qllm_weight_t *w, int n, int M, StripPlan *plan) {
     // register-A form at M = 5..16, 4 bits, every layer a multiple of 64 wide and enough of them: blocks of four adjacent strips
     // (a register-A block re-reads all of x from L2; 64 columns share it instead of 16)
     static int sm_ra_cpl4 = env_int("QLLM_SM_RA_CPL4", 1);
-    const int cpl = (sm_ra_cpl4 && slab_nw == 0 && M >= 5 && M <= 16 && bits == 4 && m64 && cols / 64 >= compute_units() / 2) ? 4 : 1;
-    int nw = (M > 16 || cpl == 4) ? 8 : (slab_nw ? slab_nw : 16);
+    // (3 bits: two strips -- four need more than 256 registers)
+    const int cpl = (sm_ra_cpl4 && slab_nw == 0 && M >= 5 && M <= 16 && m64 && cols / 64 >= compute_units() / 2) ? (bits == 3 ? 2 : 4) : 1;
+    int nw = (M > 16 || cpl > 1) ? 8 : (slab_nw ? slab_nw : 16);
     for (int tries = 0; tries < 2; ++tries) {
       const int spw = strip_spw(w[0].K, w[0].group_size, nw);
       const int ra = (slab_nw == 0 || (longk && nw == 16)) ? 1 : 0;
@@ -188,7 +189,7 @@ static bool strip_plan(const qllm_weight_t *w, int n, int M, StripPlan *plan) {
         plan->sm = 1;
         return true;
       }
-      if (nw == 16 || M > 16 || cpl == 4) break;
+      if (nw == 16 || M > 16 || cpl > 1) break;
       nw = 16;  // shorter per-wave chunks
     }
     return false;

@@ -69,15 +69,19 @@ __device__ __forceinline__ float dpp_add(float v) {
 //       every block re-reads all of x from L2) are shared by 64 columns instead of 16; each wave-load is still 256 contiguous bytes.
 // DBG: diagnostics instantiation: wave 0 of the first, the middle and the last block record 100 MHz timestamps
 //       [entry, loads issued, x staged, rounds done, after the barrier, exit] into p.dbg (tools/lab/cbench --timeline).
-template <int NW, int CPL, int MAXS, int SPG, int XL, int BITS, bool RA = false, bool RA_BF16 = false, int MT = 1, bool SM = false, bool DBG = false>
+// ONER (strip-major batch-1 slab form): the wave's chunk is exactly ONE round (spw == MAXS, checked by the host): the chunk
+//       geometry folds to constants (about a fifth of the instructions in front of the first weight load).
+template <int NW, int CPL, int MAXS, int SPG, int XL, int BITS, bool RA = false, bool RA_BF16 = false, int MT = 1, bool SM = false, bool DBG = false,
+          bool ONER = false>
 // (second launch-bound = minimum waves per SIMD: the 8-wave 64-column slab variant sits right at the 128-register edge
 //  that lets two blocks share a CU -- 130 registers halve its occupancy: gate/up 13.7 -> 15.0 us; the strip-major 4- and 8-wave
 //  forms are held to 128 registers; forcing 64 / 80 costs 7-55 spilled registers, the natural allocation is 80 / 126)
 __global__ __launch_bounds__(NW * 64, (SM && !RA && NW <= 8) ? ((NW == 8 && MAXS == 16 && SPG == 4 && XL <= 2) ? 6 : 4) : ((NW == 8 && CPL == 4 && SPG == 4 && !RA) ? 4 : 1)) void strip_kernel(const StripParams p) {
-  static_assert(BITS == 4 || (BITS == 3 && CPL == 1), "3-bit strips are 16 columns wide");
+  static_assert(BITS == 4 || (BITS == 3 && (CPL == 1 || SM)), "3-bit row-stream strips are 16 columns wide");
   static_assert(!RA || MAXS == 8, "register-A rounds are 8 k-steps");
   static_assert(MT == 1 || (RA && CPL == 1), "several row tiles: register-A, 16-column strips");
-  static_assert(!SM || CPL == 1 || (RA && BITS == 4 && MT == 1), "strip-major blocks of several 16-column strips: register-A form, 4 bits");
+  static_assert(!SM || CPL == 1 || (RA && MT == 1), "strip-major blocks of several 16-column strips: register-A form, one row tile");
+  static_assert(!ONER || (SM && !RA && XL <= 2), "one-round fold: strip-major batch-1 slab form");
   constexpr int NG = MAXS / SPG;   // groups per round (MAXS is a multiple of SPG; rounds start on a group boundary)
   constexpr int TN = 16 * CPL;     // columns per block
   constexpr int GL = 4 * SPG;      // lanes (16-byte chunks) per group in the staging pass: 8 or 16
@@ -102,10 +106,16 @@ __global__ __launch_bounds__(NW * 64, (SM && !RA && NW <= 8) ? ((NW == 8 && MAXS
   }
 
   int pi = 0;
-  if (p.n_prob > 1) {  // (single-layer launches skip the 35 scalar instructions of the search)
+  if (p.n_prob > 1) {  // (single-layer launches skip the search; q/k/v and gate/up take two or one comparisons, not seven)
+    pi = ((int)blockIdx.x >= p.block_begin8[1]) ? 1 : 0;
+    if (p.n_prob > 2) {
+      pi = ((int)blockIdx.x >= p.block_begin8[2]) ? 2 : pi;
+      if (p.n_prob > 3) {
 #pragma unroll
-    for (int q = 1; q < kMaxProblems; ++q)
-      if (q < p.n_prob && (int)blockIdx.x >= p.block_begin8[q]) pi = q;
+        for (int q = 3; q < kMaxProblems; ++q)
+          if (q < p.n_prob && (int)blockIdx.x >= p.block_begin8[q]) pi = q;
+      }
+    }
   }
   // ... and the whole problem record plus the remaining launch scalars pulled in ONE batch: the empty asm "uses" them here, so
   // hipcc must have issued every s_load before this point instead of one at a time at first use
@@ -131,10 +141,11 @@ __global__ __launch_bounds__(NW * 64, (SM && !RA && NW <= 8) ? ((NW == 8 && MAXS
   constexpr bool WIN = SM && !RA;
   const int M = M1 ? 1 : p.M;
 
-  const int t0 = wave * p.spw;                    // spw is a multiple of SPG: every wave starts on a group boundary
-  const int kend = min(32 * (t0 + p.spw), p.K);   // activations at k >= kend are staged as zero
-  const int tend = min(t0 + p.spw, p.T);          // WIN: the wave owns k-steps [t0, tend)
-  const int rounds = (p.spw + MAXS - 1) / MAXS;
+  const int spw = ONER ? MAXS : p.spw;
+  const int t0 = wave * spw;                      // spw is a multiple of SPG: every wave starts on a group boundary
+  const int kend = min(32 * (t0 + spw), p.K);     // activations at k >= kend are staged as zero
+  const int tend = min(t0 + spw, p.T);            // WIN: the wave owns k-steps [t0, tend)
+  const int rounds = ONER ? 1 : (spw + MAXS - 1) / MAXS;
   const int spw_pad = rounds * MAXS;
   const int ngw = spw_pad / SPG;                  // groups in this wave's (padded) chunk
 
@@ -297,6 +308,7 @@ __global__ __launch_bounds__(NW * 64, (SM && !RA && NW <= 8) ? ((NW == 8 && MAXS
     const int G0 = base / SPG;
     half_t sc[NG][CPL];
     uint32_t zraw[NG][(SM && CPL > 2) ? CPL : 2];  // strip-major blocks of several strips: one zero-point word per strip
+    uint32_t zraw2[(SM && CPL > 1 && BITS == 3) ? NG : 1][CPL];  // ... and, 3 bits packed, the word the field may straddle into
     if constexpr (WIN) {
       // wave-uniform group base + the lane's fixed offset: the loads of the round differ by immediate offsets only
       const half_t *sl = scp + (size_t)G0 * 16;
@@ -316,6 +328,7 @@ __global__ __launch_bounds__(NW * 64, (SM && !RA && NW <= 8) ? ((NW == 8 && MAXS
         for (int c = 0; c < CPL; ++c) {
           sc[j][c] = scp[((size_t)c * (Gmax + 1) + G) * 16];
           zraw[j][c] = zbase[((size_t)c * (Gmax + 1) + G) * zmul + zoff];
+          if constexpr (BITS == 3) zraw2[j][c] = zbase[((size_t)c * (Gmax + 1) + G) * zmul + zoff + zoff2];
         }
       } else {
       if constexpr (CPL == 4) {
@@ -343,7 +356,7 @@ __global__ __launch_bounds__(NW * 64, (SM && !RA && NW <= 8) ? ((NW == 8 && MAXS
     // ---- 3. every weight load of this round: exactly MAXS loads, rows clamped into the matrix;
     //         address = wave-uniform row base (SALU) + one per-lane 32-bit offset -------------------------------------
     wvec_t w[MAXS];
-    uint32_t w_hi[BITS == 3 ? MAXS : 1];
+    wvec_t w_hi[BITS == 3 ? MAXS : 1];
     if constexpr (WIN) {
       const uint32_t *wl = qw + (size_t)base * (WR * 16);  // wave-uniform
 #pragma unroll
@@ -352,7 +365,7 @@ __global__ __launch_bounds__(NW * 64, (SM && !RA && NW <= 8) ? ((NW == 8 && MAXS
           w[s][0] = __builtin_nontemporal_load(wl + lane_off + s * (WR * 16));
         } else {
           w[s][0] = __builtin_nontemporal_load(wl + lane_off3_lo + s * (WR * 16));
-          w_hi[s] = __builtin_nontemporal_load(wl + lane_off3_hi + s * (WR * 16));
+          w_hi[s][0] = __builtin_nontemporal_load(wl + lane_off3_hi + s * (WR * 16));
         }
       }
     } else {
@@ -361,13 +374,20 @@ __global__ __launch_bounds__(NW * 64, (SM && !RA && NW <= 8) ? ((NW == 8 && MAXS
       const uint32_t *rowp = qw + (size_t)(WR * min(base + s, tmax)) * WS;
       if constexpr (SM && CPL > 1) {
 #pragma unroll
-        for (int c = 0; c < CPL; ++c) w[s][c] = __builtin_nontemporal_load(rowp + c * strip_words + lane_off);
+        for (int c = 0; c < CPL; ++c) {
+          if constexpr (BITS == 4) {
+            w[s][c] = __builtin_nontemporal_load(rowp + c * strip_words + lane_off);
+          } else {
+            w[s][c] = __builtin_nontemporal_load(rowp + c * strip_words + lane_off3_lo);
+            w_hi[s][c] = __builtin_nontemporal_load(rowp + c * strip_words + lane_off3_hi);
+          }
+        }
       } else if constexpr (BITS == 4) {
         w[s] = __builtin_nontemporal_load((const wvec_t *)(rowp + lane_off));
       } else {
         // 32 k = 3 words: lane group g needs stream bits [24g, 24g+24) = words {0,0,1,2}[g] and {0,1,2,2}[g]
         w[s][0] = __builtin_nontemporal_load(rowp + lane_off3_lo);
-        w_hi[s] = __builtin_nontemporal_load(rowp + lane_off3_hi);
+        w_hi[s][0] = __builtin_nontemporal_load(rowp + lane_off3_hi);
       }
     }
     }
@@ -397,7 +417,7 @@ __global__ __launch_bounds__(NW * 64, (SM && !RA && NW <= 8) ? ((NW == 8 && MAXS
       half8_t av[MT];
       if constexpr (RA) {
         // k-steps past this wave's chunk (padding of the last round) or past K contribute nothing: zero multipliers
-        const bool valid = (r * MAXS + s < p.spw) && (base + s <= tmax);
+        const bool valid = (r * MAXS + s < spw) && (base + s <= tmax);
         const half_t one = valid ? (half_t)1.f : (half_t)0.f;
         const float4_t zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -435,7 +455,7 @@ __global__ __launch_bounds__(NW * 64, (SM && !RA && NW <= 8) ? ((NW == 8 && MAXS
           // f: the lane's 8 three-bit values at bits 0,3,..,21.  f1 = f << 1 puts q5,q6,q7 at bits 16,19,22 (upper half,
           // offsets 0,3,6) and q0,q1,q2 at bits 1,4,7 (lower half): three v_and_or give (2 q0, q5), (16 q1, 8 q6),
           // (128 q2, 64 q7) on top of 1024; q3,q4 (bits 9,12) are moved to bit 0 / bit 16 separately.
-          const uint32_t f = __builtin_amdgcn_alignbit(w_hi[s], w[s][0], shift3);
+          const uint32_t f = __builtin_amdgcn_alignbit(w_hi[s][c], w[s][c], shift3);
           const uint32_t f1 = f << 1;
           b0 = as_h2((f1 & m3a) | kMagic);
           b1 = as_h2((f1 & m3b) | kMagic);
@@ -468,7 +488,7 @@ __global__ __launch_bounds__(NW * 64, (SM && !RA && NW <= 8) ? ((NW == 8 && MAXS
         for (int c = 0; c < CPL; ++c) {
           // this group's scale / zero of column n+c, converted to fp32 here (keeps the raw 16/32-bit words live instead)
           constexpr bool MS = SM && CPL > 1;  // several strips per block: column i of strip c, its own zero-point word
-          const uint32_t zfield = (BITS == 3) ? (uint32_t)(((((uint64_t)zraw[j][1]) << 32) | zraw[j][0]) >> ((3 * zcol) & 31))
+          const uint32_t zfield = (BITS == 3) ? (uint32_t)(((((uint64_t)(MS ? zraw2[MS ? j : 0][c] : zraw[j][1])) << 32) | (MS ? zraw[j][c] : zraw[j][0])) >> ((3 * zcol) & 31))
                                               : (MS ? (zraw[j][c] >> (4 * (zcol & 7))) : (zraw[j][0] >> (4 * ((zcol + c) & 7))));
           const float zp = (float)((zfield + (uint32_t)p.add_zero_bias) & (uint32_t)((1 << BITS) - 1));
           const uint32_t zd = MS ? zraw[j][c] : ((CPL >= 2) ? zraw[j][c >> 1] : zraw[j][0]);
@@ -489,7 +509,8 @@ __global__ __launch_bounds__(NW * 64, (SM && !RA && NW <= 8) ? ((NW == 8 && MAXS
       }
     }
   };
-  for (int r = 0; r < rounds; ++r) round_body(r);
+  if constexpr (ONER) round_body(0);
+  else for (int r = 0; r < rounds; ++r) round_body(r);
   if constexpr (DBG) {
     if (dbg_slot && lane == 0) dbg_slot[3] = __builtin_amdgcn_s_memrealtime();
   }
@@ -526,12 +547,13 @@ __global__ __launch_bounds__(NW * 64, (SM && !RA && NW <= 8) ? ((NW == 8 && MAXS
   }
 }
 
-template <int NW, int CPL, int MAXS, int SPG, int XL, int BITS = 4, bool RA = false, bool RA_BF16 = false, int MT = 1, bool SM = false, bool DBG = false>
+template <int NW, int CPL, int MAXS, int SPG, int XL, int BITS = 4, bool RA = false, bool RA_BF16 = false, int MT = 1, bool SM = false, bool DBG = false,
+          bool ONER = false>
 static int launch_strip_t(const StripParams &p, int grid, size_t lds, hipStream_t stream) {
   // the >64 KB dynamic-LDS opt-in is a per-DEVICE function attribute: latch it per (kernel instantiation, device)
   static DeviceLatch attr_done;
-  if (int rc = lds_optin(attr_done, (const void *)strip_kernel<NW, CPL, MAXS, SPG, XL, BITS, RA, RA_BF16, MT, SM, DBG>)) return rc;
-  hipLaunchKernelGGL((strip_kernel<NW, CPL, MAXS, SPG, XL, BITS, RA, RA_BF16, MT, SM, DBG>), dim3(grid), dim3(NW * 64), lds, stream, p);
+  if (int rc = lds_optin(attr_done, (const void *)strip_kernel<NW, CPL, MAXS, SPG, XL, BITS, RA, RA_BF16, MT, SM, DBG, ONER>)) return rc;
+  hipLaunchKernelGGL((strip_kernel<NW, CPL, MAXS, SPG, XL, BITS, RA, RA_BF16, MT, SM, DBG, ONER>), dim3(grid), dim3(NW * 64), lds, stream, p);
   QLLM_HIP_CHECK(hipGetLastError());
   return QLLM_OK;
 }

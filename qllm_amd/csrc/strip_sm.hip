@@ -32,7 +32,10 @@ static int launch_sm_slab(const StripParams &p, int grid, size_t lds, hipStream_
   const bool small_x = p.M == 1 && strip_xl(p.nw, 1, p.spw, 1, 1) <= 2;  // the XL = 2 instantiations are batch-1 kernels (M folded)
   const int maxs = strip_maxs(p.nw, p.spw, 1, 0, 1);
   // instantiations are limited to the forms the planner reaches AND that do not spill (tests/test_kernel_resources_cpu.py)
-#define QLLM_SM1(NW_, MAXS_) return launch_strip_t<NW_, 1, MAXS_, SPG, 2, BITS, false, false, 1, true, DBG>(p, grid, lds, stream)
+  // batch-1 forms: the one-round instantiation when the wave chunk is exactly one round (every Llama-class shape)
+#define QLLM_SM1(NW_, MAXS_)                                                                                                   \
+  return (p.spw == MAXS_) ? launch_strip_t<NW_, 1, MAXS_, SPG, 2, BITS, false, false, 1, true, DBG, true>(p, grid, lds, stream) \
+                          : launch_strip_t<NW_, 1, MAXS_, SPG, 2, BITS, false, false, 1, true, DBG, false>(p, grid, lds, stream)
 #define QLLM_SM8(NW_, MAXS_) return launch_strip_t<NW_, 1, MAXS_, SPG, 8, BITS, false, false, 1, true, DBG>(p, grid, lds, stream)
   if constexpr (BITS == 3) {
     if (p.nw == 16 && maxs == 8) { if (small_x) { QLLM_SM1(16, 8); } else { QLLM_SM8(16, 8); } }

@@ -14,6 +14,7 @@ static int launch_sm_ra(const StripParams &p, int grid, size_t lds, hipStream_t 
     }
     return p.M > 32 ? launch_strip_t<8, 1, 8, SPG, 1, 4, true, BF, 4, true>(p, grid, lds, stream) : launch_strip_t<8, 1, 8, SPG, 1, 4, true, BF, 2, true>(p, grid, lds, stream);
   }
+  if (p.bits == 3 && p.cpl == 2) return launch_strip_t<8, 2, 8, SPG, 1, 3, true, BF, 1, true>(p, grid, lds, stream);  // (four 3-bit strips spill)
   if (p.bits == 3) {
     if constexpr (SPG == 2 && BF)  // (this one spills 7 registers: not built; callers stream the reference layout in place)
       return set_error(QLLM_ERR_UNSUPPORTED, "3-bit g64 native-layout layers with bf16 activations: no strip-major kernel");

@@ -177,6 +177,21 @@ class HipForwardMixin:
                 return w
         return self._descriptor(act_order_g_idx, add_zero_bias)
 
+    def forward_into(self, x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+        """y = forward(x) written into the caller's contiguous [M, out_features] tensor `out` (no allocation; used by the
+        tensor-parallel wrappers, whose shard kernels write straight into their slice of the gathered output).  Layers without a
+        plain fused path for the call (act-order, unsupported shapes) compute normally and copy."""
+        x2d = x.reshape(-1, x.shape[-1])
+        if getattr(self, "act_order", None) or not x2d.is_contiguous() or not out.is_contiguous():
+            out.copy_(self(x).reshape(out.shape))
+            return out
+        azb = autogptq_compat() if self._layout_name() == "GPTQ" else 0
+        try:
+            ops.linear_forward(self.decode_descriptor(None, azb), x2d, out=out.view(x2d.shape[0], self.outfeatures))
+        except ops.QllmUnsupported:
+            out.copy_(self(x).reshape(out.shape))
+        return out
+
     def _hip_linear(self, x: torch.Tensor, act_order_g_idx=None, add_zero_bias: int = 0) -> torch.Tensor:
         if not x.is_cuda or not self.qweight.is_cuda:
             raise RuntimeError(

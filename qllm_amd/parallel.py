@@ -93,8 +93,11 @@ def shard_rows(layer: nn.Module, rank: int, world: int) -> nn.Module:
 
 
 class ColumnParallelQuantLinear(nn.Module):
+    """`static_output=True`: the gathered output lives in a buffer the module owns and re-uses (the contract of a hipGraph's
+    static outputs: valid until the next call) -- the forward then allocates nothing at all."""
+
     def __init__(self, shard: nn.Module, out_features: int, group=None, gather_output: bool = True,
-                 collective: str = "all_gather"):
+                 collective: str = "all_gather", static_output: bool = False):
         super().__init__()
         assert collective in ("all_gather", "all_reduce")
         self.shard = shard
@@ -102,50 +105,94 @@ class ColumnParallelQuantLinear(nn.Module):
         self.group = group
         self.gather_output = gather_output
         self.collective = collective
+        self.static_output = static_output
+        self._bufs: dict = {}
 
     @classmethod
-    def from_full(cls, layer: nn.Module, group=None, gather_output: bool = True, collective: str = "all_gather"):
+    def from_full(cls, layer: nn.Module, group=None, gather_output: bool = True, collective: str = "all_gather",
+                  static_output: bool = False):
         rank, world = _world(group)
-        return cls(shard_columns(layer, rank, world), layer.outfeatures, group, gather_output, collective)
+        return cls(shard_columns(layer, rank, world), layer.outfeatures, group, gather_output, collective, static_output)
+
+    def _buffer(self, tag, shape, dtype, device, zero=False):
+        if not self.static_output:
+            return (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=device)
+        key = (tag, tuple(shape), dtype, device)
+        buf = self._bufs.get(key)
+        if buf is None:
+            buf = self._bufs[key] = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=device)
+        return buf
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        y = self.shard(x)  # [..., N/P] through the fused kernel
         rank, world = _world(self.group)
         if not self.gather_output or world == 1:
-            return y
-        nl = y.shape[-1]
+            return self.shard(x)  # [..., N/P] through the fused kernel
+        nl = self.shard.outfeatures
+        lead = tuple(x.shape[:-1])
+        m = 1
+        for d in lead:
+            m *= int(d)
+        full = self._buffer("full", (m, world * nl), x.dtype, x.device, zero=(self.collective == "all_reduce" and m > 1))
+        if m == 1:
+            # decode: the rank's slice of the [1, N] output is contiguous -- the shard kernel writes it in place and the
+            # collective runs in place on `full` (all_gather: input = the slice at offset rank * nl of the output; all_reduce:
+            # the other slices are zero).  One output tensor (none with static_output), no temporaries, no permute.
+            if self.collective == "all_reduce":
+                full.zero_()
+            self.shard.forward_into(x, full[:, rank * nl:(rank + 1) * nl])
+            if self.collective == "all_gather":
+                dist.all_gather_into_tensor(full.view(world * nl), full.view(world * nl)[rank * nl:(rank + 1) * nl], group=self.group)
+            else:
+                dist.all_reduce(full, op=dist.ReduceOp.SUM, group=self.group)  # disjoint slices: exact
+            return full.view(lead + (world * nl,))
         if self.collective == "all_gather":
-            y2 = y.reshape(-1, nl).contiguous()
-            parts = torch.empty((world * y2.shape[0], nl), dtype=y.dtype, device=y.device)
-            dist.all_gather_into_tensor(parts, y2, group=self.group)  # rank-major concatenation along dim 0
-            full = parts.view(world, y2.shape[0], nl).permute(1, 0, 2).reshape(y2.shape[0], world * nl)
-            return full.reshape(tuple(y.shape[:-1]) + (world * nl,))
-        full = torch.zeros(tuple(y.shape[:-1]) + (world * nl,), dtype=y.dtype, device=y.device)
-        full[..., rank * nl:(rank + 1) * nl] = y
+            # rank-major [P, M, N/P] gather buffer; the shard writes its own [M, N/P] block in place, one strided copy
+            # re-arranges to [M, P * N/P]
+            parts = self._buffer("parts", (world, m, nl), x.dtype, x.device)
+            self.shard.forward_into(x, parts[rank])
+            dist.all_gather_into_tensor(parts.view(world * m, nl), parts[rank], group=self.group)
+            full.view(m, world, nl).copy_(parts.permute(1, 0, 2))
+            return full.view(lead + (world * nl,))
+        y = self._buffer("y", (m, nl), x.dtype, x.device)
+        self.shard.forward_into(x, y)
+        if self.static_output:
+            full.zero_()
+        full[:, rank * nl:(rank + 1) * nl] = y
         dist.all_reduce(full, op=dist.ReduceOp.SUM, group=self.group)  # disjoint slices: exact
-        return full
+        return full.view(lead + (world * nl,))
 
 
 class RowParallelQuantLinear(nn.Module):
-    def __init__(self, shard: nn.Module, group=None, input_is_parallel: bool = True):
+    def __init__(self, shard: nn.Module, group=None, input_is_parallel: bool = True, static_output: bool = False):
         super().__init__()
         self.shard = shard
         self.group = group
         self.input_is_parallel = input_is_parallel
+        self.static_output = static_output
+        self._bufs: dict = {}
 
     @classmethod
-    def from_full(cls, layer: nn.Module, group=None, input_is_parallel: bool = True):
+    def from_full(cls, layer: nn.Module, group=None, input_is_parallel: bool = True, static_output: bool = False):
         rank, world = _world(group)
-        return cls(shard_rows(layer, rank, world), group, input_is_parallel)
+        return cls(shard_rows(layer, rank, world), group, input_is_parallel, static_output)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         rank, world = _world(self.group)
         if not self.input_is_parallel and world > 1:
             kl = x.shape[-1] // world
             x = x[..., rank * kl:(rank + 1) * kl]
-        y = self.shard(x.contiguous())
+        x = x.contiguous()
+        if self.static_output:
+            lead = tuple(x.shape[:-1])
+            key = (lead, x.dtype, x.device)
+            y = self._bufs.get(key)
+            if y is None:
+                y = self._bufs[key] = torch.empty(lead + (self.shard.outfeatures,), dtype=x.dtype, device=x.device)
+            self.shard.forward_into(x, y.view(-1, self.shard.outfeatures))
+        else:
+            y = self.shard(x)
         if world > 1:
-            dist.all_reduce(y, op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_reduce(y, op=dist.ReduceOp.SUM, group=self.group)  # partial products over K: ONE collective, in place
         return y
 
 

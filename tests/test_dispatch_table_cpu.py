@@ -131,6 +131,7 @@ def test_native_layout_decode_routes(lib):
     assert plan(lib, [attn] * 3, 16) == "strip nw=8 cpl=4 spw=16 form=register-A row_tiles=1" + sm
     assert plan(lib, [up] * 2, 8) == "strip nw=8 cpl=4 spw=16 form=register-A row_tiles=1" + sm
     assert plan(lib, [W(4096, 11008, 64, 4, NATIVE_F16Z)] * 2, 16) == "strip nw=8 cpl=4 spw=16 form=register-A row_tiles=1" + sm
+    assert plan(lib, [W(4096, 4096, 64, 3, NATIVE_F16Z)] * 3, 16) == "strip nw=8 cpl=2 spw=16 form=register-A row_tiles=1" + sm  # 3 bits: two strips
     assert plan(lib, [attn], 32) == "strip nw=8 cpl=1 spw=16 form=register-A row_tiles=2" + sm
     assert plan(lib, [up] * 2, 64) == "strip nw=8 cpl=1 spw=16 form=register-A row_tiles=4" + sm
     # shard shapes of Llama-2-70B (TP = 8): short K -> 4-wave blocks, K = 8192 -> 8 waves x one round of 32

@@ -114,6 +114,30 @@ def test_native_grouped_launch_and_autogptq_offset():
                 assert O.rel_err(o.cpu().numpy(), Ref(dict(d, compat=compat)).y16(x)) <= 1e-2, (compat, m)
 
 
+@pytest.mark.parametrize("layout,bits,g", [("HQQ", 4, 64), ("HQQ", 3, 64), ("GPTQ", 3, 128), ("GEMM", 4, 128)])
+def test_native_multi_strip_blocks_at_batch_16(layout, bits, g):
+    """M = 5..16 on wide grouped launches: register-A blocks of four (3 bits: two) adjacent strips sharing the activation fragments
+    (BASELINE configs[3]: HQQ g64, mixed 3 / 4 bits, batch 16)."""
+    from qllm_amd import ops
+    ds = [synth(layout, bits, g, 4096, n, seed=90 + i, bias=(i == 0)) for i, n in enumerate((4096, 4096, 4096))]
+    layers = [to_layer(d, DEV) for d in ds]
+    ws = [l.native_descriptor(0) for l in layers]
+    want = "cpl=2" if bits == 3 else "cpl=4"
+    for m in (5, 16):
+        assert want in ops.plan_describe(ws, m) and "register-A" in ops.plan_describe(ws, m), ops.plan_describe(ws, m)
+        x = randx(m, 4096, seed=m)
+        outs = ops.linear_forward_grouped(ws, torch.from_numpy(x).to(DEV))
+        for o, d in zip(outs, ds):
+            ref = Ref(d)
+            assert O.rel_err(o.cpu().numpy(), ref.y16(x)) <= 1e-2, (layout, bits, m)
+            assert O.rel_err(o.cpu().numpy().astype(np.float64), ref.y64(x)) <= 2e-3, (layout, bits, m)
+    if not (bits == 3 and g == 64):
+        xb = torch.from_numpy(randx(16, 4096, seed=7)).to(DEV).to(torch.bfloat16)
+        outs = ops.linear_forward_grouped(ws, xb)
+        for o, d in zip(outs, ds):
+            assert O.rel_err(o.float().cpu().numpy(), Ref(d).y64(xb.float().cpu().numpy().astype(np.float16))) <= 2e-2
+
+
 def test_native_layout_is_what_the_modules_decode_from():
     """The module path: decode-sized forwards stream the native copy (plan text), prefill-sized ones the reference buffers; the
     state dict is untouched and QLLM_NATIVE_LAYOUT=0 keeps everything in place."""

@@ -150,12 +150,18 @@ def shard_shapes_leg(dev, n_layers=16):
 
 
 def run(args, world, rank, dev, info):
-    """bench.py --tp N: N ranks (or 1 rank running the TP=8 shard shapes without a collective)."""
+    """bench.py --tp N: N ranks (or 1 rank running the TP=8 shard shapes without a collective).  `args.tp_layers` (default: all
+    80) shortens the stack for smoke runs (tests/test_tp_collective_gpu.py drives this function with two gloo ranks on one GPU,
+    so that the first 8-GPU lease is not its first execution)."""
     import torch.distributed as dist
     P = world if world > 1 else 8
     if world > 1 and args.tp != world:
         raise SystemExit(f"--tp {args.tp} needs --gpus {args.tp} (one rank per GPU)")
-    blocks = build_stack(P, L70, dev, seed=4321 + rank)  # every rank: its own shard of every layer
+    n_layers = int(getattr(args, "tp_layers", 0) or L70)
+    backend = dist.get_backend() if world > 1 else None
+    if rank == 0:
+        print(f"[tp_bench] world_size={dist.get_world_size() if world > 1 else 1} backend={backend} tp_degree={P} layers={n_layers}", flush=True)
+    blocks = build_stack(P, n_layers, dev, seed=4321 + rank)  # every rank: its own shard of every layer
     M = 1
     h0 = torch.randn(M, H70, device=dev, dtype=torch.float16)
     if world > 1:
@@ -167,15 +173,24 @@ def run(args, world, rank, dev, info):
             h = b(h)
         return h
 
-    graph = None
-    try:  # RCCL collectives are graph-capturable on the compute stream; fall back to eager launches if this build refuses
-        graph, out = _capture(step)
-        run_step = graph.replay
-    except Exception as e:  # noqa: BLE001
-        torch.cuda.synchronize()
+    # Graph path: one rank (no collective) or RCCL ("nccl": its collectives are stream operations and capture with the kernels).
+    # Any other backend (gloo: host-side collectives) runs eagerly BY DESIGN; a failed RCCL capture is reported, not hidden.
+    want_graph = world == 1 or (backend == "nccl" and os.environ.get("QLLM_TP_GRAPH", "1") != "0")
+    graph_mode = "eager (backend %s: collectives are not stream operations)" % backend if not want_graph else None
+    run_step = step
+    out = None
+    if want_graph:
+        try:
+            graph, out = _capture(step)
+            run_step = graph.replay
+            graph_mode = "hipGraph replay"
+        except Exception as e:  # noqa: BLE001
+            torch.cuda.synchronize()
+            graph_mode = f"eager (capture FAILED: {type(e).__name__}: {e})"
+    if out is None:
         out = step()
-        run_step = step
-        graph = f"eager ({type(e).__name__})"
+    if rank == 0:
+        print(f"[tp_bench] step runs as: {graph_mode}", flush=True)
     assert torch.isfinite(out.float()).all()
 
     def barrier():
@@ -204,20 +219,20 @@ def run(args, world, rank, dev, info):
             dist.all_reduce(buf)
         torch.cuda.synchronize()
         ar_us = _time(lambda: dist.all_reduce(buf), 200) * 1e3
-    nbytes = shard_bytes_per_token(P, L70, M)
+    nbytes = shard_bytes_per_token(P, n_layers, M)
     if rank == 0:
         print(json.dumps({
             "metric": "decode_tokens_per_s_llama2_70b_w4a16_g128_linear_stack_tp", "value": round(M * args.steps / wall, 2),
             "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": "llama2-70b-awq-w4-g128-decode-b1-tp", "tp_degree": P, "ranks": world,
-                       "layers": L70, "launches_per_layer": 4, "all_reduces_per_layer": 2 if world > 1 else 0,
-                       "graph": graph if isinstance(graph, str) else True, "parallelism": f"tp{P}" + ("" if world > 1 else " (1 rank, no collective)"),
+            "config": {"workload": "llama2-70b-awq-w4-g128-decode-b1-tp", "tp_degree": P, "ranks": world, "backend": backend,
+                       "layers": n_layers, "launches_per_layer": 4, "all_reduces_per_layer": 2 if world > 1 else 0,
+                       "graph": graph_mode, "parallelism": f"tp{P}" + ("" if world > 1 else " (1 rank, no collective)"),
                        "device": info["arch"]},
             "roofline": {"bound": "hbm", "kernel": "qllm::strip_kernel", "achieved": round(nbytes / ms_per_step / 1e6, 1),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s (per rank)", "frac": round(nbytes / ms_per_step / 1e6 / HBM_PEAK_GBPS, 4),
                          "traffic": None},
             "all_reduce_us_16KB": None if ar_us is None else round(ar_us, 2),
             "cpu_baseline": None}), flush=True)
-    if world > 1:
+    if world > 1 and not getattr(args, "keep_process_group", False):
         dist.destroy_process_group()
