@@ -30,7 +30,7 @@ static int env_int(const char *name, int dflt) {
 }
 // CUs of the current device (launch heuristics only); 256 (MI355X) when no device is reachable, so that the pure-host
 // planners (qllm_plan_describe, qllm_workspace_bytes) stay deterministic without a GPU.  QLLM_NUM_CU overrides.
-static int compute_units() {
+int compute_units() {
   static int v = [] {
     int e = env_int("QLLM_NUM_CU", 0);
     if (e > 0) return e;
@@ -134,7 +134,9 @@ static bool strip_plan(const qllm_weight_t *w, int n, int M, StripPlan *plan) {
   {
     int cols_all = 0;
     for (int i = 0; i < n; ++i) cols_all += w[i].N;
-    const int lim = max_m ? max_m : (sm ? (w[0].bits == 3 ? 32 : 64) : ((w[0].K <= 4096 && cols_all <= 4096) ? 64 : 32));
+    // (native layout, round 3, profiles/r03_mid_m.md: four row tiles 17-21 us vs gemm2 27-28 on 4096 x 4096; 46-59 and 43-54 vs
+    //  40 on the 11008-wide shapes: the same line as for the reference layouts)
+    const int lim = max_m ? max_m : ((w[0].K <= 4096 && cols_all <= 4096 && !(sm && w[0].bits == 3)) ? 64 : 32);
     if (M > lim) return false;
   }
   if (M > 64 || strip_min_strips() <= 0) return false;
@@ -480,14 +482,17 @@ int qllm_device_info(int device, qllm_device_info_t *out) {
 
 size_t qllm_workspace_bytes(const qllm_weight_t *w, int32_t M) {
   if (!w || M <= 0) return kCounterBytes;
-  if (M > 64) {  // prefill: fp32 partial tiles of the split-K GEMM (mid-size M only) + the fp16 copy of bf16 activations where
-    GemmParams p;  // the wave-specialised kernel would serve the call (the caller's activation dtype is not known here)
-    fill_gemm_params(p, w, nullptr, nullptr, M, QLLM_F16);
+  size_t tiles = 0;
+  if (M > 32) {  // the 256-row-tile GEMMs (every M > 64, and 33..64 rows of the shapes the strips leave alone): fp32 partial
+    GemmParams p;  // tiles of the split-K forms + the fp16 copy of bf16 activations where the wave-specialised kernel would
+    fill_gemm_params(p, w, nullptr, nullptr, M, QLLM_F16);  // serve the call (the caller's activation dtype is not known here)
     p.g_idx = nullptr;
     const bool g3 = gemm3_ok(p, w->bits == 3 ? kGemm3Rows3Bit : (w->layout == QLLM_LAYOUT_AWQ_GEMM ? QLLM_LAYOUT_AWQ_GEMM : QLLM_LAYOUT_GPTQ));
-    return kCounterBytes + align_up(gemm2_slab_bytes(M, w->N, gemm2_split_k(M, w->N, w->K)), 256) + (g3 ? bf16_copy_bytes(M, w->K, 1) : 0);
+    tiles = align_up(gemm2_slab_bytes(M, w->N, gemm2_split_k(M, w->N, w->K)), 256) + (g3 ? bf16_copy_bytes(M, w->K, 1) : 0);
+    if (M > 64) return kCounterBytes + tiles;
   }
-  return kCounterBytes + align_up((size_t)skinny_max_split(M) * M * w->N * sizeof(float), 256);
+  const size_t slabs = align_up((size_t)skinny_max_split(M) * M * w->N * sizeof(float), 256);
+  return kCounterBytes + (tiles > slabs ? tiles : slabs);
 }
 
 int qllm_workspace_init(void *workspace, size_t bytes, void *stream) {
@@ -554,6 +559,11 @@ int qllm_linear_forward(const qllm_weight_t *w, const void *x, void *y, int32_t 
   if (skinny_ok(*w, M)) {
     void *ys[1] = {y};
     if (strip_ok(w, 1, M)) return run_strip(w, ys, 1, x, M, act_dtype, (hipStream_t)stream);
+    if (M > 32 && gemm_ok(*w)) {  // 33..64 rows the strips leave alone (wide shapes): the 256-row-tile GEMM beats split-K here
+      GemmParams p;
+      fill_gemm_params(p, w, x, y, M, act_dtype);
+      if (gemm2_ok(p, w->layout)) return run_tile_gemm(p, w->layout, workspace, workspace_bytes, (hipStream_t)stream);
+    }
     return run_skinny(w, ys, 1, x, M, act_dtype, workspace, workspace_bytes, (hipStream_t)stream);
   }
   if (w->bits == 3 && M > 64 && w->layout != QLLM_LAYOUT_AWQ_GEMM && !w->g_idx && (uintptr_t)w->qweight % 16 == 0 &&
@@ -658,6 +668,15 @@ int qllm_plan_describe(const qllm_weight_t *w, int32_t n_weights, int32_t M, int
       }
     }
     return QLLM_OK;
+  }
+  if (n_weights == 1 && decode_ok && w[0].bits == 4 && skinny_ok(w[0], M) && M > 32 && gemm_ok(w[0])) {
+    GemmParams p;
+    fill_gemm_params(p, &w[0], nullptr, nullptr, M, QLLM_F16);
+    if (gemm2_ok(p, w[0].layout)) {
+      const int S = have_workspace ? gemm2_split_k(M, w[0].N, w[0].K) : 1;
+      snprintf(buf, buflen, "gemm2 tile=256x%d split_k=%d", gemm2_tile_n(M, w[0].N, S), S);
+      return QLLM_OK;
+    }
   }
   if (decode_ok && w[0].bits == 4 && skinny_ok(w[0], M)) {
     const int awq_w = skinny_awq_w(M), tn = skinny_tile_cols(w[0].layout, awq_w);

@@ -18,7 +18,10 @@ typedef uint32_t uint4_t __attribute__((ext_vector_type(4)));
 typedef uint32_t uint2_t __attribute__((ext_vector_type(2)));
 
 constexpr int kWave = 64;
-constexpr int kNumCU = 256;  // MI355X; used only for launch heuristics (workspace sizing must be host-pure)
+constexpr int kNumCU = 256;  // MI355X: the fallback of compute_units() when no device is reachable (pure-host planning)
+// CUs of the current device, for launch heuristics only (capi.hip): hipDeviceAttributeMultiprocessorCount, cached; QLLM_NUM_CU
+// overrides; kNumCU without a device, so that qllm_plan_describe / qllm_workspace_bytes stay deterministic in CPU-only tests.
+int compute_units();
 
 // zero-point representation, decided on the host from (layout, qzeros)
 enum ZeroKind : int { ZK_PACKED = 0, ZK_F16 = 1, ZK_SYM = 2 };

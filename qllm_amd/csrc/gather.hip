@@ -66,7 +66,7 @@ template <int CHUNKS>
 int launch_b(const void *x, const int32_t *perm, void *out, int M, int K, int parts, hipStream_t stream) {
   // rows per block: enough blocks to cover the chip several times, at least 2 rows each so the double buffer has something to hide
   int rows = 1;
-  while (rows < 16 && (M + 2 * rows - 1) / (2 * rows) >= 4 * kNumCU) rows *= 2;
+  while (rows < 16 && (M + 2 * rows - 1) / (2 * rows) >= 4 * compute_units()) rows *= 2;
   if (rows == 1 && M >= 2) rows = 2;
   const int grid = (M + rows - 1) / rows;
   if ((size_t)K * 4 > 64 * 1024) {  // above the default dynamic-LDS limit: opt in once per device
@@ -86,7 +86,7 @@ int launch_gather_columns(const void *x, const int32_t *perm, void *out, int M, 
   const int groups = ((K >> 3) + kGatherThreads - 1) / kGatherThreads;  // 256-thread passes over a row's chunks
   // decode-sized M: split the columns over up to `groups` blocks per row pair, so that a single row is not one block's job
   int parts = 1;
-  while (parts < groups && ((M + 1) / 2) * parts < kNumCU / 4) parts *= 2;
+  while (parts < groups && ((M + 1) / 2) * parts < compute_units() / 4) parts *= 2;
   parts = min(parts, groups);
   const int chunks = (groups + parts - 1) / parts;
   if (chunks <= 1) return launch_b<1>(x, perm, out, M, K, parts, stream);

@@ -404,7 +404,9 @@ bool gemm2_ok(const GemmParams &p, int layout) {
   // below 192 rows a 256-row tile wastes > 25 % of its MFMAs -- but with split-K the k-loop length, not the MFMA count, sets
   // the time at these sizes.  Measured (us per linear, 128x128 kernel -> this one; profiles/r02_mid_m.md): M = 96..160 on
   // 4096x4096 100 -> 27.5, 4096x11008 103 -> 40, 11008x4096 258 -> 41.
-  static const int min_m = getenv("QLLM_GEMM2_MIN_M") ? atoi(getenv("QLLM_GEMM2_MIN_M")) : 65;
+  // 33..64 rows (round 3, profiles/r03_mid_m.md): on the 11008-wide Llama shapes this kernel (40 us) beats both the four-row-tile
+  // strips (42-59 us) and the split-K decode kernel (48-53 us); the dispatcher sends it only what the strips do not take
+  static const int min_m = getenv("QLLM_GEMM2_MIN_M") ? atoi(getenv("QLLM_GEMM2_MIN_M")) : 33;
   if (p.g_idx || p.K % 64 != 0 || p.N % 128 != 0 || p.M < min_m) return false;
   return p.group_size % 32 == 0 && p.gs_shift >= 0;  // one group per thread per k-tile; power-of-two group size
 }
@@ -435,7 +437,7 @@ int gemm2_split_k(int M, int N, int K) {
   if (N % 128 != 0) return 1;
   const int tiles = ((M + 255) / 256) * (N / 128), kt = K / 64;
   int s = 1;
-  while (s < 8 && tiles * (s * 2) <= kNumCU && kt / (s * 2) >= 8) s *= 2;
+  while (s < 8 && tiles * (s * 2) <= compute_units() && kt / (s * 2) >= 8) s *= 2;
   return s;
 }
 size_t gemm2_slab_bytes(int M, int N, int S) { return S > 1 ? (size_t)((M + 255) / 256) * (N / 128) * S * 256 * 128 * sizeof(float) : 0; }
@@ -445,8 +447,8 @@ int gemm2_tile_n(int M, int N, int split_k) {
   static int force_bn = getenv("QLLM_GEMM2_BN") ? atoi(getenv("QLLM_GEMM2_BN")) : 0;
   if (split_k > 1) return 128;  // the slab layout is the 256x128 tile's
   const int tiles256 = ((M + 255) / 256) * (N / 256);
-  const int rounds = (tiles256 + kNumCU - 1) / kNumCU;
-  const bool good256 = (N % 256 == 0) && tiles256 >= 0.85 * rounds * kNumCU;
+  const int rounds = (tiles256 + compute_units() - 1) / compute_units();
+  const bool good256 = (N % 256 == 0) && tiles256 >= 0.85 * rounds * compute_units();
   return force_bn ? force_bn : (good256 ? 256 : 128);
 }
 

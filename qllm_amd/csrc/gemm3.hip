@@ -407,8 +407,11 @@ bool gemm3_ok(const GemmParams &p, int layout) {
   static const int on = getenv("QLLM_GEMM3") ? atoi(getenv("QLLM_GEMM3")) : 1;
   // 4 bits: from M = 1024 (below it gemm2's split-K form was the measured choice; QLLM_GEMM3_MIN_M moves the line);
   // 3 bits: every prefill size -- the alternative there is the dequant kernel + a dense GEMM
-  static const int min_m = getenv("QLLM_GEMM3_MIN_M") ? atoi(getenv("QLLM_GEMM3_MIN_M")) : 1024;
-  static const int min_m3 = getenv("QLLM_GEMM3_MIN_M_3BIT") ? atoi(getenv("QLLM_GEMM3_MIN_M_3BIT")) : 65;
+  // round 3 (profiles/r03_mid_m.md, tools/lab/gbench): with split-K this kernel passes gemm2 from M = 384 on the 11008-wide shapes
+  // (59 vs 64 us at M = 384 / 512, 110 vs 130 and 89 vs 93 at 768) and from 768 on 4096 x 4096 (41 vs 43; 34.5 vs 33 below)
+  static const int min_m_env = getenv("QLLM_GEMM3_MIN_M") ? atoi(getenv("QLLM_GEMM3_MIN_M")) : 0;
+  const int min_m = min_m_env ? min_m_env : (((size_t)p.K * p.N > (size_t)4096 * 4096) ? 384 : 768);
+  static const int min_m3 = getenv("QLLM_GEMM3_MIN_M_3BIT") ? atoi(getenv("QLLM_GEMM3_MIN_M_3BIT")) : 33;  // (33..64: native-layout layers whose strips stop at two row tiles)
   if (!on || p.g_idx || p.K % 64 != 0 || p.N % 128 != 0) return false;
   if (p.M < (layout == kGemm3Rows3Bit ? min_m3 : min_m)) return false;
   // fp16 activations only: the activation tile goes to LDS by DMA, which cannot convert bf16 on the way (callers convert x with

@@ -64,7 +64,9 @@ def test_workspace_bytes_is_pure(lib):
     assert lib.qllm_workspace_bytes(ctypes.byref(w), 256) == 16384 + 32 * 8 * tile
     assert lib.qllm_workspace_bytes(ctypes.byref(w), 1024) == 16384 + 128 * 2 * tile + 1024 * 4096 * 2
     wide = _lib.QllmWeight(16, 16, 16, None, None, 4096, 11008, 128, 4, 0, 0)
-    assert lib.qllm_workspace_bytes(ctypes.byref(wide), 512) == 16384      # 172 tiles: a split would need two rounds of blocks
+    # 172 tiles: a split would need two rounds of blocks; from M = 384 the wave-specialised kernel serves this shape (bf16 copy of x)
+    assert lib.qllm_workspace_bytes(ctypes.byref(wide), 512) == 16384 + 512 * 4096 * 2
+    assert lib.qllm_workspace_bytes(ctypes.byref(wide), 320) == 16384
     short = _lib.QllmWeight(16, 16, 16, None, None, 512, 4096, 128, 4, 0, 0)
     assert lib.qllm_workspace_bytes(ctypes.byref(short), 512) == 16384     # 8 k-tiles: too short to split
     ragged = _lib.QllmWeight(16, 16, 16, None, None, 4096, 4000, 128, 4, 0, 0)

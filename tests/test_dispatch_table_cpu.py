@@ -46,9 +46,10 @@ def test_llama7b_decode_routes(lib):
         assert plan(lib, [attn] * 3, m).endswith("row_tiles=2")
     for m in (33, 64):
         assert plan(lib, [attn], m) == "strip nw=8 cpl=1 spw=16 form=register-A row_tiles=4"   # measured 1.5x over split-K
-        assert plan(lib, [up], m).startswith("skinny tile_cols=64")                           # ... which loses on the wide shapes
-        assert plan(lib, [down], m).startswith("skinny tile_cols=64")
-        assert plan(lib, [attn] * 3, m).startswith("skinny tile_cols=64")
+        assert plan(lib, [up], m) == "gemm2 tile=256x128 split_k=2"       # the wide shapes: the 256-row-tile GEMM (round 3:
+        assert plan(lib, [down], m) == "gemm2 tile=256x128 split_k=8"     #   40 us against 48-53 split-K and 42-59 strips)
+        assert plan(lib, [attn] * 3, m).startswith("skinny tile_cols=64")  # grouped launches have no GEMM form
+        assert plan(lib, [W(4096, 11000)], m).startswith("skinny")          # N % 128 != 0: split-K decode kernel
 
 
 def test_llama7b_prefill_routes(lib):
@@ -60,16 +61,19 @@ def test_llama7b_prefill_routes(lib):
     assert plan(lib, [W(4096 + 64, 4096, 64)], 2048) == g3                  # an odd number of k-tiles is fine (tail barrier)
     assert plan(lib, [attn], 512) == "gemm2 tile=256x128 split_k=4"       # 64 tiles -> 4 blocks per tile
     assert plan(lib, [attn], 256) == "gemm2 tile=256x128 split_k=8"
-    assert plan(lib, [down], 1024) == g3 + " split_k=2"                    # from M = 1024 the wave-specialised kernel also splits K
+    assert plan(lib, [down], 1024) == g3 + " split_k=2"                    # the wave-specialised kernel also splits K
     assert plan(lib, [attn], 1024) == g3 + " split_k=2"                    # (measured 47.7 vs 52.2 us, 100.6 vs 110.2 us for `down`)
-    assert plan(lib, [down], 512) == "gemm2 tile=256x128 split_k=4"        # below that gemm2 (measured, profiles/r02_mid_m.md)
-    assert plan(lib, [up], 512) == "gemm2 tile=256x128 split_k=1"         # 172 tiles: a split would need two rounds
+    # round 3 (profiles/r03_mid_m.md): the wave-specialised kernel from M = 384 on the 11008-wide shapes, from 768 on 4096 x 4096
+    assert plan(lib, [down], 512) == g3 + " split_k=4" and plan(lib, [down], 384) == g3 + " split_k=4"
+    assert plan(lib, [up], 512) == g3 and plan(lib, [up], 383).startswith("gemm2")
+    assert plan(lib, [attn], 768) == g3 + " split_k=2" and plan(lib, [attn], 767).startswith("gemm2")
     assert plan(lib, [attn], 512, have_ws=0) == "gemm2 tile=256x128 split_k=1"  # no workspace: no split, still fused
     assert plan(lib, [attn], 128) == "gemm2 tile=256x128 split_k=8"       # 64 < M < 192: k-loop-bound, split-K (2.5-6x the 128x128 kernel)
     assert plan(lib, [attn], 65) == "gemm2 tile=256x128 split_k=8"
     assert plan(lib, [W(4096, 4000)], 2048) == "gemm tile=128x128"        # ragged N
     assert plan(lib, [W(4096, 4096, layout=AWQ)], 2048) == g3               # AWQ layout read in place
     assert plan(lib, [W(4096, 4096, layout=AWQ)], 512) == "gemm2 tile=256x128 split_k=4"
+    assert plan(lib, [W(4096, 11008, layout=AWQ)], 48) == "gemm2 tile=256x128 split_k=2"   # 33..64 rows, AWQ in place
 
 
 def test_other_layouts_and_widths(lib):
@@ -133,7 +137,9 @@ def test_native_layout_decode_routes(lib):
     assert plan(lib, [W(4096, 11008, 64, 4, NATIVE_F16Z)] * 2, 16) == "strip nw=8 cpl=4 spw=16 form=register-A row_tiles=1" + sm
     assert plan(lib, [W(4096, 4096, 64, 3, NATIVE_F16Z)] * 3, 16) == "strip nw=8 cpl=2 spw=16 form=register-A row_tiles=1" + sm  # 3 bits: two strips
     assert plan(lib, [attn], 32) == "strip nw=8 cpl=1 spw=16 form=register-A row_tiles=2" + sm
-    assert plan(lib, [up] * 2, 64) == "strip nw=8 cpl=1 spw=16 form=register-A row_tiles=4" + sm
+    assert plan(lib, [attn], 64) == "strip nw=8 cpl=1 spw=16 form=register-A row_tiles=4" + sm
+    assert plan(lib, [up], 64) == "gemm2 tile=256x128 split_k=2" + sm      # 33..64 rows on the wide shapes: the tile GEMM
+    assert plan(lib, [down], 33) == "gemm2 tile=256x128 split_k=8" + sm
     # shard shapes of Llama-2-70B (TP = 8): short K -> 4-wave blocks, K = 8192 -> 8 waves x one round of 32
     assert plan(lib, [W(1024, 8192, layout=NATIVE)], 1).startswith("strip nw=4 cpl=1 spw=8 form=lds-slab")
     assert plan(lib, [W(8192, 1024, layout=NATIVE)], 1).startswith("strip nw=8 cpl=1 spw=32 form=lds-slab")
@@ -147,7 +153,7 @@ def test_native_layout_decode_routes(lib):
     assert plan(lib, [h3], 1).startswith("strip nw=16 cpl=1 spw=8 form=lds-slab")
     assert plan(lib, [h3], 16).startswith("strip nw=16 cpl=1 spw=8 form=register-A")
     assert plan(lib, [h3], 32).endswith("row_tiles=2" + sm)
-    assert plan(lib, [h3], 48).startswith("unsupported")                     # four 3-bit row tiles would need > 256 registers
+    assert plan(lib, [h3], 48).startswith("gemm3") and "bits=3" in plan(lib, [h3], 48)   # (four 3-bit row tiles would need > 256 registers)
     assert plan(lib, [W(4096, 4096, 32, layout=NATIVE)], 1).startswith("unsupported")   # group sizes the strips do not serve
     assert plan(lib, [W(128, 4096, layout=NATIVE)], 1).startswith("unsupported")        # K shorter than one round of 8 k-steps
 

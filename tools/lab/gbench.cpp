@@ -1,0 +1,122 @@
+// Per-shape, per-M timing of qllm_linear_forward through the C ABI without Python / torch (developer tool): the three Llama-2-7B
+// linears, native strip-major layout (and, with --layout gptq, the reference row stream in place), M from the decode / prefill
+// boundary (33) to 2048, hipGraph replay over rotating weight sets (HBM-resident).  The env knobs of the dispatcher are latched at
+// first use, so variants are separate invocations:
+//     tools/lab/gbench                                     default dispatch
+//     QLLM_GEMM3_MIN_M=65 tools/lab/gbench                 the wave-specialised kernel for every M > 64
+//     QLLM_STRIP_MAX_M=32 QLLM_GEMM2_MIN_M=33 tools/lab/gbench --m 33 48 64      gemm2 instead of the 4-row-tile strips
+// Build: hipcc --offload-arch=gfx950 -O3 -I include -o tools/lab/gbench tools/lab/gbench.cpp -L qllm_amd -lqllm_mi355x -Wl,-rpath,'$ORIGIN/../../qllm_amd'
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "qllm_mi355x.h"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+#define QK(x) do { int r_ = (x); if (r_ != 0) { printf("qllm error %d (%s) at %s:%d\n", r_, qllm_last_error(), __FILE__, __LINE__); exit(1); } } while (0)
+
+__device__ __host__ inline uint32_t hash32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+__global__ void fill_words(uint32_t *p, size_t n, uint32_t seed) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = hash32((uint32_t)i * 2654435761u + seed);
+}
+__global__ void fill_scales(_Float16 *p, size_t n, uint32_t seed, float base) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = (_Float16)(((hash32((uint32_t)i + seed) & 0xffff) / 65536.f * 0.4f + 0.8f) * base);
+}
+__global__ void fill_x(_Float16 *p, size_t n, uint32_t seed) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    float s = 0;
+    for (int j = 0; j < 4; ++j) s += (hash32((uint32_t)i * 4 + j + seed) & 0xffff) / 65536.f - 0.5f;
+    p[i] = (_Float16)(s * 1.732f);
+  }
+}
+
+static qllm_weight_t make_layer(int K, int N, int group, uint32_t seed, bool native) {
+  const size_t qw = (size_t)K / 8 * N, G = K / group;
+  uint32_t *w, *z;
+  _Float16 *s;
+  CK(hipMalloc(&w, qw * 4)); CK(hipMalloc(&z, G * (N / 8) * 4)); CK(hipMalloc(&s, G * N * 2));
+  fill_words<<<(qw + 255) / 256, 256>>>(w, qw, seed);
+  fill_words<<<(G * (N / 8) + 255) / 256, 256>>>(z, G * (N / 8), seed ^ 0x9e3779b9u);
+  fill_scales<<<(G * N + 255) / 256, 256>>>(s, G * N, seed ^ 0x1234567u, 1.f / (sqrtf((float)K) * 6.5f));
+  qllm_weight_t g{w, s, z, nullptr, nullptr, K, N, group, 4, QLLM_LAYOUT_GPTQ, 0};
+  if (!native) return g;
+  size_t bw, bs, bz;
+  QK(qllm_native_sizes(&g, &bw, &bs, &bz));
+  void *nw, *ns, *nz;
+  CK(hipMalloc(&nw, bw)); CK(hipMalloc(&ns, bs)); CK(hipMalloc(&nz, bz));
+  QK(qllm_repack_native(&g, nw, ns, nz, nullptr));
+  CK(hipDeviceSynchronize());
+  CK(hipFree(w)); CK(hipFree(z)); CK(hipFree(s));
+  return qllm_weight_t{nw, ns, nz, nullptr, nullptr, K, N, group, 4, QLLM_LAYOUT_NATIVE, 0};
+}
+
+int main(int argc, char **argv) {
+  std::vector<int> ms = {33, 48, 64, 65, 96, 128, 192, 256, 384, 512, 768, 1024, 2048};
+  std::string layout = "native";
+  int bf16 = 0;
+  for (int i = 1; i < argc; ++i) {
+    if (!strcmp(argv[i], "--m")) { ms.clear(); while (i + 1 < argc && argv[i + 1][0] != '-') ms.push_back(atoi(argv[++i])); }
+    else if (!strcmp(argv[i], "--layout")) layout = argv[++i];
+    else if (!strcmp(argv[i], "--bf16")) bf16 = 1;
+  }
+  const bool native = layout == "native";
+  struct Shape { const char *name; int K, N; } shapes[] = {{"4096x4096", 4096, 4096}, {"4096x11008", 4096, 11008}, {"11008x4096", 11008, 4096}};
+  const int NSET = 12;  // 12 x 8.4 .. 22.5 MB: beyond the L2s, rotating
+  void *ws;
+  const size_t ws_bytes = 256 << 20;
+  CK(hipMalloc(&ws, ws_bytes));
+  CK(hipMemset(ws, 0, ws_bytes));
+  hipStream_t st;
+  CK(hipStreamCreate(&st));
+  printf("layout=%s act=%s; us per linear (TFLOP/s) [plan]\n", layout.c_str(), bf16 ? "bf16" : "f16");
+  for (auto sh : shapes) {
+    std::vector<qllm_weight_t> sets;
+    for (int i = 0; i < NSET; ++i) sets.push_back(make_layer(sh.K, sh.N, 128, 100 * i + sh.K, native));
+    for (int M : ms) {
+      _Float16 *x, *y;
+      CK(hipMalloc(&x, (size_t)M * sh.K * 2)); CK(hipMalloc(&y, (size_t)M * sh.N * 2));
+      fill_x<<<((size_t)M * sh.K + 255) / 256, 256>>>(x, (size_t)M * sh.K, 7);
+      CK(hipDeviceSynchronize());
+      auto run = [&]() { for (int i = 0; i < NSET; ++i) QK(qllm_linear_forward(&sets[i], x, y, M, bf16 ? QLLM_BF16 : QLLM_F16, ws, ws_bytes, st)); };
+      run();
+      CK(hipStreamSynchronize(st));
+      hipGraph_t g; hipGraphExec_t ge;
+      CK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
+      run();
+      CK(hipStreamEndCapture(st, &g));
+      CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+      for (int i = 0; i < 2; ++i) CK(hipGraphLaunch(ge, st));
+      CK(hipStreamSynchronize(st));
+      hipEvent_t e0, e1;
+      CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+      const int iters = M >= 1024 ? 5 : 20;
+      CK(hipEventRecord(e0, st));
+      for (int i = 0; i < iters; ++i) CK(hipGraphLaunch(ge, st));
+      CK(hipEventRecord(e1, st));
+      CK(hipEventSynchronize(e1));
+      float ms_;
+      CK(hipEventElapsedTime(&ms_, e0, e1));
+      const double us = ms_ * 1e3 / iters / NSET;
+      char plan[160];
+      QK(qllm_plan_describe(&sets[0], 1, M, 1, plan, sizeof plan));
+      printf("  %-11s M=%5d  %8.2f us  %7.1f TFLOP/s  [%s]\n", sh.name, M, us, 2.0 * M * sh.K * sh.N / us / 1e6, plan);
+      fflush(stdout);
+      CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
+      CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
+      CK(hipFree(x)); CK(hipFree(y));
+    }
+    for (auto &w : sets) { CK(hipFree((void *)w.qweight)); CK(hipFree((void *)w.scales)); CK(hipFree((void *)w.qzeros)); }
+  }
+  return 0;
+}
