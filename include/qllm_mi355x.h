@@ -28,11 +28,15 @@
  *                same interleave; scales f16 [K/g, N]; 4-bit only; no g_idx
  *       HQQ      qweight as GPTQ; qzeros f16 [ceil(K/g), N] (un-packed, non-integer); no g_idx
  *   - numerics, by kernel path (qllm_plan_describe() names the path a call takes):
- *       qllm_dequant / qllm_ort_dequant, the prefill GEMMs ("gemm2", "gemm") and the split-K decode kernel ("skinny"):
+ *       qllm_dequant / qllm_ort_dequant, the tile GEMMs ("gemm3": the wave-specialised 256x128 kernel, the default from M = 384 /
+ *       768; "gemm2": 33 / 65 <= M below that and bf16 activations below 1024 rows; "gemm": ragged N, non-uniform act-order) and the
+ *       split-K decode kernel ("skinny"):
  *         W[k,n] = fp16( fp16(s*q) - fp16(z*s) ) exactly as DequantizeLinearBlockWise (quant_linear_gptq.py:38-48) -- one IEEE
  *         rounding per op, bit-identical to the CPU path -- then y = x.W accumulated in fp32, bias added in fp32, one
- *         rounding to the activation dtype.
- *       the full-K decode kernel ("strip", M <= 32 on row-stream layouts -- the default decode path):
+ *         rounding to the activation dtype (bf16 activations on "gemm3": x is converted to fp16 first and the fp16 result is
+ *         rounded to bf16, the arithmetic of the reference's own shim, quant_linear_awq.py:29-36).
+ *       the full-K decode kernel ("strip": M <= 32 everywhere, M <= 64 for K <= 4096 and at most 4096 columns; every layout it
+ *       serves -- the reference row streams in place and the native strip-major layout; the default decode path):
  *         y = sum_G s_G * ( sum_{k in G} x_k q_k  -  z_G * sum_{k in G} x_k ) evaluated in fp32, i.e. x.W for the UNROUNDED
  *         W = s*(q - z); it differs from the path above by the fp16 rounding noise of W (<= 3e-4 relative measured; the
  *         tests bound every decode case at 2e-3 against float64 of the reference's W and at 1e-2 against the CPU path).
@@ -115,7 +119,8 @@ int qllm_workspace_init(void *workspace, size_t bytes, void *stream);
 /* ---- the hot path -------------------------------------------------------------------------------------- */
 /* y[M,N] = x[M,K] . dequant(w) (+ bias).  x, y in `act_dtype`; scales/bias stay f16 (bf16 activations are
  * converted on load, replacing the reference's bf16->f16 shims, ort_ops.cc:119-138, quant_linear_awq.py:29-36).
- * Dispatch: M <= 64 -> weight-streaming MFMA matvec (HBM-bound); larger M -> LDS-tiled MFMA GEMM.
+ * Dispatch: M <= 32 (<= 64 on small shapes) -> weight-streaming MFMA matvec (HBM-bound); larger M -> LDS-tiled MFMA GEMM
+ * (qllm_plan_describe names the kernel; profiles/r03_mid_m.md holds the measurements behind the lines).
  * Fused widths: 4 bits everywhere; 3 bits (GPTQ / HQQ row stream; fp16, symmetric or packed zero points) for M <= 64 and, with
  * K % 64 == 0, N % 128 == 0 and fp16 activations, for every larger M; every other width / shape returns QLLM_ERR_UNSUPPORTED and the
  * caller takes the reference's own two-step branch (qllm_dequant + a dense GEMM, quant_linear_gptq.py:81-85).
