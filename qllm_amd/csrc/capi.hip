@@ -181,7 +181,10 @@ static bool strip_plan(const qllm_weight_t *w, int n, int M, StripPlan *plan) {
     int nw = (M > 16 || cpl > 1) ? 8 : (slab_nw ? slab_nw : 16);
     for (int tries = 0; tries < 2; ++tries) {
       const int spw = strip_spw(w[0].K, w[0].group_size, nw);
-      const int ra = (slab_nw == 0 || (longk && nw == 16)) ? 1 : 0;
+      int ra = (slab_nw == 0 || (longk && nw == 16)) ? 1 : 0;
+      // activations through LDS by DMA (strip_kernel.hpp, XD): whole 64-k pairs, one or two row tiles
+      static int ra_xd = env_int("QLLM_RA_XD", 1);
+      if (ra && ra_xd && w[0].K % 64 == 0 && M <= 32 && strip_lds_bytes(M, spw, nw, cpl, w[0].group_size, 2, 1) <= 156 * 1024) ra = 2;
       if (!ra && w[0].K / 32 < strip_maxs(nw, spw, 1, 0, 1)) return false;  // a round's window must fit into the strip
       if ((ra || strip_x_ok(M, spw, nw, 1, 1)) && strip_lds_bytes(M, spw, nw, cpl, w[0].group_size, ra, 1) <= 156 * 1024) {
         plan->cpl = cpl;
@@ -644,7 +647,7 @@ int qllm_plan_describe(const qllm_weight_t *w, int32_t n_weights, int32_t M, int
   bool decode_ok = true;
   for (int i = 0; i < n_weights; ++i) decode_ok = decode_ok && (w[i].bits == 3 || is_native(w[i]) || skinny_ok(w[i], M));
   if ((n_weights > 1 || w[0].bits == 3 || is_native(w[0]) || skinny_ok(w[0], M)) && decode_ok && strip_plan(w, n_weights, M, &pl)) {
-    snprintf(buf, buflen, "strip nw=%d cpl=%d spw=%d form=%s row_tiles=%d%s", pl.nw, pl.cpl, pl.spw, pl.ra ? "register-A" : "lds-slab",
+    snprintf(buf, buflen, "strip nw=%d cpl=%d spw=%d form=%s row_tiles=%d%s", pl.nw, pl.cpl, pl.spw, pl.ra == 2 ? "dma-A" : (pl.ra ? "register-A" : "lds-slab"),
              M > 32 ? 4 : (M > 16 ? 2 : 1), pl.sm ? " layout=strip-major" : "");
     return QLLM_OK;
   }

@@ -78,7 +78,8 @@ int strip_spw(int K, int group_size, int nw) {
 
 size_t strip_lds_bytes(int M, int spw, int nw, int cpl, int group_size, int ra, int sm) {
   const size_t red = (size_t)nw * M * 16 * cpl * sizeof(float);
-  if (ra) return red;  // register-A: only the cross-wave reduction buffer
+  // register-A: only the cross-wave reduction buffer; ra == 2 (activations by LDS-DMA): + 8 KB per wave and 16-row tile
+  if (ra) return red + (ra == 2 ? (size_t)nw * (M > 32 ? 4 : (M > 16 ? 2 : 1)) * 8192 : 0);
   const int pad = strip_spw_pad(nw, spw, cpl, 0, sm);
   const int groups = pad / (group_size / 32);  // groups per wave chunk
   return red + (size_t)nw * M * (pad * 32 + 8) * sizeof(half_t) +

@@ -5,31 +5,36 @@
 
 namespace qllm {
 
-template <int SPG, bool BF>
+template <int SPG, bool BF, int XV>
 static int launch_sm_ra(const StripParams &p, int grid, size_t lds, hipStream_t stream) {
   if (p.M > 16) {
     if (p.bits == 3) {  // (four 3-bit row tiles need 256+ registers: the planner stops at two)
       if (p.M > 32) return set_error(QLLM_ERR_UNSUPPORTED, "internal: 3-bit strip-major strips serve M <= 32");
-      return launch_strip_t<8, 1, 8, SPG, 1, 3, true, BF, 2, true>(p, grid, lds, stream);
+      return launch_strip_t<8, 1, 8, SPG, XV, 3, true, BF, 2, true>(p, grid, lds, stream);
     }
-    return p.M > 32 ? launch_strip_t<8, 1, 8, SPG, 1, 4, true, BF, 4, true>(p, grid, lds, stream) : launch_strip_t<8, 1, 8, SPG, 1, 4, true, BF, 2, true>(p, grid, lds, stream);
+    // (four row tiles: 32 KB of activations per wave and round do not fit next to the reduction buffer -- fragment loads)
+    return p.M > 32 ? launch_strip_t<8, 1, 8, SPG, 1, 4, true, BF, 4, true>(p, grid, lds, stream) : launch_strip_t<8, 1, 8, SPG, XV, 4, true, BF, 2, true>(p, grid, lds, stream);
   }
-  if (p.bits == 3 && p.cpl == 2) return launch_strip_t<8, 2, 8, SPG, 1, 3, true, BF, 1, true>(p, grid, lds, stream);  // (four 3-bit strips spill)
+  if (p.bits == 3 && p.cpl == 2) return launch_strip_t<8, 2, 8, SPG, XV, 3, true, BF, 1, true>(p, grid, lds, stream);  // (four 3-bit strips spill)
   if (p.bits == 3) {
-    if constexpr (SPG == 2 && BF)  // (this one spills 7 registers: not built; callers stream the reference layout in place)
+    if constexpr (SPG == 2 && BF && XV == 1)  // (this one spills 7 registers: not built; callers stream the reference layout in place)
       return set_error(QLLM_ERR_UNSUPPORTED, "3-bit g64 native-layout layers with bf16 activations: no strip-major kernel");
     else
-      return launch_strip_t<16, 1, 8, SPG, 1, 3, true, BF, 1, true>(p, grid, lds, stream);
+      return launch_strip_t<16, 1, 8, SPG, XV, 3, true, BF, 1, true>(p, grid, lds, stream);
   }
-  if (p.cpl == 4) return launch_strip_t<8, 4, 8, SPG, 1, 4, true, BF, 1, true>(p, grid, lds, stream);  // four strips per 8-wave block
-  return p.nw == 8 ? launch_strip_t<8, 1, 8, SPG, 1, 4, true, BF, 1, true>(p, grid, lds, stream)
-                   : launch_strip_t<16, 1, 8, SPG, 1, 4, true, BF, 1, true>(p, grid, lds, stream);
+  if (p.cpl == 4) return launch_strip_t<8, 4, 8, SPG, XV, 4, true, BF, 1, true>(p, grid, lds, stream);  // four strips per 8-wave block
+  return p.nw == 8 ? launch_strip_t<8, 1, 8, SPG, XV, 4, true, BF, 1, true>(p, grid, lds, stream)
+                   : launch_strip_t<16, 1, 8, SPG, XV, 4, true, BF, 1, true>(p, grid, lds, stream);
 }
 
 int launch_strip_sm_ra(const StripParams &p, int grid, hipStream_t stream) {
-  const size_t lds = strip_lds_bytes(p.M, p.spw, p.nw, p.cpl, p.group_size, 1, 1);
-  if (p.group_size == 64) return p.act_bf16 ? launch_sm_ra<2, true>(p, grid, lds, stream) : launch_sm_ra<2, false>(p, grid, lds, stream);
-  return p.act_bf16 ? launch_sm_ra<4, true>(p, grid, lds, stream) : launch_sm_ra<4, false>(p, grid, lds, stream);
+  const size_t lds = strip_lds_bytes(p.M, p.spw, p.nw, p.cpl, p.group_size, p.ra, 1);
+  if (p.ra == 2) {  // activations by LDS-DMA
+    if (p.group_size == 64) return p.act_bf16 ? launch_sm_ra<2, true, 2>(p, grid, lds, stream) : launch_sm_ra<2, false, 2>(p, grid, lds, stream);
+    return p.act_bf16 ? launch_sm_ra<4, true, 2>(p, grid, lds, stream) : launch_sm_ra<4, false, 2>(p, grid, lds, stream);
+  }
+  if (p.group_size == 64) return p.act_bf16 ? launch_sm_ra<2, true, 1>(p, grid, lds, stream) : launch_sm_ra<2, false, 1>(p, grid, lds, stream);
+  return p.act_bf16 ? launch_sm_ra<4, true, 1>(p, grid, lds, stream) : launch_sm_ra<4, false, 1>(p, grid, lds, stream);
 }
 
 }  // namespace qllm
