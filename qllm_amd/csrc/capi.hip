@@ -177,14 +177,46 @@ static bool strip_plan(const qllm_weight_t *w, int n, int M, StripPlan *plan) {
     // (a register-A block re-reads all of x from L2; 64 columns share it instead of 16)
     static int sm_ra_cpl4 = env_int("QLLM_SM_RA_CPL4", 1);
     // (3 bits: two strips -- four need more than 256 registers)
-    const int cpl = (sm_ra_cpl4 && slab_nw == 0 && M >= 5 && M <= 16 && m64 && cols / 64 >= compute_units() / 2) ? (bits == 3 ? 2 : 4) : 1;
+    int cpl = (sm_ra_cpl4 && slab_nw == 0 && M >= 5 && M <= 16 && m64 && cols / 64 >= compute_units() / 2) ? (bits == 3 ? 2 : 4) : 1;
     int nw = (M > 16 || cpl > 1) ? 8 : (slab_nw ? slab_nw : 16);
+    // strip_dma.hpp (M = 5..32, K a multiple of 64): the activations go through LDS by DMA.  A block pulls the activations of its
+    // k range through the CU's memory pipe once, a CU ingests ~55 GB/s here, so the launch costs about (rounds of blocks on the
+    // CUs) x (bytes one block pulls): blocks of cpl strips share one activation stream -- pick the cpl that minimises that product
+    // (profiles/r03_batch16.md).  One strip per block: 16 waves; several: 8 waves (registers).  The last block of a layer may be ragged.
+    static int ra_xd = env_int("QLLM_RA_XD", 1);
+    static int dma_cpl = env_int("QLLM_DMA_CPL", 0);
+    if (ra_xd && slab_nw == 0 && M >= 5 && M <= 32 && w[0].K % 64 == 0) {
+      const int cus = compute_units();
+      static const int cands4[] = {1, 2, 4, 6}, cands3[] = {1, 2, 4};
+      const int *cands = bits == 4 ? cands4 : cands3;
+      const int n_cands = (M > 16) ? 1 : (bits == 4 ? 4 : 3);  // (two row tiles: one strip per block)
+      const double x_bytes = (double)M * w[0].K * 2, strip_bytes = (double)w[0].K * bits * 2 + (double)(w[0].K / w[0].group_size) * 64;
+      int best = 1;
+      double best_cost = 0;
+      for (int ci = 0; ci < n_cands; ++ci) {
+        const int c = cands[ci];
+        int blocks = 0;
+        for (int i = 0; i < n; ++i) blocks += (w[i].N / 16 + c - 1) / c;
+        const double cost = (double)((blocks + cus - 1) / cus) * (x_bytes + c * strip_bytes);
+        if (ci == 0 || cost < best_cost * 0.97 || c == dma_cpl) { best = c; best_cost = (c == dma_cpl) ? 0 : cost; }
+      }
+      cpl = best;
+      nw = (cpl == 1 && M <= 16) ? 16 : 8;
+      const int spw = strip_spw(w[0].K, w[0].group_size, nw);
+      if (strip_lds_bytes(M, spw, nw, cpl, w[0].group_size, 2, 1) <= 156 * 1024) {
+        plan->cpl = cpl;
+        plan->nw = nw;
+        plan->spw = spw;
+        plan->ra = 2;
+        plan->sm = 1;
+        return true;
+      }
+      cpl = 1;  // (does not fit: the register-A form below)
+      nw = (M > 16) ? 8 : 16;
+    }
     for (int tries = 0; tries < 2; ++tries) {
       const int spw = strip_spw(w[0].K, w[0].group_size, nw);
-      int ra = (slab_nw == 0 || (longk && nw == 16)) ? 1 : 0;
-      // activations through LDS by DMA (strip_kernel.hpp, XD): whole 64-k pairs, one or two row tiles
-      static int ra_xd = env_int("QLLM_RA_XD", 1);
-      if (ra && ra_xd && w[0].K % 64 == 0 && M <= 32 && strip_lds_bytes(M, spw, nw, cpl, w[0].group_size, 2, 1) <= 156 * 1024) ra = 2;
+      const int ra = (slab_nw == 0 || (longk && nw == 16)) ? 1 : 0;
       if (!ra && w[0].K / 32 < strip_maxs(nw, spw, 1, 0, 1)) return false;  // a round's window must fit into the strip
       if ((ra || strip_x_ok(M, spw, nw, 1, 1)) && strip_lds_bytes(M, spw, nw, cpl, w[0].group_size, ra, 1) <= 156 * 1024) {
         plan->cpl = cpl;
@@ -264,7 +296,7 @@ static int run_strip(const qllm_weight_t *w, void *const *y, int n, const void *
   p.add_zero_bias = w[0].add_zero_bias;
   p.act_bf16 = (act_dtype == QLLM_BF16);
   // diagnostics: only the lds-slab 4-bit g128 native-layout form has a timeline instantiation
-  p.dbg = (pl.sm && !pl.ra && p.bits == 4 && p.group_size == 128 && g_timeline && g_timeline_next < g_timeline_slots)
+  p.dbg = (pl.sm && (!pl.ra || pl.ra == 2) && p.bits == 4 && p.group_size == 128 && g_timeline && g_timeline_next < g_timeline_slots)
               ? g_timeline + 24 * (g_timeline_next++) : nullptr;
   int block = 0;
   for (int i = 0; i < n; ++i) {
@@ -275,7 +307,7 @@ static int run_strip(const qllm_weight_t *w, void *const *y, int n, const void *
     q.bias = (const half_t *)w[i].bias;
     q.y = y[i];
     q.N = w[i].N;
-    q.n_strips = w[i].N / (16 * pl.cpl);
+    q.n_strips = (w[i].N / 16 + pl.cpl - 1) / pl.cpl;  // (strip_dma.hpp: the last block may be ragged; every other form divides)
     q.block_begin = block;
     p.block_begin8[i] = block;
     q.zero_kind = zero_kind_of(w[i]);

@@ -55,7 +55,7 @@ struct StripProblem {
   const half_t *bias;
   void *y;
   int N;
-  int n_strips;     // ceil(N / (16 * cpl))
+  int n_strips;     // blocks of this problem: ceil(N / (16 * cpl))
   int block_begin;  // first blockIdx.x of this problem
   int zero_kind;
 };

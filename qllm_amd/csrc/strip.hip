@@ -3,6 +3,8 @@
 // strip-major (native layout) instantiations are in strip_sm.hip.
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "strip_kernel.hpp"
 
 namespace qllm {
@@ -78,8 +80,10 @@ int strip_spw(int K, int group_size, int nw) {
 
 size_t strip_lds_bytes(int M, int spw, int nw, int cpl, int group_size, int ra, int sm) {
   const size_t red = (size_t)nw * M * 16 * cpl * sizeof(float);
-  // register-A: only the cross-wave reduction buffer; ra == 2 (activations by LDS-DMA): + 8 KB per wave and 16-row tile
-  if (ra) return red + (ra == 2 ? (size_t)nw * (M > 32 ? 4 : (M > 16 ? 2 : 1)) * 8192 : 0);
+  // register-A: only the cross-wave reduction buffer; ra == 2 (strip_dma.hpp): the waves' activation rings, 8 KB per 16-row tile,
+  // which the reduction buffer re-uses
+  if (ra == 2) return std::max(red, (size_t)nw * (M > 16 ? 2 : 1) * 8192);
+  if (ra) return red;
   const int pad = strip_spw_pad(nw, spw, cpl, 0, sm);
   const int groups = pad / (group_size / 32);  // groups per wave chunk
   return red + (size_t)nw * M * (pad * 32 + 8) * sizeof(half_t) +

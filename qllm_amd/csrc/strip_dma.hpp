@@ -1,0 +1,371 @@
+// Full-K strip kernel for small batches (M = 5..32) on the strip-major native layout: y[M, N] = x . dequant(W), no cross-block
+// reduction.  Same decomposition as strip_kernel.hpp (block = NW waves = CPL adjacent 16-column strips for ALL of K; wave w owns a
+// contiguous chunk of spw k-steps; raw biased fp16 B fragments, one fp32 scale / zero-point step per group; LDS reduction over the
+// waves at the end), rebuilt around how the operands reach the matrix core.  What the timeline stamps (tools/lab/cbench --m 16
+// --timeline, profiles/r03_batch16.md) showed about this regime:
+//
+//   * A CU INGESTS ABOUT 55 GB/s here (activations out of L2 + weights out of HBM, whatever the mix and the instruction), and every
+//     block pulls the activations of its k range once per column block: with one strip per block that is 4x the weight bytes at
+//     M = 16.  The time of a launch is (bytes through the busiest CU) / 55 GB/s plus about 1.5 us of prologue and 2.5 us of tail
+//     (the waves of a block are served in order by the CU's memory pipe; the first ones wait at the reduction barrier).  Hence:
+//     WIDE BLOCKS -- up to six strips share one activation stream -- chosen by the host so that the whole launch is ONE round of
+//     blocks on the CUs (strip_plan: fewest bytes through the busiest CU); the last block of a layer may be ragged.
+//   * ACTIVATIONS THROUGH LDS, IN FULL LINES.  A fragment-shaped load (lane (g, i) -> 16 B of row i) touches 16 rows x 64 B per
+//     instruction: every 16-lane pass of the texture addresser sees 16 different cache lines.  Here a STAGE -- two k-steps, 16 rows
+//     x 64 k = 2 KB per wave and row tile -- arrives as two LDS-DMA pieces of 8 rows x 128 B (a 16-lane pass reads two whole
+//     lines), lands in a wave-private XOR-swizzled [16 rows][128 B] image (the source address carries the swizzle:
+//     cdna_hip_programming.md rule 21) and is read back as A fragments with ds_read_b128.  No registers are held across the load
+//     latency.  (Plain 16-byte loads + ds_write_b128 into the same image measured the same or 2-25 % slower.)
+//   * A ROLLING RING OF FOUR STAGES.  The ring slot of a stage is re-requested (activation pieces, the stage's weight words into
+//     the registers just consumed, the finished group's next scale / zero) as soon as its two k-steps have been issued to the matrix
+//     core: three stages are always in flight behind the one being computed.  Every vector-memory operation of the loop is counted
+//     by hand (raw buffer loads and DMA pieces: nothing hipcc may merge or drop), so each stage waits with an exact
+//     `s_waitcnt vmcnt(total - own)`.  All addressing is per-lane constant + wave-uniform scalar offset: no vector address
+//     arithmetic in the loop.
+//   * THE BIAS LEAVES THROUGH THE MATRIX CORE.  B fragments are raw patterns 1024 + q / 64 + q (below); a second MFMA per strip
+//     against a constant fragment of minus the slot biases brings the group accumulator to sum x q, a third per k-step against ones
+//     gives Sx: the per-group VALU work is 4 packed FMAs + the decode of one scale and one zero point per strip.
+//   * k-steps past the wave's chunk or past K: the DMA source offset is pushed out of the buffer's range, the image holds zeros and
+//     the stage contributes nothing (the weight / scale addresses are clamped into the strip and cost an L2 hit).
+//   Measured dead ends (same file, profiles/r03_batch16.md): K split over adjacent blocks with fp32 partial slabs + arrival ticket
+//   (fewer activation bytes per CU, but the fix-up costs 3-4 us: 4096 -> 4096 at M = 16 5.8 -> 10.6 us); two or four small blocks
+//   per CU (no change: the CU's ingest rate is the bound, not the blocks' start-up).
+//
+// K must be a multiple of 64 and spw even (host: strip_plan).  Replaces gemv<half> (/root/reference/csrc/ort_cuda/dq_gemv.cu:41-150)
+// and, for the HQQ configuration, the dequantise-then-matmul forward of /root/reference/qllm/modeling/q_layers/quant_linear_hqq.py.
+#pragma once
+#include "kernels.hpp"
+
+namespace qllm {
+
+// NW: waves per block; CPL: adjacent 16-column strips per block (lane (g, i) holds column i of each); SPG: k-steps per group
+// (group_size / 32: 2 or 4); BITS: 4 or 3; BF16: bf16 activations (converted after the fragment read); MT: 16-row tiles (M <= 16 MT)
+// (six strips of 64-wide groups: a ring of three stages -- four need more than 256 registers)
+template <int CPL, int SPG, int BITS>
+constexpr int strip_dma_ring() { return (CPL >= 6 && SPG == 2) ? 3 : 4; }
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  // (vmcnt is six bits: a wave keeps at most 63 requests in flight, and a wait for "all but N > 63" is written as 63 -- it waits for a
+  //  few requests more than needed, never fewer)
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N < 63 ? N : 63) : "memory");
+}
+
+template <int NW, int CPL, int SPG, int BITS, bool BF16, int MT>
+__global__ __launch_bounds__(NW * 64, NW / 4) void strip_dma_kernel(const StripParams p) {
+  static_assert(SPG == 2 || SPG == 4, "groups of 64 or 128");
+  constexpr int NS = strip_dma_ring<CPL, SPG, BITS>();  // ring slots (stages of two k-steps)
+  static_assert(NS >= 2 && NS <= 4 && (2 * NS) % SPG == 0, "a round of the ring is whole groups");
+  constexpr int NG = 2 * NS / SPG;         // groups per round of the ring
+  constexpr int TN = 16 * CPL;             // columns per block
+  constexpr int WR = (BITS == 4) ? 4 : 3;  // word-rows per k-step
+  constexpr int WL = (BITS == 4) ? 1 : 2;  // loads per weight fragment
+  typedef __attribute__((address_space(3))) void lds_void_t;
+  // vector-memory operations of one stage request, in issue order: [the scale / zero words of the group that ENDS in this slot,]
+  // the DMA pieces, the weight words.  (SPG = 2: every slot ends a group; SPG = 4: the odd ones.)
+  constexpr int LZ = CPL * (2 + (BITS == 3 ? 1 : 0));
+  constexpr int LX = 2 * MT + 2 * CPL * WL;
+  constexpr int L_EVEN = LX + (SPG == 2 ? LZ : 0), L_ODD = LX + LZ;  // requests of an even / odd slot
+  constexpr int L_ALL = (NS / 2) * (L_EVEN + L_ODD) + (NS % 2) * L_EVEN;
+  extern __shared__ __attribute__((aligned(16))) float red[];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, i = lane & 15;
+  // diagnostics (qllm_debug_timeline): wave 0 of the first, the middle and the last block stamp [entry, ring requested, first stage
+  // landed, rounds done, after the reduction barrier, exit] with the 100 MHz clock
+  uint64_t *dbg_slot = nullptr;
+  if (p.dbg && wave == 0) {
+    if (blockIdx.x == 0) dbg_slot = p.dbg;
+    else if (blockIdx.x == gridDim.x / 2) dbg_slot = p.dbg + 8;
+    else if (blockIdx.x == gridDim.x - 1) dbg_slot = p.dbg + 16;
+    if (dbg_slot && lane == 0) dbg_slot[0] = __builtin_amdgcn_s_memrealtime();
+  }
+  int pi = 0;
+  if (p.n_prob > 1) {
+#pragma unroll
+    for (int q = 1; q < kMaxProblems; ++q)
+      if (q < p.n_prob && (int)blockIdx.x >= p.block_begin8[q]) pi = q;
+  }
+  const StripProblem pr = p.prob[pi];
+  const int b = blockIdx.x - pr.block_begin;
+  const int N = pr.N, M = p.M, T = p.T;
+  const int spw = p.spw;
+  const int t0 = wave * spw;
+  const int tend = min(t0 + spw, T);  // the wave owns k-steps [t0, tend): whole pairs (t0, spw, T are even)
+  const int rounds = (spw + 2 * NS - 1) / (2 * NS);
+  const int Gmax = p.n_groups - 1;
+
+  // ---- addressing (strip-major: strip_kernel.hpp, SM).  Every load is a raw buffer load: per-lane byte offset (a loop constant) +
+  // wave-uniform scalar offset.  The last block of a layer may hold fewer than CPL strips: the missing ones re-read the layer's last
+  // strip and are not stored. --------------------------------------------------------------------------------------------------
+  const int strip_bytes = T * WR * 64;  // one strip of packed words
+  const int gtab = Gmax + 1;
+  const int zk = pr.zero_kind;
+  const int zmul = (zk == ZK_PACKED) ? 2 : 8;  // zero-point words per (strip, group)
+  const auto rs_w = __builtin_amdgcn_make_buffer_rsrc((void *)pr.qweight, 0, (int)min((size_t)(N >> 4) * strip_bytes, (size_t)0x7fffffff), 0x00020000);
+  const auto rs_s = __builtin_amdgcn_make_buffer_rsrc((void *)pr.scales, 0, (N >> 4) * gtab * 32, 0x00020000);
+  const auto rs_z = __builtin_amdgcn_make_buffer_rsrc((zk == ZK_SYM) ? (void *)pr.scales : (void *)pr.qzeros, 0,
+                                                      (zk == ZK_SYM) ? (N >> 4) * gtab * 32 : (N >> 4) * gtab * zmul * 4, 0x00020000);
+  int strip_of[CPL];  // (scalar registers)
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) strip_of[c] = min(b * CPL + c, (N >> 4) - 1);
+  const int z_group = (zk == ZK_SYM) ? 0 : zmul * 4;
+  const int lane_w = (g * 16 + i) * 4;
+  const int lane_w3_lo = ((g == 0 ? 0 : g - 1) * 16 + i) * 4, lane_w3_hi = ((g == 3 ? 2 : g) * 16 + i) * 4;
+  const uint32_t shift3 = (uint32_t)((32 - 8 * g) & 31);
+  const int lane_s = i * 2;
+  // zero points: the word holding this lane's column -- packed 4-bit: nibble i%8 of word i/8; packed 3-bit: bit 3i of the 64-bit
+  // pair (the field may straddle into the second word); fp16: half i%2 of word i/2
+  const int zoff = (zk == ZK_PACKED) ? (BITS == 3 ? (i * 3) >> 5 : (i >> 3)) : ((zk == ZK_F16) ? (i >> 1) : 0);
+  const int lane_z = zoff * 4;
+  const int lane_z2 = (BITS == 3 && zk == ZK_PACKED && zoff == 0) ? 4 : lane_z;
+  // decode, branch-free over the zero kind: field = word >> zsh; fp16 bits = ((field + add_zero_bias) & zmask) | zor; z = float(bits) + zadd
+  //   packed: the integer v through the 1024 + v pattern (0x6400 | v), zadd = -1024; fp16: the half itself; symmetric: 2^(BITS-1)
+  const uint32_t zsh = (zk == ZK_PACKED) ? (uint32_t)((BITS == 3 ? 3 * i : 4 * i) & 31) : (uint32_t)(16 * (i & 1));
+  const uint32_t zmask = (zk == ZK_PACKED) ? (uint32_t)((1 << BITS) - 1) : ((zk == ZK_F16) ? 0xffffu : 0u);
+  const uint32_t zor = (zk == ZK_F16) ? 0u : ((zk == ZK_PACKED) ? 0x6400u : (0x6400u | (1u << (BITS - 1))));
+  const uint32_t zbias = (zk == ZK_PACKED) ? (uint32_t)p.add_zero_bias : 0u;
+  const float zadd = (zk == ZK_F16) ? 0.f : -1024.f;
+
+  // ---- the activation ring: NS slots x MT row tiles x [16 rows][128 B] per wave (the reduction buffer re-uses the space) ----------
+  uint8_t *xd = (uint8_t *)red + (size_t)wave * (NS * MT * 2048);
+  const int x_bytes = (int)min((size_t)M * p.K * 2, (size_t)0x7fffffff);
+  const auto rs_x = __builtin_amdgcn_make_buffer_rsrc((void *)p.x, 0, x_bytes, 0x00020000);
+  // piece h of a row tile: lane l -> row 8h + l/8, physical 16-byte slot l%8 <- logical chunk (l%8) ^ swizzle(row)
+  int xd_voff[MT][2];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int r = 8 * h + (lane >> 3);
+      xd_voff[mt][h] = min(16 * mt + r, M - 1) * p.K * 2 + (((lane & 7) ^ lds_row_swizzle(r)) << 4);
+    }
+  // fragment read of k-step parity e: logical chunk 4e + g of row i
+  int xd_rd[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) xd_rd[e] = i * 128 + (((4 * e + g) ^ lds_row_swizzle(i)) << 4);
+
+  const uint32_t mask_lo = nib_mask_vgpr();  // 0x000f000f
+  const uint32_t mask_hi = mask_lo << 4;
+  const uint32_t m3a = ((mask_lo & 0x7u) << 1) | (mask_lo & 0x00070000u);  // 0x0007000E
+  const uint32_t m3b = m3a << 3, m3c = m3a << 6;
+  const uint32_t m3d = mask_lo & 0x00000007u, m3e = mask_lo & 0x00070000u;
+  // B fragments are raw biased fp16 patterns (no per-weight arithmetic):
+  //   4 bits: nibbles at bits 0-3 / 16-19 under 0x6400 = 1024 + q; nibbles at bits 4-7 / 20-23 under 0x5400 = 64 + q (the mantissa
+  //           bit 4 of an fp16 in [64, 128) weighs exactly 1) -- one shift and four v_and_or per 8 weights, activations unscaled;
+  //           fragment slot order (k0,k4 | k1,k5 | k2,k6 | k3,k7);
+  //   3 bits: strip_kernel.hpp's patterns: 1024 + q scaled by (2,1 | 16,8 | 128,64 | 1,1) on slots (k0,k5 | k1,k6 | k2,k7 | k3,k4),
+  //           the activations staged divided by the same factors.
+  // b_nbias: minus the slot biases; b_sum: what turns the staged activations back into sum x (ones; 3 bits: the slot factors).
+  constexpr uint32_t kMagic64 = 0x54005400u;  // (64.0h, 64.0h)
+  const half8_t b_nbias = (BITS == 4) ? half8_t{(half_t)-1024.f, (half_t)-1024.f, (half_t)-64.f, (half_t)-64.f, (half_t)-1024.f, (half_t)-1024.f, (half_t)-64.f, (half_t)-64.f}
+                                      : half8_t{(half_t)-1024.f, (half_t)-1024.f, (half_t)-1024.f, (half_t)-1024.f, (half_t)-1024.f, (half_t)-1024.f, (half_t)-1024.f, (half_t)-1024.f};
+  const half8_t b_sum = (BITS == 4) ? half8_t{(half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f}
+                                    : half8_t{(half_t)2.f, (half_t)1.f, (half_t)16.f, (half_t)8.f, (half_t)128.f, (half_t)64.f, (half_t)1.f, (half_t)1.f};
+
+  // ---- ring state: registers -----------------------------------------------------------------------------------------------
+  uint32_t w[2 * NS][CPL], w_hi[BITS == 3 ? 2 * NS : 1][CPL];
+  half2_t sc2[NG][(CPL + 1) / 2];  // scales, two strips per register
+  uint32_t zr[NG][CPL], zr2[BITS == 3 ? NG : 1][CPL];
+  float4_t yacc[MT][CPL];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) yacc[mt][c] = float4_t{0.f, 0.f, 0.f, 0.f};
+
+  // request slot u for the round starting at k-step `base`
+  auto request = [&](const int base, const int u) __attribute__((always_inline)) {
+    const int kp = base + 2 * u;
+    const bool live = kp < tend;      // wave-uniform
+    const int kc = min(kp, T - 2);    // addresses stay inside the strip
+    if ((2 * u + 1) % SPG == SPG - 1) {
+      const int j = (2 * u + 1) / SPG;
+      const int G = min(kc / SPG, Gmax);
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        const int sg = strip_of[c] * gtab + G;
+        sc2[j][c / 2][c & 1] = __builtin_bit_cast(half_t, __builtin_amdgcn_raw_buffer_load_b16(rs_s, lane_s, sg * 32, 2));
+        zr[j][c] = __builtin_amdgcn_raw_buffer_load_b32(rs_z, lane_z, sg * z_group, 2);
+        if constexpr (BITS == 3) zr2[j][c] = __builtin_amdgcn_raw_buffer_load_b32(rs_z, lane_z2, sg * z_group, 2);
+      }
+    }
+    const int so = 64 * kc;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int vo = live ? xd_voff[mt][h] : 0x7ffffff0;  // dead stage: out of range -> zeros, no memory traffic
+        lds_void_t *dst = (lds_void_t *)(xd + ((u * MT + mt) * 2 + h) * 1024);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, dst, 16, vo, so, 0, 0);
+      }
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int wrow = (WR * 64) * (kc + e);
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        if constexpr (BITS == 4) {
+          w[2 * u + e][c] = __builtin_amdgcn_raw_buffer_load_b32(rs_w, lane_w, strip_of[c] * strip_bytes + wrow, 2);
+        } else {
+          w[2 * u + e][c] = __builtin_amdgcn_raw_buffer_load_b32(rs_w, lane_w3_lo, strip_of[c] * strip_bytes + wrow, 2);
+          w_hi[2 * u + e][c] = __builtin_amdgcn_raw_buffer_load_b32(rs_w, lane_w3_hi, strip_of[c] * strip_bytes + wrow, 2);
+        }
+      }
+    }
+  };
+
+  float4_t gacc[MT][CPL], g_sx[MT];
+  // the two k-steps of slot u (+ the group's scale / zero-point step when a group ends here)
+  auto compute = [&](const int u) __attribute__((always_inline)) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int s = 2 * u + e;
+      const float4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+      half8_t av[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const uint4_t xraw = *(const uint4_t *)(xd + (u * MT + mt) * 2048 + xd_rd[e]);
+        half8_t xv;
+        if constexpr (BF16) xv = bf16x8_to_h8(xraw); else xv = __builtin_bit_cast(half8_t, xraw);
+        if constexpr (BITS == 4) {
+          av[mt] = a_perm_04152637(xv);
+        } else {
+          const half8_t pv = __builtin_shufflevector(xv, xv, 0, 5, 1, 6, 2, 7, 3, 4);
+          const half2_t q0 = half2_t{pv[0], pv[1]} * half2_t{(half_t)0.5f, (half_t)1.f};
+          const half2_t q1 = half2_t{pv[2], pv[3]} * half2_t{(half_t)0.0625f, (half_t)0.125f};
+          const half2_t q2 = half2_t{pv[4], pv[5]} * half2_t{(half_t)0.0078125f, (half_t)0.015625f};
+          av[mt] = half8_t{q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, pv[6], pv[7]};
+        }
+        g_sx[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[mt], b_sum, (s % SPG == 0) ? zero4 : g_sx[mt], 0, 0, 0);
+      }
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        half2_t b0, b1, b2, b3;
+        if constexpr (BITS == 4) {
+          const uint32_t wv = w[s][c], w8 = wv >> 8;
+          b0 = as_h2((wv & mask_lo) | kMagic); b1 = as_h2((wv & mask_hi) | kMagic64);
+          b2 = as_h2((w8 & mask_lo) | kMagic); b3 = as_h2((w8 & mask_hi) | kMagic64);
+        } else {
+          const uint32_t f = __builtin_amdgcn_alignbit(w_hi[s][c], w[s][c], shift3);
+          const uint32_t f1 = f << 1;
+          b0 = as_h2((f1 & m3a) | kMagic);
+          b1 = as_h2((f1 & m3b) | kMagic);
+          b2 = as_h2((f1 & m3c) | kMagic);
+          const uint32_t lo34 = ((f >> 9) & m3d) | kMagic;
+          b3 = as_h2(((f << 4) & m3e) | lo34);
+        }
+        const half8_t bf = {b0.x, b0.y, b1.x, b1.y, b2.x, b2.y, b3.x, b3.y};
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          gacc[mt][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[mt], bf, (s % SPG == 0) ? zero4 : gacc[mt][c], 0, 0, 0);
+          gacc[mt][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[mt], b_nbias, gacc[mt][c], 0, 0, 0);
+        }
+      }
+      if (s % SPG == SPG - 1) {
+        // y += scale * (sum x q  -  z * Sx)
+        const int j = s / SPG;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+          uint32_t field;
+          if constexpr (BITS == 3) field = (uint32_t)(((((uint64_t)zr2[j][c]) << 32) | zr[j][c]) >> zsh);
+          else field = zr[j][c] >> zsh;
+          const uint32_t zbits = ((field + zbias) & zmask) | zor;
+          const float zf = (float)__builtin_bit_cast(half_t, (uint16_t)zbits) + zadd;
+          const float sfc = (float)sc2[j][c / 2][c & 1];
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float t = __builtin_fmaf(-zf, g_sx[mt][q], gacc[mt][c][q]);
+              yacc[mt][c][q] = __builtin_fmaf(sfc, t, yacc[mt][c][q]);
+            }
+        }
+      }
+    }
+  };
+
+  // ---- prologue: the whole ring; then rounds ------------------------------------------------------------------------------
+#pragma unroll
+  for (int u = 0; u < NS; ++u) {
+    request(t0, u);
+    __builtin_amdgcn_sched_barrier(0);  // (the waits below count requests in THIS order)
+  }
+  if (dbg_slot) {
+    if (lane == 0) dbg_slot[1] = __builtin_amdgcn_s_memrealtime();
+    wait_vmcnt<L_ALL - L_EVEN>();
+    if (lane == 0) dbg_slot[2] = __builtin_amdgcn_s_memrealtime();
+  }
+  for (int r = 0; r + 1 < rounds; ++r) {
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+      // everything requested after this slot's last request: the other slots, once each
+      if (u & 1) wait_vmcnt<L_ALL - L_ODD>();
+      else wait_vmcnt<L_ALL - L_EVEN>();
+      __builtin_amdgcn_sched_barrier(0);
+      compute(u);
+      __builtin_amdgcn_sched_barrier(0);
+      request(t0 + 2 * NS * (r + 1), u);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // last round: nothing is re-requested, the slots behind the one computed are the only ones still in flight
+#pragma unroll
+  for (int u = 0; u < NS; ++u) {
+    if (u == 0) wait_vmcnt<L_ALL - L_EVEN>();
+    else if (u == 1) wait_vmcnt<L_ALL - L_EVEN - L_ODD>();
+    else if (u == 2 && NS > 3) wait_vmcnt<L_ODD>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_sched_barrier(0);
+    compute(u);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (dbg_slot && lane == 0) dbg_slot[3] = __builtin_amdgcn_s_memrealtime();
+
+  // ---- reduce the NW waves' partials through LDS: red[wave][row][col], over the rings once every wave is done with its own -------
+  __syncthreads();
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * mt + 4 * g + r;
+      if (row < M) {
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) red[(wave * M + row) * TN + c * 16 + i] = yacc[mt][c][r];
+      }
+    }
+  __syncthreads();
+  if (dbg_slot && lane == 0) dbg_slot[4] = __builtin_amdgcn_s_memrealtime();
+  for (int e = threadIdx.x; e < M * TN; e += NW * 64) {
+    const int row = e / TN, col = e - row * TN;
+    const int nn = b * TN + col;
+    if (nn >= N) continue;  // (ragged last block)
+    float v = 0.f;
+#pragma unroll
+    for (int wv = 0; wv < NW; ++wv) v += red[(wv * M + row) * TN + col];
+    if (pr.bias) v += (float)pr.bias[nn];
+    if (BF16)
+      ((uint16_t *)pr.y)[(size_t)row * N + nn] = f32_to_bf16(v);
+    else
+      ((half_t *)pr.y)[(size_t)row * N + nn] = (half_t)v;
+  }
+  if (dbg_slot && lane == 0) dbg_slot[5] = __builtin_amdgcn_s_memrealtime();
+}
+
+// dynamic LDS of a launch: the waves' activation rings (8 KB per wave and row tile); the reduction buffer (nw x M x 16 cpl floats)
+// re-uses them
+inline size_t strip_dma_lds_bytes(int M, int nw, int cpl) {
+  const int mt = M > 16 ? 2 : 1;
+  const size_t ring = (size_t)nw * 4 * mt * 2048  /* (sized for four slots whatever the ring) */, red = (size_t)nw * M * 16 * cpl * sizeof(float);
+  return ring > red ? ring : red;
+}
+
+template <int NW, int CPL, int SPG, int BITS, bool BF16, int MT>
+static int launch_strip_dma_t(const StripParams &p, int grid, hipStream_t stream) {
+  static DeviceLatch attr_done;
+  if (int rc = lds_optin(attr_done, (const void *)strip_dma_kernel<NW, CPL, SPG, BITS, BF16, MT>)) return rc;
+  hipLaunchKernelGGL((strip_dma_kernel<NW, CPL, SPG, BITS, BF16, MT>), dim3(grid), dim3(NW * 64), strip_dma_lds_bytes(p.M, NW, CPL), stream, p);
+  QLLM_HIP_CHECK(hipGetLastError());
+  return QLLM_OK;
+}
+
+}  // namespace qllm

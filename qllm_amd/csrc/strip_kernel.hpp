@@ -60,13 +60,6 @@ __device__ __forceinline__ float dpp_add(float v) {
 //       staged values; the per-slot multipliers -> Sx).  Rounds are 8 k-steps (8 x 16 B of x + 8 weight loads in flight
 //       per lane); LDS holds only the cross-wave reduction buffer.  (Measured dead end: also requesting the NEXT round's
 //       weights before computing a round -- two register sets, loop unrolled by two -- was 8-18 % slower at K=11008.)
-// XD (RA with XL == 2; strip-major): the activation fragments go through LDS instead of straight to registers.  A fragment-shaped
-//       load (lane (g, i) -> 16 B of row i) touches 16 rows x 64 B per instruction: every 16-lane pass of the texture addresser sees
-//       16 different cache lines, and at M = 16 the launch was bound by exactly that (1.2-2.4 TB/s of weights).  Here a round's
-//       activations -- 16 rows x 256 k = 8 KB per wave and row tile -- arrive as eight LDS-DMA pieces of 8 rows x 128 B (full
-//       lines: a 16-lane pass reads two), land in a wave-private XOR-swizzled [k-step pair][16 rows][128 B] image (the source
-//       address carries the swizzle: cdna_hip_programming.md rule 21) and are read back as A fragments with ds_read_b128.  No
-//       registers are held across the load latency.  K must be a multiple of 64 (host: strip_plan).
 // MT (RA only): 16-row MFMA tiles per block, M <= 16*MT.  Every B fragment built from a packed word is used MT times, so the
 //       per-weight VALU work is amortised over up to 64 rows; each k-step holds MT x 16 B of activations per lane.
 // SM: strip-major native layout: qweight [N/16][K*BITS/32][16] words, scales [N/16][K/g][16] halves, zero points
@@ -93,9 +86,6 @@ __global__ __launch_bounds__(NW * 64, (SM && !RA && NW <= 8) ? ((NW == 8 && MAXS
   constexpr int TN = 16 * CPL;     // columns per block
   constexpr int GL = 4 * SPG;      // lanes (16-byte chunks) per group in the staging pass: 8 or 16
   constexpr int WR = (BITS == 4) ? 4 : 3;  // word-rows per k-step
-  constexpr bool XD = RA && XL == 2;       // activations by LDS-DMA through a wave-private swizzled image
-  static_assert(!XD || SM, "LDS-DMA activations: strip-major instantiations only");
-  typedef __attribute__((address_space(3))) void lds_void_t;
   typedef uint32_t wvec_t __attribute__((ext_vector_type(CPL)));
   typedef float float2_t __attribute__((ext_vector_type(2)));
   // dynamic LDS: red[wave][M rows][TN cols] fp32 | per wave: activation chunk, M rows x (32*spw_pad) halves, row
@@ -306,24 +296,6 @@ __global__ __launch_bounds__(NW * 64, (SM && !RA && NW <= 8) ? ((NW == 8 && MAXS
   const uint16_t *xrow_ra[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) xrow_ra[mt] = (const uint16_t *)p.x + (size_t)min(16 * mt + i, M - 1) * p.K + 8 * g;
-  // XD: the wave's image follows the reduction buffer; per-lane source offsets of the two 8-row pieces of a row tile (row
-  // 8h + lane/8, physical slot lane%8 <- logical chunk (lane%8) ^ swizzle(row)) and the two fragment read offsets (k-step parity
-  // e: logical chunk 4e + g of row i)
-  uint8_t *xd = (uint8_t *)(red + NW * M * TN) + (size_t)wave * (MT * 8192);
-  const auto rs_x = __builtin_amdgcn_make_buffer_rsrc((void *)p.x, 0, (int)min((size_t)M * p.K * 2, (size_t)0x7fffffff), 0x00020000);
-  int xd_voff[MT][2];
-  int xd_rd[2];
-  if constexpr (XD) {
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int r = 8 * h + (lane >> 3);
-        xd_voff[mt][h] = min(16 * mt + r, M - 1) * p.K * 2 + (((lane & 7) ^ lds_row_swizzle(r)) << 4);
-      }
-#pragma unroll
-    for (int e = 0; e < 2; ++e) xd_rd[e] = i * 128 + (((4 * e + g) ^ lds_row_swizzle(i)) << 4);
-  }
   // constant B fragments: all ones, and the per-slot multipliers that undo the staged divisors (4 bits: x16 on the odd
   // pairs; 3 bits: 2,1 | 16,8 | 128,64 | 1,1)
   const half8_t b_ones = {(half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f};
@@ -374,22 +346,8 @@ __global__ __launch_bounds__(NW * 64, (SM && !RA && NW <= 8) ? ((NW == 8 && MAXS
     }
     }
     // ---- 2b. RA: this round's activation fragments, raw (16 B per k-step; L2-resident, so they land before the weights)
-    uint4_t xq[(RA && !XD) ? MAXS : 1][MT];
-    if constexpr (XD) {
-      // (the previous round's fragment reads have all been consumed by its MFMAs; nothing may move across this point)
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int u = 0; u < MAXS / 2; ++u)
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const int so = 64 * min(base + 2 * u, p.T - 2);  // bytes: k-step pair, clamped as a whole (T is even)
-            const int vo = xd_voff[mt][h];
-            lds_void_t *dst = (lds_void_t *)(xd + mt * 8192 + u * 2048 + h * 1024);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, dst, 16, vo, so, 0, 0);
-          }
-    } else if constexpr (RA) {
+    uint4_t xq[RA ? MAXS : 1][MT];
+    if constexpr (RA) {
 #pragma unroll
       for (int s = 0; s < MAXS; ++s)
 #pragma unroll
@@ -438,11 +396,6 @@ __global__ __launch_bounds__(NW * 64, (SM && !RA && NW <= 8) ? ((NW == 8 && MAXS
     // for them with vmcnt(0).  WIN: without it hipcc hoists the first instructions of the activation staging (the bf16
     // conversion) ABOVE the scale / weight loads and waits for x (s_waitcnt vmcnt(1)) before a single weight load has left
     if constexpr (RA || WIN) __builtin_amdgcn_sched_barrier(0);
-    if constexpr (XD) {
-      // the DMA pieces are older than the weight loads and memory operations retire in order: once only the weight loads are
-      // outstanding the image is complete (the weights stay in flight)
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MAXS * CPL * (BITS == 3 ? 2 : 1)) : "memory");
-    }
     if constexpr (DBG) {
       if (r == 0 && dbg_slot && lane == 0) dbg_slot[1] = __builtin_amdgcn_s_memrealtime();
     }
@@ -470,10 +423,7 @@ __global__ __launch_bounds__(NW * 64, (SM && !RA && NW <= 8) ? ((NW == 8 && MAXS
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
           half8_t xv;  // bf16 activations: compile-time variant (a runtime branch per k-step would split the straight-line body)
-          uint4_t xraw;
-          if constexpr (XD) xraw = *(const uint4_t *)(xd + mt * 8192 + (s >> 1) * 2048 + xd_rd[s & 1]);
-          else xraw = xq[s][mt];
-          if constexpr (RA_BF16) xv = bf16x8_to_h8(xraw); else xv = __builtin_bit_cast(half8_t, xraw);
+          if constexpr (RA_BF16) xv = bf16x8_to_h8(xq[s][mt]); else xv = __builtin_bit_cast(half8_t, xq[s][mt]);
           if constexpr (BITS == 4) {
             const half8_t pv = a_perm_04152637(xv);
             const half_t sixteenth = valid ? (half_t)0.0625f : (half_t)0.f;

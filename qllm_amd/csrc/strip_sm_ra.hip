@@ -1,40 +1,68 @@
 // Strip-major (native layout) instantiations of the full-K strip decode kernel (strip_kernel.hpp): register-A forms, M = 5..64
 // (and long-K g64 / 3-bit layers at any M).  16-wave blocks of one 16-column strip, 8-wave blocks for 2 / 4 row tiles, and -- M = 5..16,
 // 4 bits, every layer a multiple of 64 wide -- 8-wave blocks of FOUR adjacent strips (the activation fragments shared by 64 columns).
+#include "strip_dma.hpp"
 #include "strip_kernel.hpp"
 
 namespace qllm {
 
-template <int SPG, bool BF, int XV>
+template <int SPG, bool BF>
 static int launch_sm_ra(const StripParams &p, int grid, size_t lds, hipStream_t stream) {
   if (p.M > 16) {
     if (p.bits == 3) {  // (four 3-bit row tiles need 256+ registers: the planner stops at two)
       if (p.M > 32) return set_error(QLLM_ERR_UNSUPPORTED, "internal: 3-bit strip-major strips serve M <= 32");
-      return launch_strip_t<8, 1, 8, SPG, XV, 3, true, BF, 2, true>(p, grid, lds, stream);
+      return launch_strip_t<8, 1, 8, SPG, 1, 3, true, BF, 2, true>(p, grid, lds, stream);
     }
-    // (four row tiles: 32 KB of activations per wave and round do not fit next to the reduction buffer -- fragment loads)
-    return p.M > 32 ? launch_strip_t<8, 1, 8, SPG, 1, 4, true, BF, 4, true>(p, grid, lds, stream) : launch_strip_t<8, 1, 8, SPG, XV, 4, true, BF, 2, true>(p, grid, lds, stream);
+    return p.M > 32 ? launch_strip_t<8, 1, 8, SPG, 1, 4, true, BF, 4, true>(p, grid, lds, stream) : launch_strip_t<8, 1, 8, SPG, 1, 4, true, BF, 2, true>(p, grid, lds, stream);
   }
-  if (p.bits == 3 && p.cpl == 2) return launch_strip_t<8, 2, 8, SPG, XV, 3, true, BF, 1, true>(p, grid, lds, stream);  // (four 3-bit strips spill)
+  if (p.bits == 3 && p.cpl == 2) return launch_strip_t<8, 2, 8, SPG, 1, 3, true, BF, 1, true>(p, grid, lds, stream);  // (four 3-bit strips spill)
   if (p.bits == 3) {
-    if constexpr (SPG == 2 && BF && XV == 1)  // (this one spills 7 registers: not built; callers stream the reference layout in place)
+    if constexpr (SPG == 2 && BF)  // (this one spills 7 registers: not built; callers stream the reference layout in place)
       return set_error(QLLM_ERR_UNSUPPORTED, "3-bit g64 native-layout layers with bf16 activations: no strip-major kernel");
     else
-      return launch_strip_t<16, 1, 8, SPG, XV, 3, true, BF, 1, true>(p, grid, lds, stream);
+      return launch_strip_t<16, 1, 8, SPG, 1, 3, true, BF, 1, true>(p, grid, lds, stream);
   }
-  if (p.cpl == 4) return launch_strip_t<8, 4, 8, SPG, XV, 4, true, BF, 1, true>(p, grid, lds, stream);  // four strips per 8-wave block
-  return p.nw == 8 ? launch_strip_t<8, 1, 8, SPG, XV, 4, true, BF, 1, true>(p, grid, lds, stream)
-                   : launch_strip_t<16, 1, 8, SPG, XV, 4, true, BF, 1, true>(p, grid, lds, stream);
+  if (p.cpl == 4) return launch_strip_t<8, 4, 8, SPG, 1, 4, true, BF, 1, true>(p, grid, lds, stream);  // four strips per 8-wave block
+  return p.nw == 8 ? launch_strip_t<8, 1, 8, SPG, 1, 4, true, BF, 1, true>(p, grid, lds, stream)
+                   : launch_strip_t<16, 1, 8, SPG, 1, 4, true, BF, 1, true>(p, grid, lds, stream);
+}
+
+// M = 5..32 with the activations staged through LDS by DMA (strip_dma.hpp; host planner: ra == 2): 16-wave blocks of one strip,
+// 8-wave blocks of 1 / 2 / 4 / 6 strips (3 bits: 1 / 2 / 4), 8-wave blocks of one strip and two row tiles
+template <int SPG, bool BF>
+static int launch_sm_dma(const StripParams &p, int grid, hipStream_t stream) {
+  if (p.M > 16) {
+    if (p.cpl != 1 || p.nw != 8) return set_error(QLLM_ERR_UNSUPPORTED, "internal: two row tiles take 8-wave blocks of one strip");
+    if (p.bits == 3) return launch_strip_dma_t<8, 1, SPG, 3, BF, 2>(p, grid, stream);
+    return launch_strip_dma_t<8, 1, SPG, 4, BF, 2>(p, grid, stream);
+  }
+  if (p.cpl == 1 && p.nw == 16) return p.bits == 3 ? launch_strip_dma_t<16, 1, SPG, 3, BF, 1>(p, grid, stream) : launch_strip_dma_t<16, 1, SPG, 4, BF, 1>(p, grid, stream);
+  if (p.nw != 8) return set_error(QLLM_ERR_UNSUPPORTED, "internal: blocks of several strips are 8 waves");
+  if (p.bits == 3) {
+    switch (p.cpl) {
+      case 1: return launch_strip_dma_t<8, 1, SPG, 3, BF, 1>(p, grid, stream);
+      case 2: return launch_strip_dma_t<8, 2, SPG, 3, BF, 1>(p, grid, stream);
+      case 4: return launch_strip_dma_t<8, 4, SPG, 3, BF, 1>(p, grid, stream);
+    }
+  } else {
+    switch (p.cpl) {
+      case 1: return launch_strip_dma_t<8, 1, SPG, 4, BF, 1>(p, grid, stream);
+      case 2: return launch_strip_dma_t<8, 2, SPG, 4, BF, 1>(p, grid, stream);
+      case 4: return launch_strip_dma_t<8, 4, SPG, 4, BF, 1>(p, grid, stream);
+      case 6: return launch_strip_dma_t<8, 6, SPG, 4, BF, 1>(p, grid, stream);
+    }
+  }
+  return set_error(QLLM_ERR_UNSUPPORTED, "internal: no %d-bit block of %d strips", p.bits, p.cpl);
 }
 
 int launch_strip_sm_ra(const StripParams &p, int grid, hipStream_t stream) {
-  const size_t lds = strip_lds_bytes(p.M, p.spw, p.nw, p.cpl, p.group_size, p.ra, 1);
-  if (p.ra == 2) {  // activations by LDS-DMA
-    if (p.group_size == 64) return p.act_bf16 ? launch_sm_ra<2, true, 2>(p, grid, lds, stream) : launch_sm_ra<2, false, 2>(p, grid, lds, stream);
-    return p.act_bf16 ? launch_sm_ra<4, true, 2>(p, grid, lds, stream) : launch_sm_ra<4, false, 2>(p, grid, lds, stream);
+  if (p.ra == 2) {
+    if (p.group_size == 64) return p.act_bf16 ? launch_sm_dma<2, true>(p, grid, stream) : launch_sm_dma<2, false>(p, grid, stream);
+    return p.act_bf16 ? launch_sm_dma<4, true>(p, grid, stream) : launch_sm_dma<4, false>(p, grid, stream);
   }
-  if (p.group_size == 64) return p.act_bf16 ? launch_sm_ra<2, true, 1>(p, grid, lds, stream) : launch_sm_ra<2, false, 1>(p, grid, lds, stream);
-  return p.act_bf16 ? launch_sm_ra<4, true, 1>(p, grid, lds, stream) : launch_sm_ra<4, false, 1>(p, grid, lds, stream);
+  const size_t lds = strip_lds_bytes(p.M, p.spw, p.nw, p.cpl, p.group_size, 1, 1);
+  if (p.group_size == 64) return p.act_bf16 ? launch_sm_ra<2, true>(p, grid, lds, stream) : launch_sm_ra<2, false>(p, grid, lds, stream);
+  return p.act_bf16 ? launch_sm_ra<4, true>(p, grid, lds, stream) : launch_sm_ra<4, false>(p, grid, lds, stream);
 }
 
 }  // namespace qllm

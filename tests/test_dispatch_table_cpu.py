@@ -129,14 +129,20 @@ def test_native_layout_decode_routes(lib):
     assert plan(lib, [up] * 2, 1) == "strip nw=8 cpl=1 spw=16 form=lds-slab row_tiles=1" + sm
     assert plan(lib, [down], 1) == "strip nw=16 cpl=1 spw=24 form=lds-slab row_tiles=1" + sm
     assert plan(lib, [attn], 4) == "strip nw=8 cpl=1 spw=16 form=lds-slab row_tiles=1" + sm
+    # M = 5..32: strip_dma.hpp (activations through LDS by DMA); one strip per 16-wave block while the strips fit one round of CUs
     for m in (5, 16):
-        assert plan(lib, [attn], m) == "strip nw=16 cpl=1 spw=8 form=register-A row_tiles=1" + sm
-    # M = 5..16 on wide (grouped) launches: blocks of four adjacent strips share the activation fragments
-    assert plan(lib, [attn] * 3, 16) == "strip nw=8 cpl=4 spw=16 form=register-A row_tiles=1" + sm
-    assert plan(lib, [up] * 2, 8) == "strip nw=8 cpl=4 spw=16 form=register-A row_tiles=1" + sm
-    assert plan(lib, [W(4096, 11008, 64, 4, NATIVE_F16Z)] * 2, 16) == "strip nw=8 cpl=4 spw=16 form=register-A row_tiles=1" + sm
-    assert plan(lib, [W(4096, 4096, 64, 3, NATIVE_F16Z)] * 3, 16) == "strip nw=8 cpl=2 spw=16 form=register-A row_tiles=1" + sm  # 3 bits: two strips
-    assert plan(lib, [attn], 32) == "strip nw=8 cpl=1 spw=16 form=register-A row_tiles=2" + sm
+        assert plan(lib, [attn], m) == "strip nw=16 cpl=1 spw=8 form=dma-A row_tiles=1" + sm
+        assert plan(lib, [down], m) == "strip nw=16 cpl=1 spw=24 form=dma-A row_tiles=1" + sm
+    # ... wide (grouped) launches: blocks of several adjacent strips share one activation stream -- as many as make the launch ONE
+    # round of blocks: q/k/v 768 strips -> 192 blocks of four; gate/up 1376 strips -> 230 blocks of six, the last of each layer ragged
+    assert plan(lib, [attn] * 3, 16) == "strip nw=8 cpl=4 spw=16 form=dma-A row_tiles=1" + sm
+    assert plan(lib, [up] * 2, 8) == "strip nw=8 cpl=6 spw=16 form=dma-A row_tiles=1" + sm
+    assert plan(lib, [up], 16) == "strip nw=8 cpl=4 spw=16 form=dma-A row_tiles=1" + sm
+    assert plan(lib, [W(4096, 11008, 64, 4, NATIVE_F16Z)] * 2, 16) == "strip nw=8 cpl=6 spw=16 form=dma-A row_tiles=1" + sm
+    assert plan(lib, [W(4096, 4096, 64, 3, NATIVE_F16Z)] * 3, 16) == "strip nw=8 cpl=4 spw=16 form=dma-A row_tiles=1" + sm
+    assert plan(lib, [W(4096, 11008, 64, 3, NATIVE_F16Z)] * 2, 16) == "strip nw=8 cpl=4 spw=16 form=dma-A row_tiles=1" + sm  # 3 bits: four at most
+    assert plan(lib, [attn], 32) == "strip nw=8 cpl=1 spw=16 form=dma-A row_tiles=2" + sm
+    assert plan(lib, [W(4000, 4096, 32 * 125, 4, NATIVE)], 16).startswith("unsupported") or "dma-A" not in plan(lib, [W(4000, 4096, 32 * 125, 4, NATIVE)], 16)
     assert plan(lib, [attn], 64) == "strip nw=8 cpl=1 spw=16 form=register-A row_tiles=4" + sm
     assert plan(lib, [up], 64) == "gemm2 tile=256x128 split_k=2" + sm      # 33..64 rows on the wide shapes: the tile GEMM
     assert plan(lib, [down], 33) == "gemm2 tile=256x128 split_k=8" + sm
@@ -151,7 +157,7 @@ def test_native_layout_decode_routes(lib):
     assert plan(lib, [h4], 2).startswith("strip nw=16 cpl=1 spw=8 form=register-A")
     assert plan(lib, [W(11008, 4096, 64, 4, NATIVE_F16Z)], 1).startswith("strip nw=16 cpl=1 spw=22 form=register-A")
     assert plan(lib, [h3], 1).startswith("strip nw=16 cpl=1 spw=8 form=lds-slab")
-    assert plan(lib, [h3], 16).startswith("strip nw=16 cpl=1 spw=8 form=register-A")
+    assert plan(lib, [h3], 16).startswith("strip nw=16 cpl=1 spw=8 form=dma-A")
     assert plan(lib, [h3], 32).endswith("row_tiles=2" + sm)
     assert plan(lib, [h3], 48).startswith("gemm3") and "bits=3" in plan(lib, [h3], 48)   # (four 3-bit row tiles would need > 256 registers)
     assert plan(lib, [W(4096, 4096, 32, layout=NATIVE)], 1).startswith("unsupported")   # group sizes the strips do not serve

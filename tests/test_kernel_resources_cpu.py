@@ -19,7 +19,7 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 def _resources(src):
     if not os.path.exists(HIPCC):
         pytest.skip("hipcc not available")
-    stamp = max(int(os.path.getmtime(os.path.join(CSRC, f))) for f in (src, "strip_kernel.hpp", "kernels.hpp", "common.hpp"))
+    stamp = max(int(os.path.getmtime(os.path.join(CSRC, f))) for f in (src, "strip_kernel.hpp", "strip_dma.hpp", "kernels.hpp", "common.hpp"))
     out = os.path.join("/tmp", f"qllm_res_{src}_{stamp}.s")
     if not os.path.exists(out):
         subprocess.run([HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-S",
@@ -65,12 +65,13 @@ def test_no_strip_instantiation_spills():
     (the dispatchers build only what the planner reaches) must be spill-free, in all three translation units."""
     total = 0
     for src in ("strip.hip", "strip_sm.hip", "strip_sm_ra.hip"):
-        res = {n: v for n, v in _resources(src).items() if "strip_kernel" in n}
+        res = {n: v for n, v in _resources(src).items() if "strip_kernel" in n or "strip_dma_kernel" in n}
         assert res, src
         total += len(res)
         for n, (vgpr, spill) in res.items():
+            # (strip_dma.hpp counts its vmcnt queue by hand: a scratch reload there would also be one more entry on that queue)
             assert spill == 0, (src, n, vgpr, spill)
-            nw = int(re.search(r"strip_kernelILi(\d+)E", n).group(1))
+            nw = int(re.search(r"strip(?:_dma)?_kernelILi(\d+)E", n).group(1))
             assert vgpr <= (128 if nw == 16 else 256), (src, n, vgpr)   # a 16-wave block cannot exceed 128 registers
     assert total >= 100
 

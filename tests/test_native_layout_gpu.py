@@ -116,27 +116,32 @@ def test_native_grouped_launch_and_autogptq_offset():
 
 
 @pytest.mark.parametrize("layout,bits,g", [("HQQ", 4, 64), ("HQQ", 3, 64), ("GPTQ", 3, 128), ("GEMM", 4, 128)])
-def test_native_multi_strip_blocks_at_batch_16(layout, bits, g):
-    """M = 5..16 on wide grouped launches: register-A blocks of four (3 bits: two) adjacent strips sharing the activation fragments
-    (BASELINE configs[3]: HQQ g64, mixed 3 / 4 bits, batch 16)."""
+@pytest.mark.parametrize("widths", [(4096, 4096, 4096), (11008, 11008), (5152, 5152)])
+def test_native_multi_strip_blocks_at_batch_16(layout, bits, g, widths):
+    """M = 5..16 on wide grouped launches (BASELINE configs[3]: HQQ g64, mixed 3 / 4 bits, batch 16): blocks of several adjacent
+    strips sharing one activation stream (strip_dma.hpp).  q/k/v-like: blocks of four; gate/up-like: blocks of six (4 bits) with a
+    ragged last block per layer (688 strips = 114 x 6 + 4); (5152, 5152): 322 strips each, blocks of four, the last one of two."""
     from qllm_amd import ops
-    ds = [synth(layout, bits, g, 4096, n, seed=90 + i, bias=(i == 0)) for i, n in enumerate((4096, 4096, 4096))]
+    ds = [synth(layout, bits, g, 4096, n, seed=90 + i, bias=(i == 0)) for i, n in enumerate(widths)]
     layers = [to_layer(d, DEV) for d in ds]
     ws = [l.native_descriptor(0) for l in layers]
-    want = "cpl=2" if bits == 3 else "cpl=4"
     for m in (5, 16):
-        assert want in ops.plan_describe(ws, m) and "-A" in ops.plan_describe(ws, m), ops.plan_describe(ws, m)
+        plan = ops.plan_describe(ws, m)
+        assert "form=dma-A" in plan and "layout=strip-major" in plan, plan
+        if widths[0] in (4096, 5152):
+            assert "cpl=4" in plan, plan
+        if widths[0] == 11008:  # (3 bits: four strips at most, two when the activation rows are few)
+            assert ("cpl=6" in plan) if bits == 4 else ("cpl=4" in plan or "cpl=2" in plan), plan
         x = randx(m, 4096, seed=m)
         outs = ops.linear_forward_grouped(ws, torch.from_numpy(x).to(DEV))
         for o, d in zip(outs, ds):
             ref = Ref(d)
-            assert O.rel_err(o.cpu().numpy(), ref.y16(x)) <= 1e-2, (layout, bits, m)
-            assert O.rel_err(o.cpu().numpy().astype(np.float64), ref.y64(x)) <= 2e-3, (layout, bits, m)
-    if not (bits == 3 and g == 64):
-        xb = torch.from_numpy(randx(16, 4096, seed=7)).to(DEV).to(torch.bfloat16)
-        outs = ops.linear_forward_grouped(ws, xb)
-        for o, d in zip(outs, ds):
-            assert O.rel_err(o.float().cpu().numpy(), Ref(d).y64(xb.float().cpu().numpy().astype(np.float16))) <= 2e-2
+            assert O.rel_err(o.cpu().numpy(), ref.y16(x)) <= 1e-2, (layout, bits, m, plan)
+            assert O.rel_err(o.cpu().numpy().astype(np.float64), ref.y64(x)) <= 2e-3, (layout, bits, m, plan)
+    xb = torch.from_numpy(randx(16, 4096, seed=7)).to(DEV).to(torch.bfloat16)
+    outs = ops.linear_forward_grouped(ws, xb)
+    for o, d in zip(outs, ds):
+        assert O.rel_err(o.float().cpu().numpy(), Ref(d).y64(xb.float().cpu().numpy().astype(np.float16))) <= 2e-2
 
 
 def test_native_layout_is_what_the_modules_decode_from():
