@@ -22,9 +22,9 @@
 //     by hand (raw buffer loads and DMA pieces: nothing hipcc may merge or drop), so each stage waits with an exact
 //     `s_waitcnt vmcnt(total - own)`.  All addressing is per-lane constant + wave-uniform scalar offset: no vector address
 //     arithmetic in the loop.
-//   * THE BIAS LEAVES THROUGH THE MATRIX CORE.  B fragments are raw patterns 1024 + q / 64 + q (below); a second MFMA per strip
-//     against a constant fragment of minus the slot biases brings the group accumulator to sum x q, a third per k-step against ones
-//     gives Sx: the per-group VALU work is 4 packed FMAs + the decode of one scale and one zero point per strip.
+//   * THE BIAS LEAVES THROUGH THE MATRIX CORE.  B fragments are raw patterns 1024 + q / 64 + q (below); two bookkeeping MFMAs per
+//     k-step (shared by the block's strips) against constant fragments give minus sum x bias and Sx = sum x in the accumulator
+//     layout: the per-group VALU work of a strip is 6 packed operations + the decode of one scale and one zero point.
 //   * k-steps past the wave's chunk or past K: the DMA source offset is pushed out of the buffer's range, the image holds zeros and
 //     the stage contributes nothing (the weight / scale addresses are clamped into the strip and cost an L2 hit).
 //   Measured dead ends (same file, profiles/r03_batch16.md): K split over adjacent blocks with fp32 partial slabs + arrival ticket
@@ -40,9 +40,9 @@ namespace qllm {
 
 // NW: waves per block; CPL: adjacent 16-column strips per block (lane (g, i) holds column i of each); SPG: k-steps per group
 // (group_size / 32: 2 or 4); BITS: 4 or 3; BF16: bf16 activations (converted after the fragment read); MT: 16-row tiles (M <= 16 MT)
-// (six strips of 64-wide groups: a ring of three stages -- four need more than 256 registers)
+// (six 4-bit / four 3-bit strips of 64-wide groups: a ring of three stages -- four need more than 256 registers)
 template <int CPL, int SPG, int BITS>
-constexpr int strip_dma_ring() { return (CPL >= 6 && SPG == 2) ? 3 : 4; }
+constexpr int strip_dma_ring() { return (SPG == 2 && (CPL >= 6 || (BITS == 3 && CPL >= 4))) ? 3 : 4; }
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -87,7 +87,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void strip_dma_kernel(const StripP
     for (int q = 1; q < kMaxProblems; ++q)
       if (q < p.n_prob && (int)blockIdx.x >= p.block_begin8[q]) pi = q;
   }
+  // (the whole problem record plus the launch scalars pulled in ONE batch of scalar loads: the empty asm "uses" them here, so hipcc
+  //  cannot issue them one at a time at first use -- strip_kernel.hpp)
   const StripProblem pr = p.prob[pi];
+  asm volatile("" ::"s"(pr.qweight), "s"(pr.scales), "s"(pr.qzeros), "s"(pr.bias), "s"(pr.y), "s"(pr.N), "s"(pr.block_begin), "s"(pr.zero_kind),
+               "s"(p.x), "s"(p.M), "s"(p.K), "s"(p.T), "s"(p.spw), "s"(p.n_groups), "s"(p.add_zero_bias));
   const int b = blockIdx.x - pr.block_begin;
   const int N = pr.N, M = p.M, T = p.T;
   const int spw = p.spw;
@@ -214,7 +218,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void strip_dma_kernel(const StripP
     }
   };
 
-  float4_t gacc[MT][CPL], g_sx[MT];
+  float4_t gacc[MT][CPL], g_sx[MT], g_nb[MT];  // group accumulators: sum x (q + bias) per strip; sum x; minus sum x bias
   // the two k-steps of slot u (+ the group's scale / zero-point step when a group ends here)
   auto compute = [&](const int u) __attribute__((always_inline)) {
 #pragma unroll
@@ -237,6 +241,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void strip_dma_kernel(const StripP
           av[mt] = half8_t{q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, pv[6], pv[7]};
         }
         g_sx[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[mt], b_sum, (s % SPG == 0) ? zero4 : g_sx[mt], 0, 0, 0);
+        g_nb[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[mt], b_nbias, (s % SPG == 0) ? zero4 : g_nb[mt], 0, 0, 0);
       }
 #pragma unroll
       for (int c = 0; c < CPL; ++c) {
@@ -258,11 +263,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void strip_dma_kernel(const StripP
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
           gacc[mt][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[mt], bf, (s % SPG == 0) ? zero4 : gacc[mt][c], 0, 0, 0);
-          gacc[mt][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[mt], b_nbias, gacc[mt][c], 0, 0, 0);
         }
       }
       if (s % SPG == SPG - 1) {
-        // y += scale * (sum x q  -  z * Sx)
+        // y += scale * (sum x (q + bias) - sum x bias  -  z * Sx)
         const int j = s / SPG;
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
@@ -276,7 +280,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void strip_dma_kernel(const StripP
           for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-              const float t = __builtin_fmaf(-zf, g_sx[mt][q], gacc[mt][c][q]);
+              const float t = __builtin_fmaf(-zf, g_sx[mt][q], gacc[mt][c][q] + g_nb[mt][q]);
               yacc[mt][c][q] = __builtin_fmaf(sfc, t, yacc[mt][c][q]);
             }
         }
