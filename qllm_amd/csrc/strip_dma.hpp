@@ -74,6 +74,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void strip_dma_kernel(const StripP
   const int g = lane >> 4, i = lane & 15;
   // diagnostics (qllm_debug_timeline): wave 0 of the first, the middle and the last block stamp [entry, ring requested, first stage
   // landed, rounds done, after the reduction barrier, exit] with the 100 MHz clock
+  asm volatile("" ::"s"(p.dbg), "s"(p.n_prob), "s"(p.block_begin8[1]), "s"(p.block_begin8[2]), "s"(p.block_begin8[3]));  // (one batch of scalar loads)
   uint64_t *dbg_slot = nullptr;
   if (p.dbg && wave == 0) {
     if (blockIdx.x == 0) dbg_slot = p.dbg;
@@ -111,9 +112,13 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void strip_dma_kernel(const StripP
   const auto rs_s = __builtin_amdgcn_make_buffer_rsrc((void *)pr.scales, 0, (N >> 4) * gtab * 32, 0x00020000);
   const auto rs_z = __builtin_amdgcn_make_buffer_rsrc((zk == ZK_SYM) ? (void *)pr.scales : (void *)pr.qzeros, 0,
                                                       (zk == ZK_SYM) ? (N >> 4) * gtab * 32 : (N >> 4) * gtab * zmul * 4, 0x00020000);
-  int strip_of[CPL];  // (scalar registers)
+  int w_strip[CPL], g_strip[CPL];  // (scalar registers) byte offset of the strip's words; first row of its scale / zero tables
 #pragma unroll
-  for (int c = 0; c < CPL; ++c) strip_of[c] = min(b * CPL + c, (N >> 4) - 1);
+  for (int c = 0; c < CPL; ++c) {
+    const int strip = min(b * CPL + c, (N >> 4) - 1);
+    w_strip[c] = strip * strip_bytes;
+    g_strip[c] = strip * gtab;
+  }
   const int z_group = (zk == ZK_SYM) ? 0 : zmul * 4;
   const int lane_w = (g * 16 + i) * 4;
   const int lane_w3_lo = ((g == 0 ? 0 : g - 1) * 16 + i) * 4, lane_w3_hi = ((g == 3 ? 2 : g) * 16 + i) * 4;
@@ -185,10 +190,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void strip_dma_kernel(const StripP
     const int kc = min(kp, T - 2);    // addresses stay inside the strip
     if ((2 * u + 1) % SPG == SPG - 1) {
       const int j = (2 * u + 1) / SPG;
-      const int G = min(kc / SPG, Gmax);
+      const int G = min((int)((unsigned)kc / SPG), Gmax);
 #pragma unroll
       for (int c = 0; c < CPL; ++c) {
-        const int sg = strip_of[c] * gtab + G;
+        const int sg = g_strip[c] + G;
         sc2[j][c / 2][c & 1] = __builtin_bit_cast(half_t, __builtin_amdgcn_raw_buffer_load_b16(rs_s, lane_s, sg * 32, 2));
         zr[j][c] = __builtin_amdgcn_raw_buffer_load_b32(rs_z, lane_z, sg * z_group, 2);
         if constexpr (BITS == 3) zr2[j][c] = __builtin_amdgcn_raw_buffer_load_b32(rs_z, lane_z2, sg * z_group, 2);
@@ -203,16 +208,16 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void strip_dma_kernel(const StripP
         lds_void_t *dst = (lds_void_t *)(xd + ((u * MT + mt) * 2 + h) * 1024);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, dst, 16, vo, so, 0, 0);
       }
+    const int wrow = (WR * 64) * kc;
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const int wrow = (WR * 64) * (kc + e);
+    for (int e = 0; e < 2; ++e) {  // (the second k-step of the pair: + one k-step of words, an immediate offset)
 #pragma unroll
       for (int c = 0; c < CPL; ++c) {
         if constexpr (BITS == 4) {
-          w[2 * u + e][c] = __builtin_amdgcn_raw_buffer_load_b32(rs_w, lane_w, strip_of[c] * strip_bytes + wrow, 2);
+          w[2 * u + e][c] = __builtin_amdgcn_raw_buffer_load_b32(rs_w, lane_w + e * (WR * 64), w_strip[c] + wrow, 2);
         } else {
-          w[2 * u + e][c] = __builtin_amdgcn_raw_buffer_load_b32(rs_w, lane_w3_lo, strip_of[c] * strip_bytes + wrow, 2);
-          w_hi[2 * u + e][c] = __builtin_amdgcn_raw_buffer_load_b32(rs_w, lane_w3_hi, strip_of[c] * strip_bytes + wrow, 2);
+          w[2 * u + e][c] = __builtin_amdgcn_raw_buffer_load_b32(rs_w, lane_w3_lo + e * (WR * 64), w_strip[c] + wrow, 2);
+          w_hi[2 * u + e][c] = __builtin_amdgcn_raw_buffer_load_b32(rs_w, lane_w3_hi + e * (WR * 64), w_strip[c] + wrow, 2);
         }
       }
     }

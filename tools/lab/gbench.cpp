@@ -88,7 +88,7 @@ int main(int argc, char **argv) {
     hipStream_t st;
     CK(hipStreamCreate(&st));
     struct L { const char *name; int K, N, n; } launches[] = {{"q/k/v", 4096, 4096, 3}, {"o_proj", 4096, 4096, 1}, {"gate/up", 4096, 11008, 2}, {"down", 11008, 4096, 1}};
-    const int NSET = 8;
+    const int NSET = 20;  // (20 x 10..52 MB per launch kind: far beyond the 256 MB Infinity Cache)
     for (int M : ms) {
       double total = 0, bytes_total = 0;
       for (auto l : launches) {
