@@ -121,12 +121,17 @@ if ht:
 
     def hqq_alg(K, N, bits, M=16, g=64):  # packed words + fp16 scales + fp16 zero points + x + y
         return K * N * bits // 8 + 2 * (K // g) * N * 2 + 2 * M * K + 2 * M * N
-    def bits_of(name):
+    def bits_of(name):  # strip_kernel<NW, CPL, MAXS, SPG, XL, BITS, ...> / strip_dma_kernel<NW, CPL, SPG, BITS, BF16, MT>
+        m = re.search(r"strip_dma_kernel<([^>]*)>", name)
+        if m:
+            return int(m.group(1).split(",")[3])
         m = re.search(r"strip_kernel<([^>]*)>", name)
         return int(m.group(1).split(",")[5]) if m else 0
+    def ours(name):
+        return "qllm::strip_kernel" in name or "qllm::strip_dma_kernel" in name
     names = ["q/k/v (one grouped launch)", "o_proj", "gate/up (one grouped launch)", "down_proj"]
     shapes = [(H, 3 * H), (H, H), (H, 2 * I), (I, H)]
-    tr = [r for r in csv.DictReader(open(ht[0])) if "qllm::strip_kernel" in r["Kernel_Name"]]
+    tr = [r for r in csv.DictReader(open(ht[0])) if ours(r["Kernel_Name"])]
     tr.sort(key=lambda r: int(r["Start_Timestamp"]))
     Q = [f"# {tag}: BASELINE configs[3] -- HQQ g64 fp16 zero points, batch 16, per launch", "",
          "`rocprofv3 --kernel-trace --stats -- python tools/hqq_leg.py 10` (four decoder layers of each width through the modules: sibling",
@@ -145,7 +150,7 @@ if ht:
         for kind in ("fetch", "write"):
             fs = glob.glob(f"{src}/hqq_{kind}/*counter_collection.csv")
             if fs:
-                rs = [r for r in csv.DictReader(open(fs[0])) if "qllm::strip_kernel" in r["Kernel_Name"] and bits_of(r["Kernel_Name"]) == bits]
+                rs = [r for r in csv.DictReader(open(fs[0])) if ours(r["Kernel_Name"]) and bits_of(r["Kernel_Name"]) == bits]
                 rs.sort(key=lambda r: int(r["Dispatch_Id"]))
                 agg = collections.defaultdict(lambda: [0, 0.0])
                 for i, r in enumerate(rs):
@@ -171,7 +176,8 @@ if ht:
             tm += med
             ta += a
         Q += ["", f"Sum of the four medians: {tm:.2f} us per decoder layer; algorithmic bytes per layer {ta / 1e6:.1f} MB = "
-              f"{ta / tm / 1e6:.2f} TB/s = {ta / tm / 1e6 / 8.0:.3f} of 8 TB/s.", ""]
+              f"{ta / tm / 1e6:.2f} TB/s = {ta / tm / 1e6 / 8.0:.3f} of 8 TB/s.",
+              "Template arguments of `strip_dma_kernel`: <waves per block, strips per block, k-steps per group, bits, bf16 activations, row tiles>.", ""]
     notes = f"{out}/{tag}_hqq_notes.md"
     if os.path.exists(notes):
         Q += [l.rstrip("\n") for l in open(notes)]
