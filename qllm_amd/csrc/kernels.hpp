@@ -73,7 +73,8 @@ struct StripParams {
   int cpl;      // columns per lane: 1 (16-column strips), 2 or 4 (64-column strips)
   int bits;     // 4, or 3 (bit-stream layout; cpl = 1, fp16 or symmetric zeros)
   int spw;      // k-steps per wave (nw waves per block cover all of K)
-  int ra;       // 1: "register A" variant (no activation slab in LDS; Sx / Sx' from two extra MFMAs), used for M > 2
+  int ra;       // 0: lds-slab form; 1: "register A" form (A fragments straight from L2, Sx / Sx' from two extra MFMAs); 2: strip_dma.hpp
+                // (native layout, M = 5..32: activations through LDS by DMA)
   int group_size;
   int add_zero_bias;
   int act_bf16;

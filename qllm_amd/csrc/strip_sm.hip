@@ -22,7 +22,7 @@ int strip_sm_nw(int K, int M, int group_size, int bits) {
     return T <= 32 ? 4 : (T <= 128 ? 8 : 0);
   }
   if (T <= 32) return 4;
-  if (T <= 128) return (nw4 && M == 1) ? 4 : 8;
+  if (T <= 128) return (nw4 && M == 1) ? 4 : 8;   // (measured: 16-wave blocks of one round of 8 lose here -- 4096 x 11008 6.45 -> 7.11 us)
   if (T <= 256 && M == 1) return 8;                   // one round of 32 (the M = 2..4 staging does not fit beside it: 16 waves)
   return 16;
 }

@@ -1,6 +1,6 @@
-// Strip-major (native layout) instantiations of the full-K strip decode kernel (strip_kernel.hpp): register-A forms, M = 5..64
-// (and long-K g64 / 3-bit layers at any M).  16-wave blocks of one 16-column strip, 8-wave blocks for 2 / 4 row tiles, and -- M = 5..16,
-// 4 bits, every layer a multiple of 64 wide -- 8-wave blocks of FOUR adjacent strips (the activation fragments shared by 64 columns).
+// Strip-major (native layout) instantiations for more than four rows: strip_dma.hpp for M = 5..32 (K a multiple of 64), and the
+// register-A forms of strip_kernel.hpp for what that kernel does not take (M = 33..64, other K, long-K g64 / 3-bit chunks at batch
+// 1..4, QLLM_RA_XD=0): 16-wave blocks of one 16-column strip, 8-wave blocks for 2 / 4 row tiles or 2 / 4 adjacent strips.
 #include "strip_dma.hpp"
 #include "strip_kernel.hpp"
 
