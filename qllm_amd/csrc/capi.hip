@@ -198,7 +198,8 @@ static bool strip_plan(const qllm_weight_t *w, int n, int M, StripPlan *plan) {
         int blocks = 0;
         for (int i = 0; i < n; ++i) blocks += (w[i].N / 16 + c - 1) / c;
         const double cost = (double)((blocks + cus - 1) / cus) * (x_bytes + c * strip_bytes);
-        if (ci == 0 || cost < best_cost * 0.97 || c == dma_cpl) { best = c; best_cost = (c == dma_cpl) ? 0 : cost; }
+        if (ci == 0 || cost < best_cost * 0.97) { best = c; best_cost = cost; }  // (wider only for a clear gain)
+        if (c == dma_cpl) { best = c; break; }                                    // (experiments: QLLM_DMA_CPL forces a width)
       }
       cpl = best;
       nw = (cpl == 1 && M <= 16) ? 16 : 8;
