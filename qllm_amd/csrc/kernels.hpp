@@ -95,6 +95,8 @@ bool strip_x_ok(int M, int spw, int nw, int cpl, int sm);
 int launch_strip(const StripParams &p, int grid, hipStream_t stream);
 int launch_strip_sm(const StripParams &p, int grid, hipStream_t stream);     // strip_sm.hip
 int launch_strip_sm_ra(const StripParams &p, int grid, hipStream_t stream);  // strip_sm_ra.hip
+int launch_strip_dma_g64(const StripParams &p, int grid, hipStream_t stream);   // strip_dma_g64.hip
+int launch_strip_dma_g128(const StripParams &p, int grid, hipStream_t stream);  // strip_dma_g128.hip
 
 // ---- native.hip (reference layouts <-> the strip-major native layout) -------------------------------------------------------
 int launch_repack_native(const qllm_weight_t &src, int zero_kind, void *qweight_out, void *scales_out, void *qzeros_out, hipStream_t stream);

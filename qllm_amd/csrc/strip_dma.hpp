@@ -51,7 +51,10 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N < 63 ? N : 63) : "memory");
 }
 
-template <int NW, int CPL, int SPG, int BITS, bool BF16, int MT>
+// ZF16: every layer of the launch has fp16 zero points (HQQ: the native F16Z layout): the zero-point decode of a group is a shift and a
+//       conversion instead of the branch-free five-operation form that also serves packed and symmetric zeros (a sixth of the
+//       loop's VALU work at 64-wide groups).
+template <int NW, int CPL, int SPG, int BITS, bool BF16, int MT, bool ZF16 = false>
 __global__ __launch_bounds__(NW * 64, NW / 4) void strip_dma_kernel(const StripParams p) {
   static_assert(SPG == 2 || SPG == 4, "groups of 64 or 128");
   constexpr int NS = strip_dma_ring<CPL, SPG, BITS>();  // ring slots (stages of two k-steps)
@@ -278,8 +281,13 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void strip_dma_kernel(const StripP
           uint32_t field;
           if constexpr (BITS == 3) field = (uint32_t)(((((uint64_t)zr2[j][c]) << 32) | zr[j][c]) >> zsh);
           else field = zr[j][c] >> zsh;
-          const uint32_t zbits = ((field + zbias) & zmask) | zor;
-          const float zf = (float)__builtin_bit_cast(half_t, (uint16_t)zbits) + zadd;
+          float zf;
+          if constexpr (ZF16) {
+            zf = (float)__builtin_bit_cast(half_t, (uint16_t)field);
+          } else {
+            const uint32_t zbits = ((field + zbias) & zmask) | zor;
+            zf = (float)__builtin_bit_cast(half_t, (uint16_t)zbits) + zadd;
+          }
           const float sfc = (float)sc2[j][c / 2][c & 1];
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
@@ -368,13 +376,23 @@ inline size_t strip_dma_lds_bytes(int M, int nw, int cpl) {
   return ring > red ? ring : red;
 }
 
-template <int NW, int CPL, int SPG, int BITS, bool BF16, int MT>
-static int launch_strip_dma_t(const StripParams &p, int grid, hipStream_t stream) {
+template <int NW, int CPL, int SPG, int BITS, bool BF16, int MT, bool ZF16>
+static int launch_strip_dma_z(const StripParams &p, int grid, hipStream_t stream) {
   static DeviceLatch attr_done;
-  if (int rc = lds_optin(attr_done, (const void *)strip_dma_kernel<NW, CPL, SPG, BITS, BF16, MT>)) return rc;
-  hipLaunchKernelGGL((strip_dma_kernel<NW, CPL, SPG, BITS, BF16, MT>), dim3(grid), dim3(NW * 64), strip_dma_lds_bytes(p.M, NW, CPL), stream, p);
+  if (int rc = lds_optin(attr_done, (const void *)strip_dma_kernel<NW, CPL, SPG, BITS, BF16, MT, ZF16>)) return rc;
+  hipLaunchKernelGGL((strip_dma_kernel<NW, CPL, SPG, BITS, BF16, MT, ZF16>), dim3(grid), dim3(NW * 64), strip_dma_lds_bytes(p.M, NW, CPL), stream, p);
   QLLM_HIP_CHECK(hipGetLastError());
   return QLLM_OK;
+}
+
+template <int NW, int CPL, int SPG, int BITS, bool BF16, int MT>
+static int launch_strip_dma_t(const StripParams &p, int grid, hipStream_t stream) {
+  if constexpr (SPG == 2) {  // (the fp16-zero-point form is built for 64-wide groups, HQQ's default, where the group step weighs most)
+    bool all_f16 = true;
+    for (int i = 0; i < p.n_prob; ++i) all_f16 = all_f16 && p.prob[i].zero_kind == ZK_F16;
+    if (all_f16) return launch_strip_dma_z<NW, CPL, SPG, BITS, BF16, MT, true>(p, grid, stream);
+  }
+  return launch_strip_dma_z<NW, CPL, SPG, BITS, BF16, MT, false>(p, grid, stream);
 }
 
 }  // namespace qllm

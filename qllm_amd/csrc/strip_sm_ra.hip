@@ -1,7 +1,6 @@
 // Strip-major (native layout) instantiations for more than four rows: strip_dma.hpp for M = 5..32 (K a multiple of 64), and the
 // register-A forms of strip_kernel.hpp for what that kernel does not take (M = 33..64, other K, long-K g64 / 3-bit chunks at batch
 // 1..4, QLLM_RA_XD=0): 16-wave blocks of one 16-column strip, 8-wave blocks for 2 / 4 row tiles or 2 / 4 adjacent strips.
-#include "strip_dma.hpp"
 #include "strip_kernel.hpp"
 
 namespace qllm {
@@ -27,39 +26,8 @@ static int launch_sm_ra(const StripParams &p, int grid, size_t lds, hipStream_t 
                    : launch_strip_t<16, 1, 8, SPG, 1, 4, true, BF, 1, true>(p, grid, lds, stream);
 }
 
-// M = 5..32 with the activations staged through LDS by DMA (strip_dma.hpp; host planner: ra == 2): 16-wave blocks of one strip,
-// 8-wave blocks of 1 / 2 / 4 / 6 strips (3 bits: 1 / 2 / 4), 8-wave blocks of one strip and two row tiles
-template <int SPG, bool BF>
-static int launch_sm_dma(const StripParams &p, int grid, hipStream_t stream) {
-  if (p.M > 16) {
-    if (p.cpl != 1 || p.nw != 8) return set_error(QLLM_ERR_UNSUPPORTED, "internal: two row tiles take 8-wave blocks of one strip");
-    if (p.bits == 3) return launch_strip_dma_t<8, 1, SPG, 3, BF, 2>(p, grid, stream);
-    return launch_strip_dma_t<8, 1, SPG, 4, BF, 2>(p, grid, stream);
-  }
-  if (p.cpl == 1 && p.nw == 16) return p.bits == 3 ? launch_strip_dma_t<16, 1, SPG, 3, BF, 1>(p, grid, stream) : launch_strip_dma_t<16, 1, SPG, 4, BF, 1>(p, grid, stream);
-  if (p.nw != 8) return set_error(QLLM_ERR_UNSUPPORTED, "internal: blocks of several strips are 8 waves");
-  if (p.bits == 3) {
-    switch (p.cpl) {
-      case 1: return launch_strip_dma_t<8, 1, SPG, 3, BF, 1>(p, grid, stream);
-      case 2: return launch_strip_dma_t<8, 2, SPG, 3, BF, 1>(p, grid, stream);
-      case 4: return launch_strip_dma_t<8, 4, SPG, 3, BF, 1>(p, grid, stream);
-    }
-  } else {
-    switch (p.cpl) {
-      case 1: return launch_strip_dma_t<8, 1, SPG, 4, BF, 1>(p, grid, stream);
-      case 2: return launch_strip_dma_t<8, 2, SPG, 4, BF, 1>(p, grid, stream);
-      case 4: return launch_strip_dma_t<8, 4, SPG, 4, BF, 1>(p, grid, stream);
-      case 6: return launch_strip_dma_t<8, 6, SPG, 4, BF, 1>(p, grid, stream);
-    }
-  }
-  return set_error(QLLM_ERR_UNSUPPORTED, "internal: no %d-bit block of %d strips", p.bits, p.cpl);
-}
-
 int launch_strip_sm_ra(const StripParams &p, int grid, hipStream_t stream) {
-  if (p.ra == 2) {
-    if (p.group_size == 64) return p.act_bf16 ? launch_sm_dma<2, true>(p, grid, stream) : launch_sm_dma<2, false>(p, grid, stream);
-    return p.act_bf16 ? launch_sm_dma<4, true>(p, grid, stream) : launch_sm_dma<4, false>(p, grid, stream);
-  }
+  if (p.ra == 2) return p.group_size == 64 ? launch_strip_dma_g64(p, grid, stream) : launch_strip_dma_g128(p, grid, stream);
   const size_t lds = strip_lds_bytes(p.M, p.spw, p.nw, p.cpl, p.group_size, 1, 1);
   if (p.group_size == 64) return p.act_bf16 ? launch_sm_ra<2, true>(p, grid, lds, stream) : launch_sm_ra<2, false>(p, grid, lds, stream);
   return p.act_bf16 ? launch_sm_ra<4, true>(p, grid, lds, stream) : launch_sm_ra<4, false>(p, grid, lds, stream);
