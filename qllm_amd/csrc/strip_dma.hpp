@@ -40,9 +40,10 @@ namespace qllm {
 
 // NW: waves per block; CPL: adjacent 16-column strips per block (lane (g, i) holds column i of each); SPG: k-steps per group
 // (group_size / 32: 2 or 4); BITS: 4 or 3; BF16: bf16 activations (converted after the fragment read); MT: 16-row tiles (M <= 16 MT)
-// (six 4-bit / four 3-bit strips of 64-wide groups: a ring of three stages -- four need more than 256 registers)
-template <int CPL, int SPG, int BITS>
-constexpr int strip_dma_ring() { return (SPG == 2 && (CPL >= 6 || (BITS == 3 && CPL >= 4))) ? 3 : 4; }
+// (six 4-bit strips, or four 3-bit strips with packed zero points, of 64-wide groups: a ring of three stages -- four need more than
+//  256 registers)
+template <int CPL, int SPG, int BITS, bool ZF16>
+constexpr int strip_dma_ring() { return (SPG == 2 && (CPL >= 6 || (BITS == 3 && CPL >= 4 && !ZF16))) ? 3 : 4; }
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -57,7 +58,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 template <int NW, int CPL, int SPG, int BITS, bool BF16, int MT, bool ZF16 = false>
 __global__ __launch_bounds__(NW * 64, NW / 4) void strip_dma_kernel(const StripParams p) {
   static_assert(SPG == 2 || SPG == 4, "groups of 64 or 128");
-  constexpr int NS = strip_dma_ring<CPL, SPG, BITS>();  // ring slots (stages of two k-steps)
+  constexpr int NS = strip_dma_ring<CPL, SPG, BITS, ZF16>();  // ring slots (stages of two k-steps)
   static_assert(NS >= 2 && NS <= 4 && (2 * NS) % SPG == 0, "a round of the ring is whole groups");
   constexpr int NG = 2 * NS / SPG;         // groups per round of the ring
   constexpr int TN = 16 * CPL;             // columns per block
@@ -66,7 +67,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void strip_dma_kernel(const StripP
   typedef __attribute__((address_space(3))) void lds_void_t;
   // vector-memory operations of one stage request, in issue order: [the scale / zero words of the group that ENDS in this slot,]
   // the DMA pieces, the weight words.  (SPG = 2: every slot ends a group; SPG = 4: the odd ones.)
-  constexpr int LZ = CPL * (2 + (BITS == 3 ? 1 : 0));
+  constexpr bool Z2 = BITS == 3 && !ZF16;  // packed 3-bit zero points: the field may straddle into a second word
+  constexpr int LZ = CPL * (2 + (Z2 ? 1 : 0));
   constexpr int LX = 2 * MT + 2 * CPL * WL;
   constexpr int L_EVEN = LX + (SPG == 2 ? LZ : 0), L_ODD = LX + LZ;  // requests of an even / odd slot
   constexpr int L_ALL = (NS / 2) * (L_EVEN + L_ODD) + (NS % 2) * L_EVEN;
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void strip_dma_kernel(const StripP
   // ---- ring state: registers -----------------------------------------------------------------------------------------------
   uint32_t w[2 * NS][CPL], w_hi[BITS == 3 ? 2 * NS : 1][CPL];
   half2_t sc2[NG][(CPL + 1) / 2];  // scales, two strips per register
-  uint32_t zr[NG][CPL], zr2[BITS == 3 ? NG : 1][CPL];
+  uint32_t zr[NG][CPL], zr2[Z2 ? NG : 1][CPL];
   float4_t yacc[MT][CPL];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
@@ -199,7 +201,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void strip_dma_kernel(const StripP
         const int sg = g_strip[c] + G;
         sc2[j][c / 2][c & 1] = __builtin_bit_cast(half_t, __builtin_amdgcn_raw_buffer_load_b16(rs_s, lane_s, sg * 32, 2));
         zr[j][c] = __builtin_amdgcn_raw_buffer_load_b32(rs_z, lane_z, sg * z_group, 2);
-        if constexpr (BITS == 3) zr2[j][c] = __builtin_amdgcn_raw_buffer_load_b32(rs_z, lane_z2, sg * z_group, 2);
+        if constexpr (Z2) zr2[j][c] = __builtin_amdgcn_raw_buffer_load_b32(rs_z, lane_z2, sg * z_group, 2);
       }
     }
     const int so = 64 * kc;
@@ -279,7 +281,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void strip_dma_kernel(const StripP
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
           uint32_t field;
-          if constexpr (BITS == 3) field = (uint32_t)(((((uint64_t)zr2[j][c]) << 32) | zr[j][c]) >> zsh);
+          if constexpr (Z2) field = (uint32_t)(((((uint64_t)zr2[j][c]) << 32) | zr[j][c]) >> zsh);
           else field = zr[j][c] >> zsh;
           float zf;
           if constexpr (ZF16) {
