@@ -185,7 +185,12 @@ static bool strip_plan(const qllm_weight_t *w, int n, int M, StripPlan *plan) {
     // (profiles/r03_batch16.md).  One strip per block: 16 waves; several: 8 waves (registers).  The last block of a layer may be ragged.
     static int ra_xd = env_int("QLLM_RA_XD", 1);
     static int dma_cpl = env_int("QLLM_DMA_CPL", 0);
-    if (ra_xd && slab_nw == 0 && M >= 5 && M <= 32 && w[0].K % 64 == 0) {
+    // From which batch: 5 where the lds-slab form serves 2..4 rows well (4 bits, 128-wide groups); 2 for 64-wide groups (no slab
+    // form beyond one row: the register-A form took those, gate/up 24-25 us against 18 here) and for 3 bits (whose slab form
+    // stages eight chunks per lane at 2..4 rows: q/k/v 26.6, gate/up 49 us at M = 4).  Batch 1 never: the slab / register-A forms win.
+    static int dma_min_m = env_int("QLLM_DMA_MIN_M", 0);
+    const int dma_from = dma_min_m ? dma_min_m : ((bits == 3 || w[0].group_size == 64) ? 2 : 5);
+    if (ra_xd && M >= dma_from && M >= 2 && M <= 32 && w[0].K % 64 == 0) {
       const int cus = compute_units();
       static const int cands4[] = {1, 2, 4, 6}, cands3[] = {1, 2, 4};
       const int *cands = bits == 4 ? cands4 : cands3;

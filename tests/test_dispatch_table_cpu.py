@@ -153,7 +153,9 @@ def test_native_layout_decode_routes(lib):
     # g64 / 3 bits / fp16 zero points: slab form for short chunks at batch 1, register-A beyond (no spilling instantiation is built)
     h4, h3 = W(4096, 4096, 64, 4, NATIVE_F16Z), W(4096, 4096, 64, 3, NATIVE_F16Z)
     assert plan(lib, [h4], 1).startswith("strip nw=8 cpl=1 spw=16 form=lds-slab")
-    assert plan(lib, [h4], 2).startswith("strip nw=16 cpl=1 spw=8 form=register-A")
+    assert plan(lib, [h4], 2).startswith("strip nw=16 cpl=1 spw=8 form=dma-A")          # 64-wide groups, 3 bits: strip_dma from two rows
+    assert plan(lib, [h3], 4).startswith("strip nw=16 cpl=1 spw=8 form=dma-A")
+    assert plan(lib, [W(4096, 4096, layout=NATIVE)], 4).startswith("strip nw=8 cpl=1 spw=16 form=lds-slab")  # 4 bits g128: slab up to four
     assert plan(lib, [W(11008, 4096, 64, 4, NATIVE_F16Z)], 1).startswith("strip nw=16 cpl=1 spw=22 form=register-A")
     assert plan(lib, [h3], 1).startswith("strip nw=16 cpl=1 spw=8 form=lds-slab")
     assert plan(lib, [h3], 16).startswith("strip nw=16 cpl=1 spw=8 form=dma-A")
