@@ -136,7 +136,7 @@ int qllm_linear_forward_grouped(const qllm_weight_t *w, void *const *y, int32_t 
                                 void *stream);
 
 /* Diagnostics (process-global, not thread-safe; NULL switches it off): the next native-layout decode launches (4 bits, g128: the
- * batch 1..4 "lds-slab" form and the batch 5..32 "dma-A" form) each take one 192-byte slot of `buf` (device memory, n_slots x 24 x
+ * batch-1 "lds-slab" form and the batch 2..32 "dma-A" form) each take one 192-byte slot of `buf` (device memory, n_slots x 24 x
  * u64, in launch order) and record 100 MHz device timestamps of wave 0 of their first, middle and last block: [entry, loads issued
  * (dma-A: ring requested), x staged (dma-A: first stage landed), rounds done, after the block barrier, exit, -, -] x 3.  A launch
  * captured into a hipGraph keeps its slot.  tools/lab/cbench.cpp --timeline [--m 16]. */

@@ -181,15 +181,15 @@ static bool strip_plan(const qllm_weight_t *w, int n, int M, StripPlan *plan) {
     int nw = (M > 16 || cpl > 1) ? 8 : (slab_nw ? slab_nw : 16);
     // strip_dma.hpp (M = 5..32, K a multiple of 64): the activations go through LDS by DMA.  A block pulls the activations of its
     // k range through the CU's memory pipe once, a CU ingests ~55 GB/s here, so the launch costs about (rounds of blocks on the
-    // CUs) x (bytes one block pulls): blocks of cpl strips share one activation stream -- pick the cpl that minimises that product
+    // CUs) x (a block's fixed life + the bytes it pulls): blocks of cpl strips share one activation stream -- pick the cpl that minimises that product
     // (profiles/r03_batch16.md).  One strip per block: 16 waves; several: 8 waves (registers).  The last block of a layer may be ragged.
     static int ra_xd = env_int("QLLM_RA_XD", 1);
     static int dma_cpl = env_int("QLLM_DMA_CPL", 0);
-    // From which batch: 5 where the lds-slab form serves 2..4 rows well (4 bits, 128-wide groups); 2 for 64-wide groups (no slab
-    // form beyond one row: the register-A form took those, gate/up 24-25 us against 18 here) and for 3 bits (whose slab form
-    // stages eight chunks per lane at 2..4 rows: q/k/v 26.6, gate/up 49 us at M = 4).  Batch 1 never: the slab / register-A forms win.
-    static int dma_min_m = env_int("QLLM_DMA_MIN_M", 0);
-    const int dma_from = dma_min_m ? dma_min_m : ((bits == 3 || w[0].group_size == 64) ? 2 : 5);
+    // From batch 2: the lds-slab forms stage M x K / 8 chunks per block and run one-strip blocks in several rounds on wide launches
+    // (4 bits g128 at M = 4: q/k/v 14.3 -> 10.5 us, gate/up 24.7 -> 14.1; 64-wide groups had only the register-A form there: gate/up
+    // 25 -> 18; 3 bits: q/k/v 26.6 -> 13.5, gate/up 49 -> 24).  Batch 1 never: the one-round slab forms win (profiles/r03_batch16.md).
+    static int dma_min_m = env_int("QLLM_DMA_MIN_M", 2);
+    const int dma_from = dma_min_m < 2 ? 2 : dma_min_m;
     if (ra_xd && M >= dma_from && M >= 2 && M <= 32 && w[0].K % 64 == 0) {
       const int cus = compute_units();
       static const int cands4[] = {1, 2, 4, 6}, cands3[] = {1, 2, 4};
@@ -202,7 +202,8 @@ static bool strip_plan(const qllm_weight_t *w, int n, int M, StripPlan *plan) {
         const int c = cands[ci];
         int blocks = 0;
         for (int i = 0; i < n; ++i) blocks += (w[i].N / 16 + c - 1) / c;
-        const double cost = (double)((blocks + cus - 1) / cus) * (x_bytes + c * strip_bytes);
+        // (+ 96 KB per round: the ~1.8 us a block lives before and after its stream, at the CU's ingest rate)
+        const double cost = (double)((blocks + cus - 1) / cus) * (96.0 * 1024 + x_bytes + c * strip_bytes);
         if (ci == 0 || cost < best_cost * 0.97) { best = c; best_cost = cost; }  // (wider only for a clear gain)
         if (c == dma_cpl) { best = c; break; }                                    // (experiments: QLLM_DMA_CPL forces a width)
       }

@@ -1,4 +1,4 @@
-// Full-K strip kernel for small batches (M = 5..32) on the strip-major native layout: y[M, N] = x . dequant(W), no cross-block
+// Full-K strip kernel for small batches (M = 2..32) on the strip-major native layout: y[M, N] = x . dequant(W), no cross-block
 // reduction.  Same decomposition as strip_kernel.hpp (block = NW waves = CPL adjacent 16-column strips for ALL of K; wave w owns a
 // contiguous chunk of spw k-steps; raw biased fp16 B fragments, one fp32 scale / zero-point step per group; LDS reduction over the
 // waves at the end), rebuilt around how the operands reach the matrix core.  What the timeline stamps (tools/lab/cbench --m 16

@@ -1,4 +1,4 @@
-// Strip-major (native layout) instantiations for more than four rows: strip_dma.hpp for M = 5..32 (K a multiple of 64), and the
+// Strip-major (native layout) instantiations for more than four rows: strip_dma.hpp (own translation units) serves M = 2..32 (K a multiple of 64), and the
 // register-A forms of strip_kernel.hpp for what that kernel does not take (M = 33..64, other K, long-K g64 / 3-bit chunks at batch
 // 1..4, QLLM_RA_XD=0): 16-wave blocks of one 16-column strip, 8-wave blocks for 2 / 4 row tiles or 2 / 4 adjacent strips.
 #include "strip_kernel.hpp"

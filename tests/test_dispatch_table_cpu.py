@@ -128,9 +128,8 @@ def test_native_layout_decode_routes(lib):
     assert plan(lib, [attn] * 3, 1) == "strip nw=8 cpl=1 spw=16 form=lds-slab row_tiles=1" + sm
     assert plan(lib, [up] * 2, 1) == "strip nw=8 cpl=1 spw=16 form=lds-slab row_tiles=1" + sm
     assert plan(lib, [down], 1) == "strip nw=16 cpl=1 spw=24 form=lds-slab row_tiles=1" + sm
-    assert plan(lib, [attn], 4) == "strip nw=8 cpl=1 spw=16 form=lds-slab row_tiles=1" + sm
-    # M = 5..32: strip_dma.hpp (activations through LDS by DMA); one strip per 16-wave block while the strips fit one round of CUs
-    for m in (5, 16):
+    # M = 2..32: strip_dma.hpp (activations through LDS by DMA); one strip per 16-wave block while the strips fit one round of CUs
+    for m in (2, 4, 5, 16):
         assert plan(lib, [attn], m) == "strip nw=16 cpl=1 spw=8 form=dma-A row_tiles=1" + sm
         assert plan(lib, [down], m) == "strip nw=16 cpl=1 spw=24 form=dma-A row_tiles=1" + sm
     # ... wide (grouped) launches: blocks of several adjacent strips share one activation stream -- as many as make the launch ONE
@@ -148,14 +147,13 @@ def test_native_layout_decode_routes(lib):
     # shard shapes of Llama-2-70B (TP = 8): short K -> 4-wave blocks, K = 8192 -> 8 waves x one round of 32
     assert plan(lib, [W(1024, 8192, layout=NATIVE)], 1).startswith("strip nw=4 cpl=1 spw=8 form=lds-slab")
     assert plan(lib, [W(8192, 1024, layout=NATIVE)], 1).startswith("strip nw=8 cpl=1 spw=32 form=lds-slab")
-    assert plan(lib, [W(8192, 1024, layout=NATIVE)], 3).startswith("strip nw=16 cpl=1 spw=16 form=lds-slab")
+    assert plan(lib, [W(8192, 1024, layout=NATIVE)], 3).startswith("strip nw=16 cpl=1 spw=16 form=dma-A")
     assert plan(lib, [W(28672, 1024, layout=NATIVE)], 1).startswith("strip nw=16 cpl=1 spw=56 form=lds-slab")  # three rounds of 24
     # g64 / 3 bits / fp16 zero points: slab form for short chunks at batch 1, register-A beyond (no spilling instantiation is built)
     h4, h3 = W(4096, 4096, 64, 4, NATIVE_F16Z), W(4096, 4096, 64, 3, NATIVE_F16Z)
     assert plan(lib, [h4], 1).startswith("strip nw=8 cpl=1 spw=16 form=lds-slab")
     assert plan(lib, [h4], 2).startswith("strip nw=16 cpl=1 spw=8 form=dma-A")          # 64-wide groups, 3 bits: strip_dma from two rows
     assert plan(lib, [h3], 4).startswith("strip nw=16 cpl=1 spw=8 form=dma-A")
-    assert plan(lib, [W(4096, 4096, layout=NATIVE)], 4).startswith("strip nw=8 cpl=1 spw=16 form=lds-slab")  # 4 bits g128: slab up to four
     assert plan(lib, [W(11008, 4096, 64, 4, NATIVE_F16Z)], 1).startswith("strip nw=16 cpl=1 spw=22 form=register-A")
     assert plan(lib, [h3], 1).startswith("strip nw=16 cpl=1 spw=8 form=lds-slab")
     assert plan(lib, [h3], 16).startswith("strip nw=16 cpl=1 spw=8 form=dma-A")
