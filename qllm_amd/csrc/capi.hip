@@ -190,7 +190,9 @@ static bool strip_plan(const qllm_weight_t *w, int n, int M, StripPlan *plan) {
     // 25 -> 18; 3 bits: q/k/v 26.6 -> 13.5, gate/up 49 -> 24).  Batch 1 never: the one-round slab forms win (profiles/r03_batch16.md).
     static int dma_min_m = env_int("QLLM_DMA_MIN_M", 2);
     const int dma_from = dma_min_m < 2 ? 2 : dma_min_m;
-    if (ra_xd && M >= dma_from && M >= 2 && M <= 32 && w[0].K % 64 == 0) {
+    bool small_enough = true;  // (the kernel's byte offsets are 32-bit)
+    for (int i = 0; i < n; ++i) small_enough = small_enough && (double)w[i].K * w[i].N * bits / 8 < 2147483648.0;
+    if (ra_xd && small_enough && M >= dma_from && M >= 2 && M <= 32 && w[0].K % 64 == 0) {
       const int cus = compute_units();
       static const int cands4[] = {1, 2, 4, 6}, cands3[] = {1, 2, 4};
       const int *cands = bits == 4 ? cands4 : cands3;

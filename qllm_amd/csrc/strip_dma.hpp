@@ -38,10 +38,8 @@
 
 namespace qllm {
 
-// NW: waves per block; CPL: adjacent 16-column strips per block (lane (g, i) holds column i of each); SPG: k-steps per group
-// (group_size / 32: 2 or 4); BITS: 4 or 3; BF16: bf16 activations (converted after the fragment read); MT: 16-row tiles (M <= 16 MT)
-// (six 4-bit strips, or four 3-bit strips with packed zero points, of 64-wide groups: a ring of three stages -- four need more than
-//  256 registers)
+// Ring slots of an instantiation: four; three for six 4-bit strips, or four 3-bit strips with packed zero points, of 64-wide groups
+// (four slots need more than 256 registers there).
 template <int CPL, int SPG, int BITS, bool ZF16>
 constexpr int strip_dma_ring() { return (SPG == 2 && (CPL >= 6 || (BITS == 3 && CPL >= 4 && !ZF16))) ? 3 : 4; }
 
@@ -52,9 +50,12 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N < 63 ? N : 63) : "memory");
 }
 
+// NW: waves per block; CPL: adjacent 16-column strips per block (lane (g, i) holds column i of each); SPG: k-steps per group
+// (group_size / 32: 2 or 4); BITS: 4 or 3; BF16: bf16 activations (converted after the fragment read); MT: 16-row tiles (M <= 16 MT);
 // ZF16: every layer of the launch has fp16 zero points (HQQ: the native F16Z layout): the zero-point decode of a group is a shift and a
 //       conversion instead of the branch-free five-operation form that also serves packed and symmetric zeros (a sixth of the
 //       loop's VALU work at 64-wide groups).
+// All byte offsets are 32-bit: the host sends layers of 2 GB and more of packed words to the register-A form (strip_plan).
 template <int NW, int CPL, int SPG, int BITS, bool BF16, int MT, bool ZF16 = false>
 __global__ __launch_bounds__(NW * 64, NW / 4) void strip_dma_kernel(const StripParams p) {
   static_assert(SPG == 2 || SPG == 4, "groups of 64 or 128");
