@@ -141,6 +141,13 @@ def test_native_layout_decode_routes(lib):
     assert plan(lib, [W(4096, 4096, 64, 3, NATIVE_F16Z)] * 3, 16) == "strip nw=8 cpl=4 spw=16 form=dma-A row_tiles=1" + sm
     assert plan(lib, [W(4096, 11008, 64, 3, NATIVE_F16Z)] * 2, 16) == "strip nw=8 cpl=4 spw=16 form=dma-A row_tiles=1" + sm  # 3 bits: four at most
     assert plan(lib, [attn], 32) == "strip nw=8 cpl=1 spw=16 form=dma-A row_tiles=2" + sm
+    # Llama-2-70B shapes at batch 16: 512 strips -> 256 blocks of two; q/k/v (GQA) 640 strips -> 160 blocks of four; gate/up 3584
+    # strips -> six per block; the TP = 8 shards of q/k/v (80 strips) stay one strip per 16-wave block
+    assert plan(lib, [W(8192, 8192, layout=NATIVE)], 16) == "strip nw=8 cpl=2 spw=32 form=dma-A row_tiles=1" + sm
+    assert plan(lib, [W(8192, 8192, layout=NATIVE), W(8192, 1024, layout=NATIVE), W(8192, 1024, layout=NATIVE)], 16) == "strip nw=8 cpl=4 spw=32 form=dma-A row_tiles=1" + sm
+    assert plan(lib, [W(8192, 28672, layout=NATIVE)] * 2, 16) == "strip nw=8 cpl=6 spw=32 form=dma-A row_tiles=1" + sm
+    assert plan(lib, [W(28672, 8192, layout=NATIVE)], 16) == "strip nw=8 cpl=2 spw=112 form=dma-A row_tiles=1" + sm
+    assert plan(lib, [W(8192, 1024, layout=NATIVE), W(8192, 128, layout=NATIVE), W(8192, 128, layout=NATIVE)], 16) == "strip nw=16 cpl=1 spw=16 form=dma-A row_tiles=1" + sm
     assert plan(lib, [attn], 64) == "strip nw=8 cpl=1 spw=16 form=register-A row_tiles=4" + sm
     assert plan(lib, [up], 64) == "gemm2 tile=256x128 split_k=2" + sm      # 33..64 rows on the wide shapes: the tile GEMM
     assert plan(lib, [down], 33) == "gemm2 tile=256x128 split_k=8" + sm
