@@ -149,6 +149,8 @@ def test_native_layout_decode_routes(lib):
     assert plan(lib, [W(28672, 8192, layout=NATIVE)], 16) == "strip nw=8 cpl=2 spw=112 form=dma-A row_tiles=1" + sm
     assert plan(lib, [W(8192, 1024, layout=NATIVE), W(8192, 128, layout=NATIVE), W(8192, 128, layout=NATIVE)], 16) == "strip nw=16 cpl=1 spw=16 form=dma-A row_tiles=1" + sm
     assert plan(lib, [attn], 64) == "strip nw=8 cpl=1 spw=16 form=register-A row_tiles=4" + sm
+    # strip_dma's byte offsets are 32-bit: a layer of 2 GB of packed words stays on the register-A form (64-bit pointers)
+    assert "form=register-A" in plan(lib, [W(65536, 65536, layout=NATIVE)], 16) and "form=dma-A" in plan(lib, [W(65536, 32768, layout=NATIVE)], 16)
     assert plan(lib, [up], 64) == "gemm2 tile=256x128 split_k=2" + sm      # 33..64 rows on the wide shapes: the tile GEMM
     assert plan(lib, [down], 33) == "gemm2 tile=256x128 split_k=8" + sm
     # shard shapes of Llama-2-70B (TP = 8): short K -> 4-wave blocks, K = 8192 -> 8 waves x one round of 32
