@@ -23,11 +23,14 @@ int set_error(int code, const char *fmt, ...) {
 }
 void clear_error() { g_err[0] = 0; }
 
-// ---- tuning knobs (read once; for experiments, not part of the ABI) --------------------------------------------
+// ---- tuning knobs: compile-time constants in the release build, environment reads in the lab build (common.hpp) -------------
 static int env_int(const char *name, int dflt) {
   const char *v = getenv(name);
   return (v && *v) ? atoi(v) : dflt;
 }
+#ifdef QLLM_LAB
+int knob(const char *name, int dflt) { return env_int(name, dflt); }
+#endif
 // CUs of the current device (launch heuristics only); 256 (MI355X) when no device is reachable, so that the pure-host
 // planners (qllm_plan_describe, qllm_workspace_bytes) stay deterministic without a GPU.  QLLM_NUM_CU overrides.
 int compute_units() {
@@ -42,15 +45,15 @@ int compute_units() {
   return v;
 }
 static int skinny_target_waves() {
-  static int v = env_int("QLLM_SKINNY_WAVES", 2048);
+  const int v = knob("QLLM_SKINNY_WAVES", 2048);
   return v;
 }
 static int skinny_awq_w(int M) {
-  static int v = env_int("QLLM_SKINNY_AWQ_W", 1);
+  const int v = knob("QLLM_SKINNY_AWQ_W", 1);
   return (M <= 16 && v == 2) ? 2 : 1;
 }
 static int skinny_max_m() {
-  static int v = env_int("QLLM_SKINNY_MAX_M", 64);
+  const int v = knob("QLLM_SKINNY_MAX_M", 64);
   return v > 64 ? 64 : v;
 }
 
@@ -112,7 +115,7 @@ static bool skinny_ok(const qllm_weight_t &w, int M) {
 static int strip_min_strips() {
   // measured (profiles/r02_narrow_shapes.md): even 8-80 strips beat the split-K kernel's three dependent round trips
   // (K=8192, N=1024+128+128: 15.2 -> 9.8 us; K=4096, N=1024: 11.7 -> 4.8 us)
-  static int v = env_int("QLLM_STRIP_MIN", 8);
+  const int v = knob("QLLM_STRIP_MIN", 8);
   return v;
 }
 // full-K strip kernel: row-stream layouts, M <= 64 (17..64: several 16-row tiles per block), enough 16-column strips to
@@ -129,7 +132,7 @@ static bool strip_plan(const qllm_weight_t *w, int n, int M, StripPlan *plan) {
   // 11008x4096 50.1 -> 30.3; M=64: 33.8 -> 22.6, 52.5 -> 61.5, 48.1 -> 53.9 -- four row tiles only pay on the small shape
   // M = 33..64 (four row tiles), us per linear, split-K kernel -> strips (profiles/r02_mid_m.md): 4096x4096 26.8/31.4/33.5 ->
   // 17.6/19.8/22.6 at M = 33/48/64; on the 11008-wide shapes the strips lose at M >= 48 (43.9 -> 55.1, 41.2 -> 49.8): small shape only
-  static int max_m = env_int("QLLM_STRIP_MAX_M", 0);
+  const int max_m = knob("QLLM_STRIP_MAX_M", 0);
   const bool sm = is_native(w[0]);
   {
     int cols_all = 0;
@@ -162,10 +165,10 @@ static bool strip_plan(const qllm_weight_t *w, int n, int M, StripPlan *plan) {
   // fragment loads + two bookkeeping MFMAs per k-step (strip_kernel.hpp, RA)
   // measured (graph replay, us; slab -> RA): 4096x4096 M=4 5.3 -> 6.2, M=8 9.6 -> 7.1, M=16 9.9 -> 8.5; 4096x11008 M=4 9.8 -> 9.3,
   // M=8 10.0 -> 9.7, M=16 25.7 -> 11.9; 11008x4096 M=4 13.6 -> 13.0, M=8 20.2 -> 14.6, M=16 26.4 (split-K fallback) -> 18.9
-  static int ra_min = env_int("QLLM_STRIP_RA_MIN", 5);
+  const int ra_min = knob("QLLM_STRIP_RA_MIN", 5);
   // long K with 64-wide groups or 3 bits: the one-round slab variant (24 loads + 12 scale/zero pairs per lane) spills
   // 17-21 registers in a 16-wave block; the register-A variant (rounds of 8) does not
-  static int ra_longk = env_int("QLLM_STRIP_RA_LONGK", 1);
+  const int ra_longk = knob("QLLM_STRIP_RA_LONGK", 1);
   const bool longk = ra_longk && (w[0].group_size == 64 || bits == 3) && strip_spw(w[0].K, w[0].group_size, 16) > 8;
   const int ra_base = (M >= ra_min) ? 1 : 0;
   if (sm) {
@@ -175,7 +178,7 @@ static bool strip_plan(const qllm_weight_t *w, int n, int M, StripPlan *plan) {
     const int slab_nw = ra_base ? 0 : strip_sm_nw(w[0].K, M, w[0].group_size, bits);  // 0: no slab form for this shape
     // register-A form at M = 5..16, 4 bits, every layer a multiple of 64 wide and enough of them: blocks of four adjacent strips
     // (a register-A block re-reads all of x from L2; 64 columns share it instead of 16)
-    static int sm_ra_cpl4 = env_int("QLLM_SM_RA_CPL4", 1);
+    const int sm_ra_cpl4 = knob("QLLM_SM_RA_CPL4", 1);
     // (3 bits: two strips -- four need more than 256 registers)
     int cpl = (sm_ra_cpl4 && slab_nw == 0 && M >= 5 && M <= 16 && m64 && cols / 64 >= compute_units() / 2) ? (bits == 3 ? 2 : 4) : 1;
     int nw = (M > 16 || cpl > 1) ? 8 : (slab_nw ? slab_nw : 16);
@@ -183,12 +186,12 @@ static bool strip_plan(const qllm_weight_t *w, int n, int M, StripPlan *plan) {
     // k range through the CU's memory pipe once, a CU ingests ~55 GB/s here, so the launch costs about (rounds of blocks on the
     // CUs) x (a block's fixed life + the bytes it pulls): blocks of cpl strips share one activation stream -- pick the cpl that minimises that product
     // (profiles/r03_batch16.md).  One strip per block: 16 waves; several: 8 waves (registers).  The last block of a layer may be ragged.
-    static int ra_xd = env_int("QLLM_RA_XD", 1);
-    static int dma_cpl = env_int("QLLM_DMA_CPL", 0);
+    const int ra_xd = knob("QLLM_RA_XD", 1);
+    const int dma_cpl = knob("QLLM_DMA_CPL", 0);
     // From batch 2: the lds-slab forms stage M x K / 8 chunks per block and run one-strip blocks in several rounds on wide launches
     // (4 bits g128 at M = 4: q/k/v 14.3 -> 10.5 us, gate/up 24.7 -> 14.1; 64-wide groups had only the register-A form there: gate/up
     // 25 -> 18; 3 bits: q/k/v 26.6 -> 13.5, gate/up 49 -> 24).  Batch 1 never: the one-round slab forms win (profiles/r03_batch16.md).
-    static int dma_min_m = env_int("QLLM_DMA_MIN_M", 2);
+    const int dma_min_m = knob("QLLM_DMA_MIN_M", 2);
     const int dma_from = dma_min_m < 2 ? 2 : dma_min_m;
     bool small_enough = true;  // (the kernel's byte offsets are 32-bit)
     for (int i = 0; i < n; ++i) small_enough = small_enough && (double)w[i].K * w[i].N * bits / 8 < 2147483648.0;
@@ -240,7 +243,7 @@ static bool strip_plan(const qllm_weight_t *w, int n, int M, StripPlan *plan) {
     }
     return false;
   }
-  static int force_cpl_env = env_int("QLLM_STRIP_CPL", 0);
+  const int force_cpl_env = knob("QLLM_STRIP_CPL", 0);
   int force_cpl = force_cpl_env;
   const int cus = compute_units();
   int first = (bits == 3 || M > 16) ? 1 : strip_cpl(cols, m64, m32 && M <= 4, cus);
@@ -427,6 +430,9 @@ static void fill_gemm_params(GemmParams &p, const qllm_weight_t *w, const void *
   p.n_groups = (w->K + w->group_size - 1) / w->group_size;
   p.sm = is_native(*w) ? 1 : 0;
   p.split_k = 1;
+#ifdef QLLM_LAB
+  p.dbg = g_timeline;  // (lab: qllm_debug_timeline(buf, n) before a prefill call hands gemm4 its per-block stamp buffer)
+#endif
 }
 
 // the 256-row-tile GEMMs on a row-stream (or strip-major) 4-bit layer / AWQ layer: gemm3 from M = 1024 or when it can split K,

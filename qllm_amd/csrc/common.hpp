@@ -23,6 +23,15 @@ constexpr int kNumCU = 256;  // MI355X: the fallback of compute_units() when no 
 // overrides; kNumCU without a device, so that qllm_plan_describe / qllm_workspace_bytes stay deterministic in CPU-only tests.
 int compute_units();
 
+// Tuning knobs of the dispatchers.  Release build: compile-time constants -- the library reads NO environment variable except
+// QLLM_NUM_CU (capi.hip).  Lab build (`make -C qllm_amd/csrc variant NAME=lab DEFS=-DQLLM_LAB` -> tools/lab/libqllm_lab.so, loaded
+// with QLLM_MI355X_LIB): QLLM_<NAME> is read from the environment at EVERY call, so one process can A/B variants back to back.
+#ifdef QLLM_LAB
+int knob(const char *name, int dflt);  // capi.hip
+#else
+constexpr int knob(const char *, int dflt) { return dflt; }
+#endif
+
 // zero-point representation, decided on the host from (layout, qzeros)
 enum ZeroKind : int { ZK_PACKED = 0, ZK_F16 = 1, ZK_SYM = 2 };
 

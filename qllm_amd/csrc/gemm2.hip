@@ -399,14 +399,13 @@ __global__ __launch_bounds__(512) void gemm2_kernel(const GemmParams p) {
 }
 
 bool gemm2_ok(const GemmParams &p, int layout) {
-  static const char *e = getenv("QLLM_GEMM2");
-  if (e && e[0] == '0') return false;
+  if (!knob("QLLM_GEMM2", 1)) return false;
   // below 192 rows a 256-row tile wastes > 25 % of its MFMAs -- but with split-K the k-loop length, not the MFMA count, sets
   // the time at these sizes.  Measured (us per linear, 128x128 kernel -> this one; profiles/r02_mid_m.md): M = 96..160 on
   // 4096x4096 100 -> 27.5, 4096x11008 103 -> 40, 11008x4096 258 -> 41.
   // 33..64 rows (round 3, profiles/r03_mid_m.md): on the 11008-wide Llama shapes this kernel (40 us) beats both the four-row-tile
   // strips (42-59 us) and the split-K decode kernel (48-53 us); the dispatcher sends it only what the strips do not take
-  static const int min_m = getenv("QLLM_GEMM2_MIN_M") ? atoi(getenv("QLLM_GEMM2_MIN_M")) : 33;
+  const int min_m = knob("QLLM_GEMM2_MIN_M", 33);
   if (p.g_idx || p.K % 64 != 0 || p.N % 128 != 0 || p.M < min_m) return false;
   return p.group_size % 32 == 0 && p.gs_shift >= 0;  // one group per thread per k-tile; power-of-two group size
 }
@@ -432,8 +431,7 @@ static int launch_gemm2_t(const GemmParams &p, hipStream_t stream) {
 // (tiles * S <= CUs) and leaves every block >= 8 k-tiles; 1 otherwise.  A block's k-loop runs ~0.9 us per k-tile whatever the
 // occupancy, so M <= 1024 on 4096-wide layers is bound by the loop length, not by throughput.
 int gemm2_split_k(int M, int N, int K) {
-  static const char *e = getenv("QLLM_GEMM2_SPLITK");
-  if (e && e[0] == '0') return 1;
+  if (!knob("QLLM_GEMM2_SPLITK", 1)) return 1;
   if (N % 128 != 0) return 1;
   const int tiles = ((M + 255) / 256) * (N / 128), kt = K / 64;
   int s = 1;
@@ -444,7 +442,7 @@ size_t gemm2_slab_bytes(int M, int N, int S) { return S > 1 ? (size_t)((M + 255)
 
 // 256x256 tiles when they fill the chip well; else 256x128 (twice the blocks)
 int gemm2_tile_n(int M, int N, int split_k) {
-  static int force_bn = getenv("QLLM_GEMM2_BN") ? atoi(getenv("QLLM_GEMM2_BN")) : 0;
+  const int force_bn = knob("QLLM_GEMM2_BN", 0);
   if (split_k > 1) return 128;  // the slab layout is the 256x128 tile's
   const int tiles256 = ((M + 255) / 256) * (N / 256);
   const int rounds = (tiles256 + compute_units() - 1) / compute_units();
@@ -455,9 +453,9 @@ int gemm2_tile_n(int M, int N, int split_k) {
 int launch_gemm2(const GemmParams &p_in, int layout, hipStream_t stream) {
   GemmParams p = p_in;
   if (p.split_k < 1) p.split_k = 1;
-  static int raster = getenv("QLLM_GEMM2_RASTER") ? atoi(getenv("QLLM_GEMM2_RASTER")) : 1;  // measured +2-3 %
+  const int raster = knob("QLLM_GEMM2_RASTER", 1);  // measured +2-3 %
   p.raster = raster;
-  static int stagger = getenv("QLLM_GEMM2_STAGGER") ? atoi(getenv("QLLM_GEMM2_STAGGER")) : 0;  // measured: 771 vs 808 TFLOP/s with it on
+  const int stagger = knob("QLLM_GEMM2_STAGGER", 0);  // measured: 771 vs 808 TFLOP/s with it on
   p.stagger = stagger;
   const int bn = gemm2_tile_n(p.M, p.N, p.split_k);
   if (layout == QLLM_LAYOUT_AWQ_GEMM) return bn == 256 ? launch_gemm2_t<1, 256>(p, stream) : launch_gemm2_t<1, 128>(p, stream);

@@ -404,14 +404,14 @@ __global__ __launch_bounds__((MW + 4) * 64) void gemm3_kernel(const GemmParams p
 }
 
 bool gemm3_ok(const GemmParams &p, int layout) {
-  static const int on = getenv("QLLM_GEMM3") ? atoi(getenv("QLLM_GEMM3")) : 1;
+  const int on = knob("QLLM_GEMM3", 1);
   // 4 bits: from M = 1024 (below it gemm2's split-K form was the measured choice; QLLM_GEMM3_MIN_M moves the line);
   // 3 bits: every prefill size -- the alternative there is the dequant kernel + a dense GEMM
   // round 3 (profiles/r03_mid_m.md, tools/lab/gbench): with split-K this kernel passes gemm2 from M = 384 on the 11008-wide shapes
   // (59 vs 64 us at M = 384 / 512, 110 vs 130 and 89 vs 93 at 768) and from 768 on 4096 x 4096 (41 vs 43; 34.5 vs 33 below)
-  static const int min_m_env = getenv("QLLM_GEMM3_MIN_M") ? atoi(getenv("QLLM_GEMM3_MIN_M")) : 0;
+  const int min_m_env = knob("QLLM_GEMM3_MIN_M", 0);
   const int min_m = min_m_env ? min_m_env : (((size_t)p.K * p.N > (size_t)4096 * 4096) ? 384 : 768);
-  static const int min_m3 = getenv("QLLM_GEMM3_MIN_M_3BIT") ? atoi(getenv("QLLM_GEMM3_MIN_M_3BIT")) : 33;  // (33..64: native-layout layers whose strips stop at two row tiles)
+  const int min_m3 = knob("QLLM_GEMM3_MIN_M_3BIT", 33);  // (33..64: native-layout layers whose strips stop at two row tiles)
   if (!on || p.g_idx || p.K % 64 != 0 || p.N % 128 != 0) return false;
   if (p.M < (layout == kGemm3Rows3Bit ? min_m3 : min_m)) return false;
   // fp16 activations only: the activation tile goes to LDS by DMA, which cannot convert bf16 on the way (callers convert x with
@@ -455,10 +455,13 @@ int gemm3_split_k(int M, int N, int K) {
 int launch_gemm3(const GemmParams &p_in, int layout, hipStream_t stream) {
   GemmParams p = p_in;
   if (p.split_k < 1 || !p.slabs || !p.counters) p.split_k = 1;
-  static int raster = getenv("QLLM_GEMM2_RASTER") ? atoi(getenv("QLLM_GEMM2_RASTER")) : 1;
+  const int raster = knob("QLLM_GEMM2_RASTER", 1);
   p.raster = raster;
-  static int mw = getenv("QLLM_GEMM3_MW") ? atoi(getenv("QLLM_GEMM3_MW")) : 8;  // measured (profiles/r02_prefill_summary.md): 8 matrix waves 908 / 923 / 1004 TFLOP/s, 4: 873 / 915 / 1003
-  static int prio = getenv("QLLM_GEMM3_PRIO") ? atoi(getenv("QLLM_GEMM3_PRIO")) : 1;
+#ifdef QLLM_LAB
+  if (const int g4 = knob("QLLM_GEMM4", -1); g4 >= 0) return launch_gemm4(p, layout, g4, stream);  // (lab) gemm4.hip variants
+#endif
+  const int mw = knob("QLLM_GEMM3_MW", 8);  // measured (profiles/r02_prefill_summary.md): 8 matrix waves 908 / 923 / 1004 TFLOP/s, 4: 873 / 915 / 1003
+  const int prio = knob("QLLM_GEMM3_PRIO", 1);
   if (layout == kGemm3Rows3Bit) return launch_gemm3_b<2, 8>(p, stream);
   if (mw == 4 && !prio) return layout == QLLM_LAYOUT_AWQ_GEMM ? launch_gemm3_b<1, 4, false>(p, stream) : launch_gemm3_b<0, 4, false>(p, stream);
   if (mw == 8) return layout == QLLM_LAYOUT_AWQ_GEMM ? launch_gemm3_b<1, 8>(p, stream) : launch_gemm3_b<0, 8>(p, stream);

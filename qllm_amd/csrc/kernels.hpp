@@ -123,6 +123,8 @@ struct GemmParams {
   int split_k;      // gemm2: blocks per output tile along K (1 = none)
   float *slabs;     // gemm2 split-K: [tiles][split_k][256 x 128] fp32 partial tiles
   int *counters;    // gemm2 split-K: one arrival counter per output tile (zero before and after the launch)
+  int prio;         // gemm4: s_setprio values of its wave roles (matrix | dequant << 4 | loader << 8)
+  uint64_t *dbg;    // lab builds (-DQLLM_LAB): gemm4 timeline, 16 x u64 per block (tools/lab/g4lab timeline); NULL otherwise
 };
 int launch_gemm(const GemmParams &p, int layout, hipStream_t stream);
 
@@ -139,5 +141,8 @@ bool gemm3_ok(const GemmParams &p, int layout);
 int gemm3_split_k(int M, int N, int K);
 int launch_gemm3(const GemmParams &p, int layout, hipStream_t stream);
 int launch_bf16_to_f16(const void *src, void *dst, size_t n, hipStream_t stream);  // elementwise RNE conversion (gemm3's bf16 pre-pass)
+
+// ---- gemm4.hip (256x128 tile, matrix waves + all-DMA producer waves; same contract as gemm3) ----------------------------------
+int launch_gemm4(const GemmParams &p, int layout, int variant, hipStream_t stream);
 
 }  // namespace qllm

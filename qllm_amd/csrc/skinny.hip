@@ -374,7 +374,7 @@ int launch_skinny(const SkinnyParams &p, int layout, int awq_w, int grid, hipStr
   int spw = 0;
   for (int i = 0; i < p.n_prob; ++i) spw = p.prob[i].spw > spw ? p.prob[i].spw : spw;
   const size_t x_bytes = (size_t)p.M * (4 * spw * 32 + 8) * sizeof(half_t);
-  static const bool no_xlds = getenv("QLLM_SKINNY_XLDS") && getenv("QLLM_SKINNY_XLDS")[0] == '0';
+  const bool no_xlds = !knob("QLLM_SKINNY_XLDS", 1);
   const bool xlds = !no_xlds && red_bytes + x_bytes <= 144 * 1024;
   const size_t lds = red_bytes + (xlds ? x_bytes : 0);
   if (layout == QLLM_LAYOUT_AWQ_GEMM) {

@@ -14,7 +14,7 @@ namespace qllm {
 
 // waves per block of the lds-slab form, or 0: use the register-A form (host planner, capi.hip)
 int strip_sm_nw(int K, int M, int group_size, int bits) {
-  static const int nw4 = getenv("QLLM_SM_NW4") ? atoi(getenv("QLLM_SM_NW4")) : 0;
+  const int nw4 = knob("QLLM_SM_NW4", 0);
   const int T = K / 32;
   if (bits == 3) return T <= 128 ? 16 : 0;            // 16 waves x one round of 8 (longer chunks: register-A)
   if (group_size == 64) {                             // twice the scale / zero registers per round: short rounds, batch 1 only
