@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define QLLM_ABI_VERSION 3
+#define QLLM_ABI_VERSION 4
 
 typedef enum qllm_status {
   QLLM_OK = 0,
@@ -114,6 +114,9 @@ int qllm_device_info(int device, qllm_device_info_t *out);
  * arrival counters).  The region must be zero-filled once (qllm_workspace_init) before first use; the kernels
  * leave it clean.  One workspace may be shared by calls that are ordered on one stream. */
 size_t qllm_workspace_bytes(const qllm_weight_t *w, int32_t M);
+/* The same for a known activation dtype: only bf16 calls of the 256x128 prefill kernel need the fp16 staging copy of x
+ * (M * K * 2 bytes) that qllm_workspace_bytes() has to assume.  (ABI 4) */
+size_t qllm_workspace_bytes_act(const qllm_weight_t *w, int32_t M, int32_t act_dtype);
 int qllm_workspace_init(void *workspace, size_t bytes, void *stream);
 
 /* ---- the hot path -------------------------------------------------------------------------------------- */
@@ -200,8 +203,8 @@ int qllm_plan_describe(const qllm_weight_t *w, int32_t n_weights, int32_t M, int
  *     bias f16 [N] (natural order); g_idx must be NULL (act-order layers: sort the rows by group first, qllm_gather_columns)
  * Shapes: bits 3 or 4, K % 32 == 0, N % 16 == 0 (3-bit packed zero points: N % 32 == 0), group_size % 32 == 0, K % group_size == 0.
  * A descriptor with layout = QLLM_LAYOUT_NATIVE[_F16Z] is accepted by qllm_linear_forward / _grouped (M <= 64 with group size
- * 64 / 128; larger M: see qllm_plan_describe) and by qllm_dequant.  Pure integer permutations: repack then unpack is the
- * identity.  Counterpart in the reference: the load-time repacks of its own kernel formats (quant_linear_awq.py:95-140). */
+ * 64 / 128; larger M: see qllm_plan_describe); qllm_dequant reads the reference layouts only (QLLM_ERR_UNSUPPORTED: convert
+ * back with qllm_unpack_native first).  Pure integer permutations: repack then unpack is the identity.  Counterpart in the reference: the load-time repacks of its own kernel formats (quant_linear_awq.py:95-140). */
 int qllm_native_sizes(const qllm_weight_t *src, size_t *qweight_bytes, size_t *scales_bytes, size_t *qzeros_bytes);
 int qllm_repack_native(const qllm_weight_t *src, void *qweight_out, void *scales_out, void *qzeros_out, void *stream);
 /* dst_layout: QLLM_LAYOUT_GPTQ / _AWQ_GEMM (from NATIVE) or QLLM_LAYOUT_HQQ (from NATIVE_F16Z); outputs are the reference's buffers */

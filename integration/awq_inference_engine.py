@@ -30,6 +30,7 @@ class _Weight(ctypes.Structure):  # qllm_weight_t
 
 
 _GPTQ, _AWQ, _NATIVE = 0, 1, 3
+_UNSUPPORTED = 2  # QLLM_ERR_UNSUPPORTED
 _lib.qllm_awq_gemm_forward.argtypes = [_vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _sz, _vp]
 _lib.qllm_awq_gemm_forward.restype = ctypes.c_int
 _lib.qllm_linear_forward.argtypes = [ctypes.POINTER(_Weight), _vp, _vp, _i32, _i32, _vp, _sz, _vp]
@@ -92,14 +93,17 @@ def gemm_forward_cuda(x, qweight, scales, qzeros, split_k_iters):
     with torch.cuda.device(x.device):
         stream = torch.cuda.current_stream().cuda_stream
         g = K // scales.shape[0] if scales.shape[0] and K % scales.shape[0] == 0 else 0
-        if (0 < M <= _DECODE_MAX_M and g > 0 and K % 32 == 0 and N % 16 == 0 and qweight.shape[0] == K and scales.dtype == torch.float16
-                and os.environ.get("QLLM_AWQ_DECODE_SHADOW", "1") != "0"):
-            w = _native_copy(qweight, scales, s16, qzeros.contiguous(), K, N, g, stream)
+        # the native copy only where the strip kernels take it (group sizes 64 / 128); the caller's own qzeros tensor is the cache
+        # key, so a non-contiguous one (its .contiguous() would be a fresh temporary per call) stays on the in-place path
+        if (0 < M <= _DECODE_MAX_M and g in (64, 128) and K % 32 == 0 and N % 16 == 0 and qweight.shape[0] == K
+                and scales.dtype == torch.float16 and qzeros.is_contiguous() and os.environ.get("QLLM_AWQ_DECODE_SHADOW", "1") != "0"):
+            w = _native_copy(qweight, scales, s16, qzeros, K, N, g, stream)
         else:
             w = None
+        rc = _UNSUPPORTED
         if w is not None:
             rc = _lib.qllm_linear_forward(ctypes.byref(w), xc.data_ptr(), y.data_ptr(), M, act, ws.data_ptr(), ws.numel(), stream)
-        else:
+        if rc == _UNSUPPORTED:  # no native copy, or a (shape, M) the native kernels do not serve: the caller's buffers in place
             rc = _lib.qllm_awq_gemm_forward(xc.data_ptr(), qweight.data_ptr(), s16.data_ptr(), qzeros.data_ptr(), split_k_iters, y.data_ptr(),
                                             M, K, N, K // scales.shape[0], act, ws.data_ptr(), ws.numel(), stream)
     _check(rc)

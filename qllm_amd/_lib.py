@@ -16,10 +16,10 @@ LIB_PATH = os.environ.get("QLLM_MI355X_LIB") or os.path.join(_HERE, LIB_NAME)  #
 QLLM_OK, QLLM_ERR_INVALID, QLLM_ERR_UNSUPPORTED, QLLM_ERR_WORKSPACE, QLLM_ERR_LAUNCH, QLLM_ERR_DEVICE = range(6)
 LAYOUT_GPTQ, LAYOUT_AWQ_GEMM, LAYOUT_HQQ, LAYOUT_NATIVE, LAYOUT_NATIVE_F16Z = 0, 1, 2, 3, 4
 DT_F16, DT_BF16 = 0, 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 EXPORTS = (
-    "qllm_abi_version", "qllm_last_error", "qllm_device_info", "qllm_workspace_bytes", "qllm_workspace_init",
+    "qllm_abi_version", "qllm_last_error", "qllm_device_info", "qllm_workspace_bytes", "qllm_workspace_bytes_act", "qllm_workspace_init",
     "qllm_linear_forward", "qllm_linear_forward_grouped", "qllm_dequant", "qllm_ort_gemv", "qllm_ort_dequant",
     "qllm_awq_gemm_forward", "qllm_unpack_qweight", "qllm_pack_qweight", "qllm_gather_columns", "qllm_ort_dequantize4bits",
     "qllm_plan_describe", "qllm_debug_timeline", "qllm_native_sizes", "qllm_repack_native", "qllm_unpack_native",
@@ -68,6 +68,8 @@ def _declare(lib):
     lib.qllm_device_info.argtypes = [C.c_int, C.POINTER(QllmDeviceInfo)]
     lib.qllm_workspace_bytes.restype = sz
     lib.qllm_workspace_bytes.argtypes = [wp, i32]
+    lib.qllm_workspace_bytes_act.restype = sz
+    lib.qllm_workspace_bytes_act.argtypes = [wp, i32, i32]
     lib.qllm_workspace_init.restype = C.c_int
     lib.qllm_workspace_init.argtypes = [vp, sz, vp]
     lib.qllm_linear_forward.restype = C.c_int

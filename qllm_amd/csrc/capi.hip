@@ -92,6 +92,7 @@ static int validate_weight(const qllm_weight_t *w) {
     if (w->g_idx) return set_error(QLLM_ERR_INVALID, "AWQ GEMM layout has no act-order (g_idx must be NULL)");
   } else if (is_native(*w)) {
     if (int rc = native_shape_ok(w->bits, w->K, w->N, w->group_size, w->layout == QLLM_LAYOUT_NATIVE && w->qzeros)) return rc;
+    if (w->K % w->group_size != 0) return set_error(QLLM_ERR_INVALID, "the native layout holds whole groups (K=%d g=%d)", w->K, w->group_size);
     if (w->g_idx) return set_error(QLLM_ERR_INVALID, "the native layout has no act-order (g_idx must be NULL: sort the rows by group first)");
     if (w->layout == QLLM_LAYOUT_NATIVE_F16Z && !w->qzeros) return set_error(QLLM_ERR_INVALID, "NATIVE_F16Z layout needs fp16 qzeros");
   } else {
@@ -530,15 +531,17 @@ int qllm_device_info(int device, qllm_device_info_t *out) {
   return QLLM_OK;
 }
 
-size_t qllm_workspace_bytes(const qllm_weight_t *w, int32_t M) {
+size_t qllm_workspace_bytes(const qllm_weight_t *w, int32_t M) { return qllm_workspace_bytes_act(w, M, QLLM_BF16); }
+
+size_t qllm_workspace_bytes_act(const qllm_weight_t *w, int32_t M, int32_t act_dtype) {
   if (!w || M <= 0) return kCounterBytes;
   size_t tiles = 0;
   if (M > 32) {  // the 256-row-tile GEMMs (every M > 64, and 33..64 rows of the shapes the strips leave alone): fp32 partial
     GemmParams p;  // tiles of the split-K forms + the fp16 copy of bf16 activations where the wave-specialised kernel would
-    fill_gemm_params(p, w, nullptr, nullptr, M, QLLM_F16);  // serve the call (the caller's activation dtype is not known here)
+    fill_gemm_params(p, w, nullptr, nullptr, M, QLLM_F16);  // serve a bf16 call
     p.g_idx = nullptr;
     const bool g3 = gemm3_ok(p, w->bits == 3 ? kGemm3Rows3Bit : (w->layout == QLLM_LAYOUT_AWQ_GEMM ? QLLM_LAYOUT_AWQ_GEMM : QLLM_LAYOUT_GPTQ));
-    tiles = align_up(gemm2_slab_bytes(M, w->N, gemm2_split_k(M, w->N, w->K)), 256) + (g3 ? bf16_copy_bytes(M, w->K, 1) : 0);
+    tiles = align_up(gemm2_slab_bytes(M, w->N, gemm2_split_k(M, w->N, w->K)), 256) + (g3 ? bf16_copy_bytes(M, w->K, act_dtype == QLLM_BF16) : 0);
     if (M > 64) return kCounterBytes + tiles;
   }
   const size_t slabs = align_up((size_t)skinny_max_split(M) * M * w->N * sizeof(float), 256);

@@ -135,6 +135,8 @@ class HipForwardMixin:
             if t is None or not t.is_cuda:
                 return
             rel[name] = (tuple(t.shape), t.dtype)
+        if not rel:   # nothing to release (QuantLinearORT keeps its blob): stay keyed on the buffers
+            return
         self._desc = self._desc_key = self._desc_keep = None   # they point into the buffers that go away
         for name in rel:
             setattr(self, name, torch.empty(0, dtype=rel[name][1], device=self.qweight.device))
@@ -182,6 +184,9 @@ class HipForwardMixin:
         tensor-parallel wrappers, whose shard kernels write straight into their slice of the gathered output).  Layers without a
         plain fused path for the call (act-order, unsupported shapes) compute normally and copy."""
         x2d = x.reshape(-1, x.shape[-1])
+        resolve = getattr(self, "_resolve_act_order", None)   # (GPTQ detects act-order lazily: do it before branching on it)
+        if resolve is not None:
+            resolve()
         if getattr(self, "act_order", None) or not x2d.is_contiguous() or not out.is_contiguous():
             out.copy_(self(x).reshape(out.shape))
             return out

@@ -98,15 +98,23 @@ class QuantLinearGPTQ(nn.Module, CompressWeight, HipForwardMixin):
     # sorting the rows by group (perm = argsort(g_idx)) gives a plain contiguous-group layer: the native copy of an act-order
     # layer is built from that row-permuted arrangement of its own integers (library unpack / pack kernels; bit-exact; the
     # row-stream intermediate is dropped) and the forward feeds it x[..., perm] (qllm_gather_columns).  The fused kernels then
-    # run at their no-act-order speed plus one gather of x.  Groups that are not uniform, or QLLM_ACTORDER_SHADOW=0: no native
+    # run at their no-act-order speed plus one gather of x (3- and 4-bit layers).  Groups that are not uniform, or QLLM_ACTORDER_SHADOW=0: no native
     # copy -> the in-place gather kernel on the reference buffers.
     _perm = None
 
+    def _resolve_act_order(self) -> bool:
+        """Lazy act-order detection, as the reference: a trivial g_idx has its first `groupsize` entries all zero
+        (quant_linear_gptq.py:137-138).  Called by every path that branches on `act_order` (forward, forward_into, the native copy)."""
+        if self.act_order is None:
+            self.act_order = bool(self.g_idx[: self.groupsize].sum() != 0)
+        return self.act_order
+
     def _native_source(self):
-        if not self.act_order:
+        if not self._resolve_act_order():
             return HipForwardMixin._native_source(self)
         self._perm = None
-        if os.environ.get("QLLM_ACTORDER_SHADOW", "1") == "0" or self.bits != 4 or not self.qweight.is_cuda:
+        bits = self.bits
+        if os.environ.get("QLLM_ACTORDER_SHADOW", "1") == "0" or bits not in (3, 4) or not self.qweight.is_cuda:
             return None
         from ... import ops
         dev = self.qweight.device
@@ -116,28 +124,26 @@ class QuantLinearGPTQ(nn.Module, CompressWeight, HipForwardMixin):
         if self.infeatures % self.groupsize != 0 or counts.numel() != groups or not bool((counts == self.groupsize).all()):
             return None
         perm = torch.argsort(g, stable=True)
-        q = ops.unpack_qweight(self.qweight.contiguous(), "GPTQ", 4, self.infeatures, self.outfeatures)
-        qw = ops.pack_qweight(q.index_select(0, perm).contiguous(), "GPTQ", 4)
+        q = ops.unpack_qweight(self.qweight.contiguous(), "GPTQ", bits, self.infeatures, self.outfeatures)
+        qw = ops.pack_qweight(q.index_select(0, perm).contiguous(), "GPTQ", bits)
         del q
         b = self._f16(self.bias).contiguous() if self.bias is not None else None
         self._perm = _intern_perm(perm.to(torch.int32).contiguous())
         return ops.make_weight("GPTQ", qw, self._f16(self.scales).contiguous(), self.qzeros.contiguous(), None, b,
-                               self.infeatures, self.outfeatures, self.groupsize, 4, 0)
+                               self.infeatures, self.outfeatures, self.groupsize, bits, 0)
 
     def _regenerate_reference(self):
         qweight, scales, qzeros = HipForwardMixin._regenerate_reference(self)
         if self.act_order and self._perm is not None:   # the native rows are sorted by group: undo the permutation
             from ... import ops
-            q = ops.unpack_qweight(qweight, "GPTQ", 4, self.infeatures, self.outfeatures)
+            q = ops.unpack_qweight(qweight, "GPTQ", self.bits, self.infeatures, self.outfeatures)
             inv = torch.empty_like(self._perm, dtype=torch.long)
             inv[self._perm.long()] = torch.arange(self._perm.numel(), device=inv.device)
-            qweight = ops.pack_qweight(q.index_select(0, inv).contiguous(), "GPTQ", 4)
+            qweight = ops.pack_qweight(q.index_select(0, inv).contiguous(), "GPTQ", self.bits)
         return qweight, scales, qzeros
 
     def forward(self, x):
-        if self.act_order is None:
-            # lazy detect, as the reference: trivial g_idx => first `groupsize` entries are all zero (:137-138)
-            self.act_order = bool(self.g_idx[: self.groupsize].sum() != 0)
+        self._resolve_act_order()
         # COMPATIBLE_WITH_AUTOGPTQ is read per forward by the reference (:75); it becomes add_zero_bias here
         azb = autogptq_compat()
         if self.act_order and x.is_cuda:

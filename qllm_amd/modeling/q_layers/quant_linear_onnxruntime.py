@@ -158,7 +158,7 @@ class QuantLinearORT(nn.Module, CompressWeight, HipForwardMixin):
     def _descriptor(self, act_order_g_idx=None, add_zero_bias: int = 0):
         from ... import ops
         key = (_tkey(self.qweight), _tkey(self.scales), _tkey(self.qzeros), _tkey(self.g_idx), _tkey(self.bias))
-        if (self._desc is None and self._desc_key is None) or key != self._desc_key:
+        if self._desc is None or key != self._desc_key:   # (False = cached verdict "irregular act-order": not rebuilt)
             if self.bits != 4:
                 raise NotImplementedError("the ORT blob layout is 4-bit only")
             n, k, g = self.outfeatures, self.infeatures, self.groupsize
@@ -193,9 +193,11 @@ class QuantLinearORT(nn.Module, CompressWeight, HipForwardMixin):
         return self._desc, self._desc_keep
 
     def native_descriptor(self, add_zero_bias: int = 0):
+        """The native copy is cached on the buffers' identity / version (HipForwardMixin); the transposed row-stream view was
+        only its source and is dropped once the copy exists (one derived copy, not two).  `_perm` / `act_order` stay."""
         w = HipForwardMixin.native_descriptor(self, 0)
-        if w is not None:   # the transposed view was only the source of the native copy: one derived copy, not two
-            self._desc = self._desc_keep = self._desc_key = None
+        if w is not None:
+            self._desc = self._desc_keep = None
         return w
 
     def materialize_reference(self):
@@ -206,7 +208,9 @@ class QuantLinearORT(nn.Module, CompressWeight, HipForwardMixin):
         return w if w is not None else self._descriptor()
 
     def forward(self, x):
-        if self._descriptor() is None:  # irregular act-order: the reference's own two-step path, on device
+        # the cached native copy first (a key comparison); the row-stream view is rebuilt only when there is no native copy
+        if self.native_descriptor(0) is None and self._descriptor() is None:
+            # irregular act-order: the reference's own two-step path, on device
             from ... import ops
             w = ops.ort_dequantize4bits(self.qweight, self.scales, self.qzeros, self.g_idx, self.groupsize,
                                         self.infeatures, self.outfeatures)

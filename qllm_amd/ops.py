@@ -41,19 +41,28 @@ def _act_dtype(t: torch.Tensor) -> int:
     raise RuntimeError(f"activations must be float16 or bfloat16, got {t.dtype}")
 
 
+WORKSPACE_BYTES = 64 << 20
+
+
 def workspace(device: torch.device, nbytes: int) -> torch.Tensor:
     """Per-(device, stream) scratch for split-K slabs + arrival counters; zero-filled once (kernels leave it clean).
-    The key uses the CURRENT stream of `device` (not of whatever device happens to be current)."""
+    The key uses the CURRENT stream of `device` (not of whatever device happens to be current).
+
+    The persistent buffer is 64 MB and NEVER moves or grows: hipGraphs captured earlier hold its address (arrival counters,
+    split-K slabs).  Counters + slabs are bounded by 16 KB + 32 MB for every shape; only the fp16 staging copy of a bf16
+    activation (M * K * 2 bytes, dtype-aware sizing: qllm_workspace_bytes_act) can ask for more -- such a call gets a buffer of
+    its own from torch's caching allocator (inside a capture: from the graph's private pool, i.e. static for that graph), with
+    its counter page zeroed on the call's stream."""
     idx = device.index if device.index is not None else torch.cuda.current_device()
     key = (idx, torch.cuda.current_stream(idx).cuda_stream)
     ws = _workspaces.get(key)
-    if ws is None or ws.numel() < nbytes:
-        # 64 MB up front covers every configuration of the Llama-class shapes (largest: 32 MB of split-K partial tiles):
-        # growing later would move the buffer under hipGraphs captured with the old pointer
-        size = max(int(nbytes), 64 << 20)
-        ws = torch.zeros(size, dtype=torch.uint8, device=device)
-        _workspaces[key] = ws
-    return ws
+    if ws is None:
+        ws = _workspaces[key] = torch.zeros(WORKSPACE_BYTES, dtype=torch.uint8, device=device)
+    if nbytes <= ws.numel():
+        return ws
+    big = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+    big[:16384].zero_()
+    return big
 
 
 def make_weight(layout: str, qweight, scales, qzeros, g_idx, bias, in_features: int, out_features: int,
@@ -114,7 +123,7 @@ def linear_forward(w: QllmWeight, x2d: torch.Tensor, out: Optional[torch.Tensor]
     if out is None:
         out = torch.empty((m, w.N), dtype=x2d.dtype, device=x2d.device)
     with torch.cuda.device(x2d.device):
-        nbytes = lib.qllm_workspace_bytes(C.byref(w), m)
+        nbytes = lib.qllm_workspace_bytes_act(C.byref(w), m, _act_dtype(x2d))
         ws = workspace(x2d.device, nbytes)
         rc = lib.qllm_linear_forward(C.byref(w), x2d.data_ptr(), out.data_ptr(), m, _act_dtype(x2d), ws.data_ptr(),
                                      ws.numel(), _stream_ptr())
@@ -141,7 +150,7 @@ def linear_forward_grouped(ws_desc: Sequence[QllmWeight], x2d: torch.Tensor,
     arr = (QllmWeight * n)(*ws_desc)
     ys = (C.c_void_p * n)(*[o.data_ptr() for o in outs])
     with torch.cuda.device(x2d.device):
-        nbytes = sum(lib.qllm_workspace_bytes(C.byref(w), m) for w in ws_desc)
+        nbytes = sum(lib.qllm_workspace_bytes_act(C.byref(w), m, _act_dtype(x2d)) for w in ws_desc)
         wsp = workspace(x2d.device, nbytes)
         rc = lib.qllm_linear_forward_grouped(arr, ys, n, x2d.data_ptr(), m, _act_dtype(x2d), wsp.data_ptr(),
                                              wsp.numel(), _stream_ptr())

@@ -9,7 +9,13 @@ oracle is "sharded result == unsharded result" (section 8e).
                               gather_output=True does ONE collective: all_gather (default) or, as BASELINE.json words it,
                               all_reduce of the zero-padded [M, N] (numerically identical: the slices are disjoint).
   RowParallelQuantLinear      rank r owns input rows [r*K/P, (r+1)*K/P) (whole quantisation groups); partial products
-                              are summed with ONE all_reduce.  Trivial g_idx only.
+                              are summed with ONE all_reduce.  Act-order GPTQ layers (uniform groups): rank r owns the
+                              rows of GROUPS [r*G/P, (r+1)*G/P) -- the group-sorted arrangement the single-GPU path
+                              already uses (quant_linear_gptq.py: native copy of the row-sorted integers) -- and the
+                              shard records which input channels those are (`input_index`): a replicated input is
+                              gathered by it; a Megatron pair shards the PRODUCER by the same index
+                              (shard_columns(..., columns=consumer.input_index)), so its local output already is the
+                              consumer's local input and the pair still costs one all_reduce.
 
 xGMI note (MI355X: 8 GPUs fully connected, 7 links x ~153 GB/s each): a decode-sized all-reduce (16 KB at hidden 8192)
 is latency-bound, a prefill-sized one (32 MB) bandwidth-bound with a direct reduce-scatter + all-gather using all 7
@@ -33,14 +39,43 @@ def _world(group):
     return dist.get_rank(group), dist.get_world_size(group)
 
 
-def shard_columns(layer: nn.Module, rank: int, world: int) -> nn.Module:
-    """New q_layer of the same class holding output columns [rank*N/world, (rank+1)*N/world) of `layer`."""
+def _packed_columns(qzeros: torch.Tensor, bits: int, n: int, cols: torch.Tensor) -> torch.Tensor:
+    """Columns `cols` of a GPTQ qzeros [G, n*bits/32] (bit stream along N), re-packed."""
+    from .modeling.q_layers.compress_weight import pack_bitstream, unpack_bitstream
+    z = unpack_bitstream(qzeros, bits, n, axis=1)
+    return pack_bitstream(z.index_select(1, cols.to(z.device)), bits, axis=1)
+
+
+def shard_columns(layer: nn.Module, rank: int, world: int, columns: Optional[torch.Tensor] = None) -> nn.Module:
+    """New q_layer of the same class holding output columns [rank*N/world, (rank+1)*N/world) of `layer` -- or, with `columns`
+    (an index tensor; GPTQ / HQQ layers), exactly those output columns in that order: how the producer of a Megatron pair is
+    sharded when its consumer is an act-order row-parallel layer (columns = consumer_shard.input_index)."""
     n, k, bits, g = layer.outfeatures, layer.infeatures, layer.bits, layer.groupsize
+    cls = type(layer)
+    if columns is not None:
+        cols = columns.to(torch.long).reshape(-1)
+        nl = int(cols.numel())
+        if isinstance(layer, WQLinear_GEMM) or not isinstance(layer, (QuantLinearGPTQ, QuantLinearHQQ)):
+            raise TypeError("explicit column sets: GPTQ / HQQ layers (AWQ words interleave 8 columns)")
+        if (nl * bits) % 32 != 0:
+            raise ValueError(f"a shard of {nl} columns at {bits} bits does not fill whole packed-zero words")
+        new = cls(bits, g, k, nl, layer.bias is not None, dtype=layer.scales.dtype)
+        dev = layer.qweight.device
+        new.qweight = layer.qweight.index_select(1, cols.to(dev)).contiguous()
+        if isinstance(layer, QuantLinearHQQ):
+            new.qzeros = layer.qzeros.index_select(1, cols.to(dev)).contiguous()
+        else:
+            new.qzeros = _packed_columns(layer.qzeros, bits, n, cols)
+            new.g_idx = layer.g_idx.clone()
+            new.act_order = layer.act_order
+        new.scales = layer.scales.index_select(1, cols.to(dev)).contiguous()
+        if layer.bias is not None:
+            new.bias = layer.bias.index_select(0, cols.to(dev)).contiguous()
+        return new
     if n % world != 0:
         raise ValueError(f"out_features {n} not divisible by world size {world}")
     nl = n // world
     c0, c1 = rank * nl, (rank + 1) * nl
-    cls = type(layer)
     word_cols = 32 // math.gcd(32, bits)  # columns per whole packed-zero word boundary
     if isinstance(layer, WQLinear_GEMM):
         if nl % 8 != 0:
@@ -69,22 +104,41 @@ def shard_columns(layer: nn.Module, rank: int, world: int) -> nn.Module:
 
 
 def shard_rows(layer: nn.Module, rank: int, world: int) -> nn.Module:
-    """New q_layer holding input rows [rank*K/world, (rank+1)*K/world) (whole groups).  bias stays on rank 0."""
+    """New q_layer holding 1/world of the input rows (whole groups).  bias stays on rank 0.
+
+    Trivial g_idx: rows [rank*K/world, (rank+1)*K/world).  Act-order (GPTQ, every group exactly `groupsize` rows -- what GPTQ's
+    act-order produces, reference gptq.py:229-237): the rows of groups [rank*G/world, (rank+1)*G/world) in group-sorted order
+    (perm = stable argsort(g_idx)); the shard is a plain contiguous-group layer and carries `input_index` = perm[k0:k1], the input
+    channels it consumes, in its row order."""
     n, k, bits, g = layer.outfeatures, layer.infeatures, layer.bits, layer.groupsize
     if k % world != 0 or (k // world) % g != 0 or ((k // world) * bits) % 32 != 0:
         raise ValueError(f"in_features {k} / {world} must be whole groups of {g} and whole packed words")
     kl = k // world
     k0, k1 = rank * kl, (rank + 1) * kl
-    trivial = torch.equal(layer.g_idx.cpu().to(torch.int64), torch.arange(k) // g)
-    if not trivial:
-        raise ValueError("row-parallel sharding needs a trivial g_idx (no act-order)")
     cls = type(layer)
     has_bias = layer.bias is not None and rank == 0
+    gi = layer.g_idx.to(torch.int64).cpu() if getattr(layer, "g_idx", None) is not None else torch.arange(k) // g
+    trivial = torch.equal(gi, torch.arange(k) // g)
     new = cls(bits, g, kl, n, has_bias, dtype=layer.scales.dtype)
-    if isinstance(layer, WQLinear_GEMM):
-        new.qweight = layer.qweight[k0:k1].contiguous()
+    if trivial:
+        if isinstance(layer, WQLinear_GEMM):
+            new.qweight = layer.qweight[k0:k1].contiguous()
+        else:
+            new.qweight = layer.qweight[k0 * bits // 32:k1 * bits // 32].contiguous()
     else:
-        new.qweight = layer.qweight[k0 * bits // 32:k1 * bits // 32].contiguous()
+        if not isinstance(layer, QuantLinearGPTQ):
+            raise ValueError("a non-trivial g_idx on a layer that has no act-order")
+        groups = k // g
+        counts = torch.bincount(gi, minlength=groups)
+        if counts.numel() != groups or not bool((counts == g).all()):
+            raise ValueError("row-parallel sharding of an act-order layer needs uniform groups (every group exactly groupsize rows)")
+        from .modeling.q_layers.compress_weight import pack_bitstream, unpack_bitstream
+        sel = torch.argsort(gi, stable=True)[k0:k1]
+        dev = layer.qweight.device
+        q = unpack_bitstream(layer.qweight, bits, k, axis=0)
+        new.qweight = pack_bitstream(q.index_select(0, sel.to(dev)), bits, axis=0)
+        new.act_order = False   # the shard's own g_idx is the trivial default of its constructor
+        new.register_buffer("input_index", sel.to(torch.int32).to(dev), persistent=False)
     new.qzeros = layer.qzeros[k0 // g:k1 // g].contiguous()
     new.scales = layer.scales[k0 // g:k1 // g].contiguous()
     if has_bias:
@@ -162,6 +216,14 @@ class ColumnParallelQuantLinear(nn.Module):
         return full.view(lead + (world * nl,))
 
 
+def _gather_last(x: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """x[..., idx]: the library's column-gather kernel on a HIP device (idx int32), index_select elsewhere."""
+    if x.is_cuda and x.shape[-1] % 8 == 0 and idx.numel() % 8 == 0 and idx.numel() == x.shape[-1]:
+        from . import ops
+        return ops.gather_columns(x.reshape(-1, x.shape[-1]).contiguous(), idx).reshape(x.shape[:-1] + (idx.numel(),))
+    return x.index_select(-1, idx.to(device=x.device, dtype=torch.long))
+
+
 class RowParallelQuantLinear(nn.Module):
     def __init__(self, shard: nn.Module, group=None, input_is_parallel: bool = True, static_output: bool = False):
         super().__init__()
@@ -178,9 +240,14 @@ class RowParallelQuantLinear(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         rank, world = _world(self.group)
-        if not self.input_is_parallel and world > 1:
-            kl = x.shape[-1] // world
-            x = x[..., rank * kl:(rank + 1) * kl]
+        idx = getattr(self.shard, "input_index", None)
+        if not self.input_is_parallel and (world > 1 or idx is not None):
+            if idx is not None:   # act-order shard: the input channels of its groups (one gather, as on a single GPU)
+                x = _gather_last(x, idx)
+            else:
+                kl = x.shape[-1] // world
+                x = x[..., rank * kl:(rank + 1) * kl]
+        # (input_is_parallel with an act-order shard: the producer was sharded with columns=shard.input_index)
         x = x.contiguous()
         if self.static_output:
             lead = tuple(x.shape[:-1])

@@ -74,6 +74,15 @@ def test_workspace_bytes_is_pure(lib):
     assert 16384 + 64 * 4 * tile <= 64 << 20                               # fits the 64 MB the Python wrapper allocates up front
     down = _lib.QllmWeight(16, 16, 16, None, None, 11008, 4096, 128, 4, 0, 0)
     assert lib.qllm_workspace_bytes(ctypes.byref(down), 2048) <= 64 << 20  # ... also with the bf16 copy of a [2048, 11008] input
+    # the dtype-aware form (ABI 4): fp16 callers are not charged the staging copy; bf16 == the conservative form
+    F16, BF16 = 0, 1
+    assert lib.qllm_workspace_bytes_act(ctypes.byref(w), 2048, F16) == 16384
+    assert lib.qllm_workspace_bytes_act(ctypes.byref(w), 2048, BF16) == lib.qllm_workspace_bytes(ctypes.byref(w), 2048)
+    assert lib.qllm_workspace_bytes_act(ctypes.byref(w), 1024, F16) == 16384 + 128 * 2 * tile
+    # counters + slabs alone (everything but the staging copy) never exceed the wrapper's fixed 64 MB, at any M
+    for M in (33, 64, 65, 128, 256, 384, 512, 1024, 4096, 16384):
+        for ww in (w, wide, down):
+            assert lib.qllm_workspace_bytes_act(ctypes.byref(ww), M, F16) <= 33 << 20
 
 
 def test_device_probe_fails_cleanly_without_gpu(lib):

@@ -74,13 +74,17 @@ def _worker_body(rank, world, port, names, q):
             if not torch.equal(y, y_full):  # columns are independent: bit-exact
                 ok = False
                 msgs.append(f"{name} column/{coll} mismatch")
-        if not (g["layout"] == "GPTQ" and name.endswith("actorder")) and "actorder" not in name:
-            rp = P.RowParallelQuantLinear.from_full(layer, input_is_parallel=False)
-            y = rp(x)
-            err = float((y.float() - y_full.float()).abs().max() / y_full.float().abs().max())
-            if err > 2e-3:  # different summation order + fp16 partials in this CPU stand-in
-                ok = False
-                msgs.append(f"{name} row-parallel err {err}")
+        # row-parallel, replicated input: plain layers take their slice of x, act-order layers (uniform groups) gather the
+        # input channels of their groups (shard.input_index) and run as contiguous-group layers
+        rp = P.RowParallelQuantLinear.from_full(layer, input_is_parallel=False)
+        if "actorder" in name:
+            assert rp.shard.input_index.numel() == g["K"] // world and not rp.shard.act_order
+            assert torch.equal(rp.shard.g_idx, (torch.arange(g["K"] // world) // g["groupsize"]).to(torch.int32))
+        y = rp(x)
+        err = float((y.float() - y_full.float()).abs().max() / y_full.float().abs().max())
+        if err > 2e-3:  # different summation order + fp16 partials in this CPU stand-in
+            ok = False
+            msgs.append(f"{name} row-parallel err {err}")
     # Megatron pair (o_proj after q/k/v, down after gate/up): column-parallel WITHOUT the gather feeding row-parallel with
     # input_is_parallel: rank r's output columns are exactly rank r's input rows of the second layer, so the pair costs ONE
     # all-reduce and no all-gather.  Count the collectives, compare with the unsharded pair.
@@ -127,6 +131,28 @@ def _worker_body(rank, world, port, names, q):
     if err > 2e-3:
         ok = False
         msgs.append(f"Megatron pair err {err}")
+    # the same pair with an ACT-ORDER consumer: the producer is sharded by the consumer's input channels
+    # (shard_columns(columns=consumer_shard.input_index)), so the local activation is already the consumer's local input
+    gB = (torch.arange(512) // 128)[torch.from_numpy(rng.permutation(512))].to(torch.int32)
+    Bo = mk(512, 256, True)
+    Bo.g_idx = gB
+    Bo.act_order = True
+    y_full = _oracle_forward(Bo, _oracle_forward(A, x))
+    calls = {"all_reduce": 0, "all_gather": 0}
+    dist.all_reduce, dist.all_gather_into_tensor = count_ar, count_ag
+    try:
+        row = P.RowParallelQuantLinear.from_full(Bo, input_is_parallel=True)
+        col = P.ColumnParallelQuantLinear(P.shard_columns(A, rank, world, columns=row.shard.input_index), A.outfeatures, gather_output=False)
+        y = row(col(x))
+    finally:
+        dist.all_reduce, dist.all_gather_into_tensor = real_ar, real_ag
+    if calls != {"all_reduce": 1, "all_gather": 0}:
+        ok = False
+        msgs.append(f"act-order Megatron pair used {calls}")
+    err = float((y.float() - y_full.float()).abs().max() / y_full.float().abs().max())
+    if err > 2e-3:
+        ok = False
+        msgs.append(f"act-order Megatron pair err {err}")
     if rank == 0:
         q.put((ok, msgs))
     dist.barrier()
@@ -136,7 +162,7 @@ def _worker_body(rank, world, port, names, q):
 @pytest.mark.timeout(300)
 def test_sharded_equals_unsharded_world2():
     names = ["gptq_w4_g128_asym", "gptq_w4_g128_actorder", "awq_w4_g64_bias", "hqq_w4_g64", "gptq_w4_g128_opt_bias",
-             "gptq_w3_g128_asym"]
+             "gptq_w3_g128_asym", "gptq_w3_g64_actorder", "gptq_w4_g32_actorder_bias"]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -161,8 +187,20 @@ def test_shard_shapes_and_errors():
     with pytest.raises(ValueError):
         P.shard_columns(layer, 0, 3)
     _, gl = _build("gptq_w4_g128_actorder")
+    r1 = P.shard_rows(gl, 1, 2)   # act-order, uniform groups: the rows of the upper half of the groups, group-sorted
+    gi = gl.g_idx.long()
+    assert torch.equal(r1.input_index.long(), torch.argsort(gi, stable=True)[gl.infeatures // 2:])
+    assert bool((gi[r1.input_index.long()] >= gi.max().item() // 2 + 1).all()) and r1.act_order is False
+    gl.g_idx = gl.g_idx.clone()
+    gl.g_idx[0] = gl.g_idx[1] = gl.g_idx[2]   # groups no longer uniform
     with pytest.raises(ValueError):
         P.shard_rows(gl, 0, 2)
+    _, g0 = _build("gptq_w4_g128_asym")
+    cs = P.shard_columns(g0, 0, 2, columns=torch.arange(g0.outfeatures - 1, -1, -2))   # every other column, reversed
+    cols = torch.arange(g0.outfeatures - 1, -1, -2)
+    assert cs.outfeatures == g0.outfeatures // 2 and torch.equal(cs.scales, g0.scales[:, cols])
+    x = torch.from_numpy(load_golden("gptq_w4_g128_asym")["x"][:3])
+    assert torch.equal(_oracle_forward(cs, x), _oracle_forward(g0, x)[:, cols])   # columns are independent: bit-exact
     _, hl = _build("hqq_w4_g64")
     r0 = P.shard_rows(hl, 0, 2)
     assert r0.qweight.shape == (16, 128) and r0.qzeros.shape == (2, 128) and r0.infeatures == 128
