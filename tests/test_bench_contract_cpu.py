@@ -32,3 +32,24 @@ def test_command_line_contract():
     # the oracle appears in bench.py only inside the cpu_baseline leg
     lines = [l for l in src.splitlines() if "from oracle" in l or "import oracle" in l]
     assert len(lines) == 1 and "ref_torch" in lines[0]
+
+
+def test_gpus_n_starts_its_own_ranks():
+    """`python bench.py --gpus 2 ...` with no launcher in the environment must start two ranks itself (torch.distributed.run,
+    127.0.0.1) and print ONE JSON line with n_gpus = 2.  The GPU work is stubbed (QLLM_BENCH_STUB=1: gloo, CPU) -- what runs here is
+    the launch, rendezvous, max-over-ranks reduction and printing path the driver's 8-GPU run goes through."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["QLLM_BENCH_STUB"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1 and "STUB" in rec["data"]
+    # under a launcher that set WORLD_SIZE the flag must agree with it
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="3", RANK="0"),
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "WORLD_SIZE=3" in r.stderr

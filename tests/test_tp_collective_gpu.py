@@ -121,6 +121,33 @@ def _body(rank, world):
         y_full = down(up(x))
         if _rel(y, y_full) > 2e-3:
             msgs.append(f"megatron pair m={m}: rel err {_rel(y, y_full):.2e}")
+    # ---- act-order GPTQ (4 and 3 bits) under tensor parallelism (a freshly built layer has act_order = None until
+    #      something resolves it -- the shards' forward_into must): column shards keep the g_idx, row shards take whole groups of the
+    #      group-sorted arrangement (shard.input_index), the pair's producer is sharded by the consumer's input channels
+    for bits, g in ((4, 128), (3, 64)):
+        ao = to_layer(synth("GPTQ", bits, g, 4096, 4096, act_order=True, seed=30 + bits), dev)
+        ao2 = synth("GPTQ", bits, g, 4096, 4096, act_order=True, seed=40 + bits)
+        ao2["scales"] = (ao2["scales"].astype(np.float32) * 0.2).astype(np.float16)
+        ao2 = to_layer(ao2, dev)
+        for m in (1, 5, 200):
+            x = torch.from_numpy(randx(m, 4096, seed=60 + m)).to(dev)
+            fresh = to_layer(synth("GPTQ", bits, g, 4096, 4096, act_order=True, seed=30 + bits), dev)   # act_order still None
+            cp = P.ColumnParallelQuantLinear.from_full(fresh, static_output=True)
+            y_full = ao(x)
+            y = cp(x)
+            if _ulps(y, y_full) > 1:
+                msgs.append(f"act-order w{bits} column m={m}: {_ulps(y, y_full)} ulp from the unsharded result")
+            rp = P.RowParallelQuantLinear.from_full(ao, input_is_parallel=False)
+            if _rel(rp(x), y_full) > 1e-3:
+                msgs.append(f"act-order w{bits} row m={m}: rel err {_rel(rp(x), y_full):.2e}")
+            row = P.RowParallelQuantLinear.from_full(ao2, input_is_parallel=True)
+            col = P.ColumnParallelQuantLinear(P.shard_columns(ao, rank, world, columns=row.shard.input_index), ao.outfeatures, gather_output=False)
+            before = dict(calls)
+            y = row(col(x))
+            if calls["all_reduce"] - before["all_reduce"] != 1 or calls["all_gather"] != before["all_gather"]:
+                msgs.append(f"act-order w{bits} pair m={m}: expected exactly one all_reduce")
+            if _rel(y, ao2(ao(x))) > 2e-3:
+                msgs.append(f"act-order w{bits} pair m={m}: rel err {_rel(y, ao2(ao(x))):.2e}")
     dist.all_reduce, dist.all_gather_into_tensor = real_ar, real_ag
     # ---- the local half of a decode-sized column-parallel forward captures into a hipGraph (the collective itself is a
     #      stream operation only under RCCL; gloo's is host-side)
@@ -165,5 +192,6 @@ def test_hip_shards_behind_a_real_collective_two_ranks_one_gpu(capfd):
         assert not msgs, (rank, msgs)
     out = capfd.readouterr().out
     assert "[tp_bench] world_size=2 backend=gloo tp_degree=2 layers=2" in out
+    assert "[tp_bench] sharded == unsharded on 2 rank(s)" in out
     assert "[tp_bench] step runs as: eager (backend gloo" in out
     assert '"ranks": 2' in out and '"all_reduces_per_layer": 2' in out

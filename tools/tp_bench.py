@@ -149,6 +149,39 @@ def shard_shapes_leg(dev, n_layers=16):
     return out
 
 
+def verify_sharding(world, rank, dev, group=None):
+    """Before anything is timed: ONE decoder layer's linears at the full Llama-2-70B shapes, identical on every rank (same seed),
+    sharded with qllm_amd.parallel (shard_columns / shard_rows slices of those very integers) -- the tensor-parallel result must
+    equal the unsharded HIP result computed on the same rank: bit-exact for the gathered column-parallel layer (columns are
+    independent), within 2e-3 for the Megatron pairs (the all-reduce changes the summation order).  Raises on mismatch."""
+    from qllm_amd import parallel as TP
+    from qllm_amd.modeling.q_layers import WQLinear_GEMM
+    gen = torch.Generator(device=dev).manual_seed(20240607)   # NOT rank-dependent
+    q, o = _layer(WQLinear_GEMM, H70, H70, dev, gen), _layer(WQLinear_GEMM, H70, H70, dev, gen)
+    gate, down = _layer(WQLinear_GEMM, H70, I70, dev, gen), _layer(WQLinear_GEMM, I70, H70, dev, gen)
+    report = {}
+    for M in (1, 16):
+        x = torch.randn(M, H70, device=dev, dtype=torch.float16, generator=gen)
+        y_gate = gate(x)
+        y_cp = TP.ColumnParallelQuantLinear.from_full(gate, group, gather_output=True)(x)
+        if not torch.equal(y_cp, y_gate):
+            raise AssertionError(f"column-parallel gate_proj (gathered) differs from the unsharded layer at M={M}")
+        for name, a, b in (("q->o", q, o), ("gate->down", gate, down)):
+            y_full = b(a(x))
+            col = TP.ColumnParallelQuantLinear.from_full(a, group, gather_output=False)
+            row = TP.RowParallelQuantLinear.from_full(b, group, input_is_parallel=True)
+            y_tp = row(col(x))
+            err = float((y_tp.float() - y_full.float()).abs().max() / y_full.float().abs().max())
+            if not err <= 2e-3:
+                raise AssertionError(f"Megatron pair {name} at M={M}: sharded vs unsharded relative error {err}")
+            report[f"{name} M={M}"] = round(err, 6)
+    torch.cuda.synchronize()
+    if rank == 0:
+        print(f"[tp_bench] sharded == unsharded on {world} rank(s): column-parallel bit-exact, Megatron pairs rel err {report}", flush=True)
+    del q, o, gate, down
+    torch.cuda.empty_cache()
+
+
 def run(args, world, rank, dev, info):
     """bench.py --tp N: N ranks (or 1 rank running the TP=8 shard shapes without a collective).  `args.tp_layers` (default: all
     80) shortens the stack for smoke runs (tests/test_tp_collective_gpu.py drives this function with two gloo ranks on one GPU,
@@ -161,7 +194,11 @@ def run(args, world, rank, dev, info):
     backend = dist.get_backend() if world > 1 else None
     if rank == 0:
         print(f"[tp_bench] world_size={dist.get_world_size() if world > 1 else 1} backend={backend} tp_degree={P} layers={n_layers}", flush=True)
-    blocks = build_stack(P, n_layers, dev, seed=4321 + rank)  # every rank: its own shard of every layer
+    if world > 1:
+        verify_sharding(world, rank, dev)
+    # the timed stack is built at shard shapes from per-rank seeds (as good as slices of synthetic full-size integers and 8 x
+    # less to generate; the slicing itself was just verified on one full-size layer)
+    blocks = build_stack(P, n_layers, dev, seed=4321 + rank)
     M = 1
     h0 = torch.randn(M, H70, device=dev, dtype=torch.float16)
     if world > 1:
