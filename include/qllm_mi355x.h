@@ -228,6 +228,25 @@ int qllm_pack_qweight(const int32_t *q_kn, int32_t layout, int32_t bits, int32_t
  * not range-checked).  x, perm, out 16-byte aligned, out must not alias x; K % 8 == 0 and K <= 28672, else QLLM_ERR_UNSUPPORTED. */
 int qllm_gather_columns(const void *x, const int32_t *perm, void *out, int32_t M, int32_t K, int32_t act_dtype, void *stream);
 
+/* ---- tensor-parallel decode: one-shot all-reduce over peer-mapped staging buffers (ABI 4) -------------------------------------- */
+/* For decode-sized tensors ([1, 8192] fp16 = 16 KB per row-parallel layer) a ring / tree all-reduce is pure latency.  On the xGMI
+ * full mesh every rank instead writes its vector into every peer's staging buffer (one hop), waits for the world's flags and sums
+ * locally in rank order (bit-identical on every rank).  One process per GPU: each rank allocates ONE staging buffer
+ * (qllm_comm_buffer_bytes: 2 parities x world slots + a control block; fine-grained device memory -- qllm_comm_alloc is the only
+ * allocation this library ever makes, and only on request), exports it as a 64-byte HIP IPC handle, imports the peers' handles, and
+ * passes the device array of the `world` buffer addresses (its own at index `rank`) to every call.  x_inout: n elements (n % 8 == 0,
+ * n * 2 <= slot_bytes), summed in place; the call is a single kernel on `stream`, keeps its epoch in device memory and is
+ * hipGraph-capturable.  status_dev (nullable): set to 1 by the kernel if a peer never arrived.  Every rank must make the same
+ * sequence of calls.  qllm_amd/comm.py wraps it behind torch.distributed; no counterpart in the reference (no distributed code). */
+size_t qllm_comm_buffer_bytes(int32_t world, size_t slot_bytes);
+int qllm_comm_alloc(size_t bytes, void **ptr);
+int qllm_comm_free(void *ptr);
+int qllm_comm_export(void *ptr, void *handle64);
+int qllm_comm_import(const void *handle64, void **ptr);
+int qllm_comm_close(void *ptr);
+int qllm_allreduce_oneshot(void *const *peers_dev, int32_t rank, int32_t world, void *x_inout, int32_t n, int32_t act_dtype,
+                           size_t slot_bytes, int32_t *status_dev, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -23,6 +23,8 @@ EXPORTS = (
     "qllm_linear_forward", "qllm_linear_forward_grouped", "qllm_dequant", "qllm_ort_gemv", "qllm_ort_dequant",
     "qllm_awq_gemm_forward", "qllm_unpack_qweight", "qllm_pack_qweight", "qllm_gather_columns", "qllm_ort_dequantize4bits",
     "qllm_plan_describe", "qllm_debug_timeline", "qllm_native_sizes", "qllm_repack_native", "qllm_unpack_native",
+    "qllm_comm_buffer_bytes", "qllm_comm_alloc", "qllm_comm_free", "qllm_comm_export", "qllm_comm_import", "qllm_comm_close",
+    "qllm_allreduce_oneshot",
 )
 
 
@@ -70,6 +72,20 @@ def _declare(lib):
     lib.qllm_workspace_bytes.argtypes = [wp, i32]
     lib.qllm_workspace_bytes_act.restype = sz
     lib.qllm_workspace_bytes_act.argtypes = [wp, i32, i32]
+    lib.qllm_comm_buffer_bytes.restype = sz
+    lib.qllm_comm_buffer_bytes.argtypes = [i32, sz]
+    lib.qllm_comm_alloc.restype = C.c_int
+    lib.qllm_comm_alloc.argtypes = [sz, C.POINTER(vp)]
+    lib.qllm_comm_free.restype = C.c_int
+    lib.qllm_comm_free.argtypes = [vp]
+    lib.qllm_comm_export.restype = C.c_int
+    lib.qllm_comm_export.argtypes = [vp, vp]
+    lib.qllm_comm_import.restype = C.c_int
+    lib.qllm_comm_import.argtypes = [vp, C.POINTER(vp)]
+    lib.qllm_comm_close.restype = C.c_int
+    lib.qllm_comm_close.argtypes = [vp]
+    lib.qllm_allreduce_oneshot.restype = C.c_int
+    lib.qllm_allreduce_oneshot.argtypes = [vp, i32, i32, vp, i32, i32, sz, vp, vp]
     lib.qllm_workspace_init.restype = C.c_int
     lib.qllm_workspace_init.argtypes = [vp, sz, vp]
     lib.qllm_linear_forward.restype = C.c_int

@@ -1,0 +1,93 @@
+"""One-shot all-reduce for decode-sized tensors (tensor-parallel row-parallel layers at small M) over peer-mapped staging buffers:
+the host side of `csrc/comm.hip` (include/qllm_mi355x.h, "one-shot all-reduce").
+
+    ar = OneShotAllReduce(group=None, max_bytes=65536)     # collective: every rank of the group constructs it
+    ar.all_reduce(y)                                       # in place, sum, fp16 / bf16, y.numel() * 2 <= max_bytes
+
+One process per GPU.  Every rank allocates one fine-grained staging buffer through the library, exports it as a HIP IPC handle,
+exchanges the handles with `torch.distributed.all_gather_object` (any backend) and maps the peers' buffers; a call is then ONE
+kernel on the current stream (push to every peer, wait for the world's flags, local sum in rank order) -- no host work, no RCCL
+launch, hipGraph-capturable.  Tensors that do not fit (prefill sizes) and anything the kernel does not take go to
+`dist.all_reduce` (RCCL): the wrapper never changes results, only how small sums travel.  The reference has no distributed code.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+
+
+class OneShotAllReduce:
+    def __init__(self, group=None, max_bytes: int = 64 * 1024, device: Optional[torch.device] = None):
+        if not dist.is_available() or not dist.is_initialized():
+            raise RuntimeError("OneShotAllReduce needs an initialised torch.distributed process group")
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.slot_bytes = (int(max_bytes) + 255) // 256 * 256
+        self._lib = _lib.load()
+        self._own = C.c_void_p()
+        self._peers = []
+        with torch.cuda.device(self.device):
+            nbytes = self._lib.qllm_comm_buffer_bytes(self.world, self.slot_bytes)
+            _lib.check(self._lib.qllm_comm_alloc(nbytes, C.byref(self._own)))
+            handle = (C.c_char * 64)()
+            _lib.check(self._lib.qllm_comm_export(self._own, handle))
+            handles = [None] * self.world
+            dist.all_gather_object(handles, bytes(handle.raw), group=group)
+            ptrs = []
+            for r, h in enumerate(handles):
+                if r == self.rank:
+                    ptrs.append(self._own.value)
+                    continue
+                p = C.c_void_p()
+                buf = (C.c_char * 64).from_buffer_copy(h)
+                _lib.check(self._lib.qllm_comm_import(buf, C.byref(p)))
+                self._peers.append(p)
+                ptrs.append(p.value)
+            self._table = torch.tensor(ptrs, dtype=torch.int64, device=self.device)   # void *peers[world], on the device
+            self._status = torch.zeros(1, dtype=torch.int32, device=self.device)
+        torch.cuda.synchronize(self.device)
+        dist.barrier(group=group)   # every rank has mapped every buffer before the first push
+
+    def supports(self, t: torch.Tensor) -> bool:
+        return (t.is_cuda and t.device == self.device and t.is_contiguous() and t.dtype in (torch.float16, torch.bfloat16)
+                and t.numel() % 8 == 0 and 0 < t.numel() * 2 <= self.slot_bytes and t.data_ptr() % 16 == 0)
+
+    def all_reduce(self, t: torch.Tensor) -> torch.Tensor:
+        """Sum `t` over the group, in place.  Small fp16 / bf16 tensors: the one-shot kernel; everything else: dist.all_reduce."""
+        if self.world == 1:
+            return t
+        if not self.supports(t):
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            return t
+        with torch.cuda.device(self.device):
+            rc = self._lib.qllm_allreduce_oneshot(self._table.data_ptr(), self.rank, self.world, t.data_ptr(), t.numel(),
+                                                  _lib.DT_F16 if t.dtype == torch.float16 else _lib.DT_BF16, self.slot_bytes,
+                                                  self._status.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc)
+        return t
+
+    def check(self):
+        """Raise if a call timed out waiting for a peer (host sync; for tests and shutdown paths)."""
+        if int(self._status.item()) != 0:
+            raise RuntimeError("one-shot all-reduce: a peer never arrived (every rank must make the same sequence of calls)")
+
+    def close(self):
+        torch.cuda.synchronize(self.device)
+        if dist.is_initialized():
+            dist.barrier(group=self.group)   # nobody unmaps while a peer may still push
+        for p in self._peers:
+            self._lib.qllm_comm_close(p)
+        self._peers = []
+        if self._own:
+            self._lib.qllm_comm_free(self._own)
+            self._own = C.c_void_p()
+
+
+__all__ = ["OneShotAllReduce"]

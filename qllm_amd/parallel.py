@@ -225,18 +225,22 @@ def _gather_last(x: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
 
 
 class RowParallelQuantLinear(nn.Module):
-    def __init__(self, shard: nn.Module, group=None, input_is_parallel: bool = True, static_output: bool = False):
+    """`reducer`: an object with `all_reduce(tensor)` (qllm_amd.comm.OneShotAllReduce: decode-sized sums through the one-shot
+    peer-write kernel, larger ones through RCCL); None = `dist.all_reduce`."""
+
+    def __init__(self, shard: nn.Module, group=None, input_is_parallel: bool = True, static_output: bool = False, reducer=None):
         super().__init__()
         self.shard = shard
         self.group = group
         self.input_is_parallel = input_is_parallel
         self.static_output = static_output
+        self.reducer = reducer
         self._bufs: dict = {}
 
     @classmethod
-    def from_full(cls, layer: nn.Module, group=None, input_is_parallel: bool = True, static_output: bool = False):
+    def from_full(cls, layer: nn.Module, group=None, input_is_parallel: bool = True, static_output: bool = False, reducer=None):
         rank, world = _world(group)
-        return cls(shard_rows(layer, rank, world), group, input_is_parallel, static_output)
+        return cls(shard_rows(layer, rank, world), group, input_is_parallel, static_output, reducer)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         rank, world = _world(self.group)
@@ -258,8 +262,11 @@ class RowParallelQuantLinear(nn.Module):
             self.shard.forward_into(x, y.view(-1, self.shard.outfeatures))
         else:
             y = self.shard(x)
-        if world > 1:
-            dist.all_reduce(y, op=dist.ReduceOp.SUM, group=self.group)  # partial products over K: ONE collective, in place
+        if world > 1:   # partial products over K: ONE collective, in place
+            if self.reducer is not None:
+                self.reducer.all_reduce(y)
+            else:
+                dist.all_reduce(y, op=dist.ReduceOp.SUM, group=self.group)
         return y
 
 

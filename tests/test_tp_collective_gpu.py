@@ -170,6 +170,60 @@ def _body(rank, world):
     torch.cuda.synchronize()
     if not torch.equal(buf[:, rank * nl:(rank + 1) * nl], y_ref[:, rank * nl:(rank + 1) * nl]):
         msgs.append("graph replay of the shard's in-place forward differs")
+    # ---- the one-shot all-reduce (csrc/comm.hip, qllm_amd/comm.py): HIP IPC staging buffers mapped across the two PROCESSES (one
+    #      device here, xGMI peers on a node), every call one kernel; against dist.all_reduce on copies: the same fp32 sum in rank
+    #      order -> within one rounding of the collective's result; bit-identical across ranks; epochs / parities over many calls;
+    #      in place behind a row-parallel layer; captured into a hipGraph and replayed
+    from qllm_amd.comm import OneShotAllReduce
+    ar = OneShotAllReduce(max_bytes=64 * 1024)
+    gen = torch.Generator(device=dev).manual_seed(1000 + rank)
+    for dtype in (torch.float16, torch.bfloat16):
+        for n in (8, 8192, 32768):
+            for it in range(7):
+                t = torch.randn(n, device=dev, dtype=torch.float32, generator=gen).to(dtype)
+                ref = t.clone()
+                dist.all_reduce(ref)
+                out = ar.all_reduce(t.clone())
+                torch.cuda.synchronize()
+                if _rel(out, ref) > (1e-3 if dtype == torch.float16 else 8e-3):
+                    msgs.append(f"one-shot all-reduce {dtype} n={n} call {it}: rel err {_rel(out, ref):.2e}")
+                both = [torch.empty_like(out) for _ in range(world)]
+                dist.all_gather(both, out)
+                if not torch.equal(both[0], both[1]):
+                    msgs.append(f"one-shot all-reduce {dtype} n={n}: ranks disagree")
+    ar.check()
+    big = torch.randn(1 << 20, device=dev, dtype=torch.float16, generator=gen)   # does not fit a slot: falls through to the group's collective
+    ref = big.clone()
+    dist.all_reduce(ref)
+    if not torch.equal(ar.all_reduce(big.clone()), ref):
+        msgs.append("one-shot wrapper: large tensor did not take dist.all_reduce")
+    rp1 = P.RowParallelQuantLinear.from_full(full["GEMM"], input_is_parallel=False, static_output=True, reducer=ar)
+    x1 = torch.from_numpy(randx(1, K, seed=77)).to(dev)
+    if _rel(rp1(x1), full["GEMM"](x1)) > 1e-3:
+        msgs.append("row-parallel layer behind the one-shot reducer differs from the unsharded layer")
+    t = torch.randn(8192, device=dev, dtype=torch.float16, generator=gen)
+    tin = t.clone()
+    exp = tin.clone()
+    dist.all_reduce(exp)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        ar.all_reduce(t)
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        ar.all_reduce(t)
+    dist.barrier()
+    for _ in range(3):   # replays advance the epoch on the device, like the captured call did
+        t.copy_(tin)
+        g.replay()
+        torch.cuda.synchronize()
+        if _rel(t, exp) > 1e-3:
+            msgs.append("graph replay of the one-shot all-reduce differs")
+        dist.barrier()
+    ar.check()
+    ar.close()
     # ---- tools/tp_bench.run, as `bench.py --tp 2` would drive it (two layers, eager because the backend is gloo)
     from qllm_amd import _lib
     from tools import tp_bench
@@ -193,5 +247,6 @@ def test_hip_shards_behind_a_real_collective_two_ranks_one_gpu(capfd):
     out = capfd.readouterr().out
     assert "[tp_bench] world_size=2 backend=gloo tp_degree=2 layers=2" in out
     assert "[tp_bench] sharded == unsharded on 2 rank(s)" in out
+    assert "[tp_bench] row-parallel sums: one-shot peer-write kernel" in out and '"oneshot_all_reduce_us_16KB"' in out
     assert "[tp_bench] step runs as: eager (backend gloo" in out
     assert '"ranks": 2' in out and '"all_reduces_per_layer": 2' in out

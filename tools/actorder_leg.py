@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""The act-order prefill leg of bench.py on its own (4 decoder layers of GPTQ w4 g128 act-order linears, M = 2048, graph replay):
+the target of `rocprofv3 --kernel-trace --stats` when the question is what the act-order path adds to the plain one."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from qllm_amd.modeling.q_layers import QuantLinearGPTQ, WQLinear_GEMM  # noqa: E402
+
+dev = torch.device("cuda:0")
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+for tag, cls, act in (("awq", WQLinear_GEMM, False), ("gptq_actorder", QuantLinearGPTQ, True)):
+    ps = bench.Stack(cls, 4, dev, seed=99, act_order=act)
+    xp = torch.randn(2048, bench.HIDDEN, device=dev, dtype=torch.float16)
+    gp, _ = bench.capture(lambda: ps(xp))
+    ms = bench.time_events(gp.replay, iters)
+    print(f"{tag}: {ms:.3f} ms per 4 layers, {bench.flops_per_pass(4, 2048) / ms / 1e9:.1f} TFLOP/s", flush=True)
+    del gp, ps

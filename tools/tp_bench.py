@@ -22,6 +22,7 @@ import time
 import torch
 
 H70, KV70, I70, L70, G = 8192, 1024, 28672, 80, 128
+M_MAX_ONESHOT = 4   # rows whose [M, 8192] sum still travels through the one-shot kernel (64 KB)
 HBM_PEAK_GBPS = 8000.0
 MFMA_PEAK_TFLOPS = 2500.0
 
@@ -43,16 +44,16 @@ class ShardBlock(torch.nn.Module):
     """One decoder layer's shards on this rank, as the Megatron pairing leaves them (built directly at shard shapes: the
     synthetic integers of a shard are as good as a slice of synthetic full-size integers; tests/ cover slicing)."""
 
-    def __init__(self, cls, P, dev, gen, group=None):
+    def __init__(self, cls, P, dev, gen, group=None, reducer=None):
         super().__init__()
         from qllm_amd import parallel as TP
         self.q_proj = _layer(cls, H70, H70 // P, dev, gen)
         self.k_proj = _layer(cls, H70, KV70 // P, dev, gen)
         self.v_proj = _layer(cls, H70, KV70 // P, dev, gen)
-        self.o_proj = TP.RowParallelQuantLinear(_layer(cls, H70 // P, H70, dev, gen), group)
+        self.o_proj = TP.RowParallelQuantLinear(_layer(cls, H70 // P, H70, dev, gen), group, reducer=reducer)
         self.gate_proj = _layer(cls, H70, I70 // P, dev, gen)
         self.up_proj = _layer(cls, H70, I70 // P, dev, gen)
-        self.down_proj = TP.RowParallelQuantLinear(_layer(cls, I70 // P, H70, dev, gen), group)
+        self.down_proj = TP.RowParallelQuantLinear(_layer(cls, I70 // P, H70, dev, gen), group, reducer=reducer)
 
     def forward(self, h):
         q = self.q_proj(h)
@@ -98,10 +99,10 @@ def _time(fn, iters):
     return e0.elapsed_time(e1) / iters
 
 
-def build_stack(P, n_layers, dev, seed, group=None):
+def build_stack(P, n_layers, dev, seed, group=None, reducer=None):
     from qllm_amd.modeling.q_layers import WQLinear_GEMM, install_sibling_groups
     gen = torch.Generator(device=dev).manual_seed(seed)
-    blocks = torch.nn.ModuleList([ShardBlock(WQLinear_GEMM, P, dev, gen, group) for _ in range(n_layers)])
+    blocks = torch.nn.ModuleList([ShardBlock(WQLinear_GEMM, P, dev, gen, group, reducer) for _ in range(n_layers)])
     install_sibling_groups(blocks, [WQLinear_GEMM])
     return blocks
 
@@ -198,7 +199,18 @@ def run(args, world, rank, dev, info):
         verify_sharding(world, rank, dev)
     # the timed stack is built at shard shapes from per-rank seeds (as good as slices of synthetic full-size integers and 8 x
     # less to generate; the slicing itself was just verified on one full-size layer)
-    blocks = build_stack(P, n_layers, dev, seed=4321 + rank)
+    # decode-sized all-reduces ([1, 8192] fp16 = 16 KB): the one-shot peer-write kernel (qllm_amd/comm.py) unless QLLM_TP_ONESHOT=0
+    reducer, reducer_mode = None, "dist.all_reduce"
+    if world > 1 and os.environ.get("QLLM_TP_ONESHOT", "1") != "0":
+        try:
+            from qllm_amd.comm import OneShotAllReduce
+            reducer = OneShotAllReduce(max_bytes=M_MAX_ONESHOT * H70 * 2)
+            reducer_mode = "one-shot peer-write kernel (HIP IPC staging buffers)"
+        except Exception as e:  # noqa: BLE001  (e.g. IPC not permitted in this container): RCCL serves the sums
+            reducer_mode = f"dist.all_reduce (one-shot unavailable: {type(e).__name__}: {e})"
+    if rank == 0:
+        print(f"[tp_bench] row-parallel sums: {reducer_mode}", flush=True)
+    blocks = build_stack(P, n_layers, dev, seed=4321 + rank, reducer=reducer)
     M = 1
     h0 = torch.randn(M, H70, device=dev, dtype=torch.float16)
     if world > 1:
@@ -249,13 +261,19 @@ def run(args, world, rank, dev, info):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t[0])
     ms_per_step = wall * 1e3 / args.steps
-    ar_us = None
+    ar_us = ar1_us = None
     if world > 1:  # the decode-sized all-reduce on its own ([1, 8192] fp16 = 16 KB: latency-bound over xGMI)
         buf = torch.zeros(M, H70, device=dev, dtype=torch.float16)
         for _ in range(10):
             dist.all_reduce(buf)
         torch.cuda.synchronize()
         ar_us = _time(lambda: dist.all_reduce(buf), 200) * 1e3
+        if reducer is not None:
+            for _ in range(10):
+                reducer.all_reduce(buf)
+            torch.cuda.synchronize()
+            ar1_us = _time(lambda: reducer.all_reduce(buf), 200) * 1e3
+            reducer.check()
     nbytes = shard_bytes_per_token(P, n_layers, M)
     if rank == 0:
         print(json.dumps({
@@ -270,6 +288,9 @@ def run(args, world, rank, dev, info):
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s (per rank)", "frac": round(nbytes / ms_per_step / 1e6 / HBM_PEAK_GBPS, 4),
                          "traffic": None},
             "all_reduce_us_16KB": None if ar_us is None else round(ar_us, 2),
+            "oneshot_all_reduce_us_16KB": None if ar1_us is None else round(ar1_us, 2), "row_parallel_sums": reducer_mode,
             "cpu_baseline": None}), flush=True)
+    if reducer is not None:
+        reducer.close()
     if world > 1 and not getattr(args, "keep_process_group", False):
         dist.destroy_process_group()
