@@ -122,7 +122,7 @@ def test_decode_kernel_vs_oracle(layout, g, K, N, zk, bias):
     d = synth(layout, 4, g, K, N, zk, False, bias, seed=K + N)
     layer = to_layer(d, DEV)
     ref = Ref(d)
-    for m in (1, 2, 4, 5, 7, 16, 17, 32, 33, 64):  # 1-4: LDS-slab strips; 5-32: register-A strips (17-32: two row tiles); 33+: split-K
+    for m in (1, 2, 4, 5, 7, 16, 17, 32, 33, 64):  # 1: LDS-slab strips; 2-32: strip_dma (17-32: two row tiles); 33-64: four row tiles / gemm2 (see qllm_plan_describe)
         x = randx(m, K, seed=m)
         y = layer(torch.from_numpy(x).to(DEV)).cpu().numpy()
         assert O.rel_err(y, ref.y16(x)) <= TOL, (layout, K, N, m)
