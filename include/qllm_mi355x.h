@@ -75,8 +75,16 @@ typedef enum qllm_layout {
 
 typedef enum qllm_dtype {
   QLLM_F16 = 0,
-  QLLM_BF16 = 1
+  QLLM_BF16 = 1,
+  /* qllm_linear_forward only (ABI 4): x is fp16 -- bf16 activations the CALLER converted once, e.g. for q/k/v which share their
+   * input -- and y is written as bf16(fp16(result)): the reference's own bf16 shim around its fp16 kernels
+   * (quant_linear_awq.py:29-36, 144-146) with the conversion of x hoisted out of the call.  Served where the 256x128 prefill
+   * kernel serves a bf16 call (the call that would otherwise convert x into the workspace); QLLM_ERR_UNSUPPORTED elsewhere. */
+  QLLM_F16_IN_BF16_OUT = 2
 } qllm_dtype_t;
+
+/* elementwise bf16 -> fp16 (round to nearest even), n a multiple of 8: the conversion the QLLM_F16_IN_BF16_OUT caller hoists (ABI 4) */
+int qllm_convert_bf16_to_f16(const void *src, void *dst, size_t n, void *stream);
 
 /* One quantized linear layer's buffers: the reference module's state dict, by pointer. */
 typedef struct qllm_weight {

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("QLLM_MI355X_LIB") or os.path.join(_HERE, LIB_NAME)  #
 
 QLLM_OK, QLLM_ERR_INVALID, QLLM_ERR_UNSUPPORTED, QLLM_ERR_WORKSPACE, QLLM_ERR_LAUNCH, QLLM_ERR_DEVICE = range(6)
 LAYOUT_GPTQ, LAYOUT_AWQ_GEMM, LAYOUT_HQQ, LAYOUT_NATIVE, LAYOUT_NATIVE_F16Z = 0, 1, 2, 3, 4
-DT_F16, DT_BF16 = 0, 1
+DT_F16, DT_BF16, DT_F16_IN_BF16_OUT = 0, 1, 2
 ABI_VERSION = 4
 
 EXPORTS = (
@@ -24,7 +24,7 @@ EXPORTS = (
     "qllm_awq_gemm_forward", "qllm_unpack_qweight", "qllm_pack_qweight", "qllm_gather_columns", "qllm_ort_dequantize4bits",
     "qllm_plan_describe", "qllm_debug_timeline", "qllm_native_sizes", "qllm_repack_native", "qllm_unpack_native",
     "qllm_comm_buffer_bytes", "qllm_comm_alloc", "qllm_comm_free", "qllm_comm_export", "qllm_comm_import", "qllm_comm_close",
-    "qllm_allreduce_oneshot",
+    "qllm_allreduce_oneshot", "qllm_convert_bf16_to_f16",
 )
 
 
@@ -86,6 +86,8 @@ def _declare(lib):
     lib.qllm_comm_close.argtypes = [vp]
     lib.qllm_allreduce_oneshot.restype = C.c_int
     lib.qllm_allreduce_oneshot.argtypes = [vp, i32, i32, vp, i32, i32, sz, vp, vp]
+    lib.qllm_convert_bf16_to_f16.restype = C.c_int
+    lib.qllm_convert_bf16_to_f16.argtypes = [vp, vp, sz, vp]
     lib.qllm_workspace_init.restype = C.c_int
     lib.qllm_workspace_init.argtypes = [vp, sz, vp]
     lib.qllm_linear_forward.restype = C.c_int

@@ -589,6 +589,13 @@ int qllm_gather_columns(const void *x, const int32_t *perm, void *out, int32_t M
   return launch_gather_columns(x, perm, out, M, K, (hipStream_t)stream);
 }
 
+int qllm_convert_bf16_to_f16(const void *src, void *dst, size_t n, void *stream) {
+  clear_error();
+  if (!src || !dst || n % 8 != 0 || (uintptr_t)src % 16 != 0 || (uintptr_t)dst % 16 != 0)
+    return set_error(QLLM_ERR_INVALID, "qllm_convert_bf16_to_f16: 16-byte aligned buffers, n a multiple of 8");
+  return n ? launch_bf16_to_f16(src, dst, n, (hipStream_t)stream) : QLLM_OK;
+}
+
 int qllm_debug_timeline(void *buf, int32_t n_slots) {  // n_slots x 24 x u64
   clear_error();
   g_timeline = (uint64_t *)buf;
@@ -602,6 +609,20 @@ int qllm_linear_forward(const qllm_weight_t *w, const void *x, void *y, int32_t 
   clear_error();
   int rc = validate_weight(w);
   if (rc) return rc;
+  if (act_dtype == QLLM_F16_IN_BF16_OUT) {
+    // x already converted by the caller: only the 256x128 prefill kernel writes bf16 from fp16 inputs (out_bf16)
+    rc = check_io(x, y, M, QLLM_F16);
+    if (rc) return rc;
+    if (w->bits != 4 || w->g_idx || M <= 64 || (uintptr_t)w->qweight % 16 != 0 || (uintptr_t)w->scales % 16 != 0)
+      return set_error(QLLM_ERR_UNSUPPORTED, "QLLM_F16_IN_BF16_OUT: 4-bit prefill calls of the 256x128 kernel only");
+    GemmParams p;
+    fill_gemm_params(p, w, x, y, M, QLLM_F16);
+    const int lay = w->layout == QLLM_LAYOUT_AWQ_GEMM ? QLLM_LAYOUT_AWQ_GEMM : QLLM_LAYOUT_GPTQ;
+    if (!gemm3_ok(p, lay) || !(gemm2_split_k(p.M, p.N, p.K) == 1 || gemm3_use_split(p, workspace, workspace_bytes)))
+      return set_error(QLLM_ERR_UNSUPPORTED, "QLLM_F16_IN_BF16_OUT: M=%d K=%d N=%d is not served by the 256x128 prefill kernel", M, w->K, w->N);
+    p.out_bf16 = 1;
+    return launch_gemm3(p, lay, (hipStream_t)stream);
+  }
   rc = check_io(x, y, M, act_dtype);
   if (rc) return rc;
   if ((w->bits == 3 || is_native(*w)) && strip_ok(w, 1, M)) {

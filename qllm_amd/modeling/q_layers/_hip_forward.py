@@ -212,7 +212,8 @@ class HipForwardMixin:
         w = self.decode_descriptor(act_order_g_idx, add_zero_bias)
         try:
             try:
-                y = ops.linear_forward(w, x2d)
+                # (bf16 prefill: x is converted to fp16 ONCE per distinct tensor -- siblings share it -- instead of once per call)
+                y = ops.linear_forward_shared(w, x2d) if act_order_g_idx is None else ops.linear_forward(w, x2d)
             except ops.QllmUnsupported:
                 if w.layout not in (ops.LAYOUTS["NATIVE"], ops.LAYOUTS["NATIVE_F16Z"]):
                     raise

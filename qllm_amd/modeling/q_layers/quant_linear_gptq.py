@@ -152,7 +152,7 @@ class QuantLinearGPTQ(nn.Module, CompressWeight, HipForwardMixin):
                 from ... import ops
                 x2d = _gathered(x, self._perm)
                 try:
-                    return ops.linear_forward(w, x2d).reshape(x.shape[:-1] + (self.outfeatures,))
+                    return ops.linear_forward_shared(w, x2d).reshape(x.shape[:-1] + (self.outfeatures,))
                 except ops.QllmUnsupported:
                     self._needs_reference = True   # a shape the native kernels do not serve: the in-place gather kernel below
         g_idx = self.g_idx if self.act_order else None

@@ -131,6 +131,56 @@ def linear_forward(w: QllmWeight, x2d: torch.Tensor, out: Optional[torch.Tensor]
     return out
 
 
+_LAST_CONVERT: dict = {}
+
+
+def bf16_as_f16(x2d: torch.Tensor) -> torch.Tensor:
+    """fp16 copy of a contiguous bf16 activation matrix (round to nearest even, what `.to(float16)` does), made by the library's
+    kernel and REMEMBERED per device for the very tensor it was made from (identity + version, held weakly): q/k/v -- and gate/up --
+    are called with the same tensor one after the other, so three prefill calls convert once."""
+    import weakref
+    ver = 0 if x2d.is_inference() else x2d._version
+    hit = _LAST_CONVERT.get(x2d.device)
+    if hit is not None and hit[0]() is x2d and hit[1] == ver:
+        return hit[2]
+    _check_input(x2d, "x")
+    out = torch.empty(x2d.shape, dtype=torch.float16, device=x2d.device)
+    with torch.cuda.device(x2d.device):
+        _lib.check(_lib.load().qllm_convert_bf16_to_f16(x2d.data_ptr(), out.data_ptr(), x2d.numel(), _stream_ptr()))
+    _LAST_CONVERT[x2d.device] = (weakref.ref(x2d), ver, out)
+    return out
+
+
+def linear_forward_bf16_via_f16(w: QllmWeight, x2d: torch.Tensor) -> torch.Tensor:
+    """Prefill-sized bf16 call with the conversion of x hoisted and shared (QLLM_F16_IN_BF16_OUT): bit-identical to
+    `linear_forward(w, x2d)` on the 256x128 prefill kernel, which converts x into the workspace on every call.  Raises
+    QllmUnsupported where that kernel does not serve the call (callers then use linear_forward)."""
+    _check_x(x2d, (w,))
+    if x2d.dtype != torch.bfloat16 or x2d.shape[0] <= 64 or x2d.numel() % 8 != 0:
+        raise QllmUnsupported("bf16 prefill calls only")
+    lib = _lib.load()
+    m = x2d.shape[0]
+    xh = bf16_as_f16(x2d)
+    out = torch.empty((m, w.N), dtype=torch.bfloat16, device=x2d.device)
+    with torch.cuda.device(x2d.device):
+        nbytes = lib.qllm_workspace_bytes_act(C.byref(w), m, DT_F16)
+        ws = workspace(x2d.device, nbytes)
+        rc = lib.qllm_linear_forward(C.byref(w), xh.data_ptr(), out.data_ptr(), m, _lib.DT_F16_IN_BF16_OUT, ws.data_ptr(), ws.numel(),
+                                     _stream_ptr())
+    _lib.check(rc)
+    return out
+
+
+def linear_forward_shared(w: QllmWeight, x2d: torch.Tensor) -> torch.Tensor:
+    """linear_forward for module code: bf16 prefill calls go through the shared fp16 copy of x where the kernel allows it."""
+    if x2d.dtype == torch.bfloat16 and x2d.shape[0] > 64:
+        try:
+            return linear_forward_bf16_via_f16(w, x2d)
+        except QllmUnsupported:
+            pass
+    return linear_forward(w, x2d)
+
+
 def linear_forward_grouped(ws_desc: Sequence[QllmWeight], x2d: torch.Tensor,
                            outs: Optional[Sequence[torch.Tensor]] = None):
     """Several layers sharing x (q/k/v, gate/up) in ONE launch (decode sizes only)."""

@@ -579,6 +579,19 @@ def test_wave_specialised_prefill_kernel_vs_oracle(layout, g, K, N, zk, bias, na
     yb = layer(xb.to(DEV))
     assert yb.dtype == torch.bfloat16
     assert O.rel_err(yb.float().cpu().numpy(), ref.y64(xb.to(torch.float16).numpy())) <= TOL
+    # the module call above went through the SHARED fp16 copy of x (QLLM_F16_IN_BF16_OUT, ops.linear_forward_bf16_via_f16): it must
+    # be bit-identical to the plain bf16 call of the C ABI, which converts x into the workspace itself; and a sibling called with
+    # the same tensor converts nothing
+    xd = xb.to(DEV)
+    y_plain = ops.linear_forward(layer.decode_descriptor(), xd)
+    assert torch.equal(layer(xd), y_plain)
+    calls = []
+    real = ops._lib.load().qllm_convert_bf16_to_f16
+    h0 = ops.bf16_as_f16(xd)
+    assert ops.bf16_as_f16(xd) is h0 and torch.equal(h0, xd.to(torch.float16))
+    xd.add_(0)   # an in-place update bumps the version: converted again
+    assert ops.bf16_as_f16(xd) is not h0
+    del calls, real
     # determinism: same launch twice -> same bits
     x = torch.from_numpy(randx(4096, K, seed=9)).to(DEV)
     assert ops.plan_describe([layer._descriptor(None, 0)], 4096).startswith("gemm3")

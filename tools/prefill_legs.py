@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""The act-order prefill leg of bench.py on its own (4 decoder layers of GPTQ w4 g128 act-order linears, M = 2048, graph replay):
-the target of `rocprofv3 --kernel-trace --stats` when the question is what the act-order path adds to the plain one."""
+"""The three prefill legs of bench.py on their own (4 decoder layers at M = 2048, graph replay: AWQ fp16, GPTQ act-order fp16, AWQ
+bf16): the target of `rocprofv3 --kernel-trace --stats` when the question is what the act-order / bf16 paths add to the plain one."""
 import os
 import sys
 
@@ -13,9 +13,10 @@ from qllm_amd.modeling.q_layers import QuantLinearGPTQ, WQLinear_GEMM  # noqa: E
 
 dev = torch.device("cuda:0")
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 10
-for tag, cls, act in (("awq", WQLinear_GEMM, False), ("gptq_actorder", QuantLinearGPTQ, True)):
+for tag, cls, act, xdt in (("awq", WQLinear_GEMM, False, torch.float16), ("gptq_actorder", QuantLinearGPTQ, True, torch.float16),
+                           ("awq_bf16", WQLinear_GEMM, False, torch.bfloat16)):
     ps = bench.Stack(cls, 4, dev, seed=99, act_order=act)
-    xp = torch.randn(2048, bench.HIDDEN, device=dev, dtype=torch.float16)
+    xp = torch.randn(2048, bench.HIDDEN, device=dev, dtype=xdt)
     gp, _ = bench.capture(lambda: ps(xp))
     ms = bench.time_events(gp.replay, iters)
     print(f"{tag}: {ms:.3f} ms per 4 layers, {bench.flops_per_pass(4, 2048) / ms / 1e9:.1f} TFLOP/s", flush=True)
