@@ -289,33 +289,34 @@ __global__ __launch_bounds__((MW + 4) * 64) void gemm3_kernel(const GemmParams p
   // #kt-1): pieces 0,1 beside sub-step 3 of tile kt-1, pieces 2..7 beside sub-steps 0..2 of tile kt.  At barrier #kt the
   // pieces of tile kt+1 are older than those 8: vmcnt(8) retires exactly them.
 #define G3_SB() __builtin_amdgcn_sched_barrier(0)
+  // NP == 4 (one piece per sub-step): the piece goes BETWEEN the two halves of the sub-step's MFMAs, not behind them (round 4,
+  // profiles/logs/r04p_time_native.log: +1-2 % on all three shapes; alternating the position between the two matrix waves of a SIMD: none)
+#define G3_PIECE_MID(kt_, slot_, q8, q4) { dma_piece(kt_, slot_, NP == 8 ? q8 : q4); G3_SB(); }
+#define G3_PIECE_END(kt_, slot_, q8, q4) if constexpr (NP == 8) { dma_piece(kt_, slot_, q8); } G3_SB();
   int sa = 0;  // A ring slot of tile kt (kt % 3)
   for (int kt = 0; kt < KT; ++kt) {
     const int sb = kt & 1;
     const int sa1 = (sa == 2) ? 0 : sa + 1, sa2 = (sa == 0) ? 2 : sa - 1;  // slots of tiles kt+1, kt+2
-    // pieces per sub-step: NP / 4 (2 or 1), one behind each half (NP = 8) or behind the second half (NP = 4) of its MFMAs;
+    // pieces per sub-step: NP / 4 (2 or 1), one behind each half (NP = 8) or behind the first half (NP = 4) of its MFMAs;
     // piece indices: sub-step 3 of the previous tile took [0, NP/4), sub-steps 0..2 take the rest
     read_frags(sa, sb, 1, fa1, fb1);
     G3_SB();
     mfma_half(fa0, fb0, 0); G3_SB();
-    if constexpr (NP == 8) { dma_piece(kt + 2, sa2, 2); G3_SB(); }
+    G3_PIECE_MID(kt + 2, sa2, 2, 1)
     mfma_half(fa0, fb0, 1); G3_SB();
-    dma_piece(kt + 2, sa2, NP == 8 ? 3 : 1);  // sub-step 0
-    G3_SB();
+    G3_PIECE_END(kt + 2, sa2, 3, 1)  // sub-step 0
     read_frags(sa, sb, 2, fa0, fb0);
     G3_SB();
     mfma_half(fa1, fb1, 0); G3_SB();
-    if constexpr (NP == 8) { dma_piece(kt + 2, sa2, 4); G3_SB(); }
+    G3_PIECE_MID(kt + 2, sa2, 4, 2)
     mfma_half(fa1, fb1, 1); G3_SB();
-    dma_piece(kt + 2, sa2, NP == 8 ? 5 : 2);  // sub-step 1
-    G3_SB();
+    G3_PIECE_END(kt + 2, sa2, 5, 2)  // sub-step 1
     read_frags(sa, sb, 3, fa1, fb1);
     G3_SB();
     mfma_half(fa0, fb0, 0); G3_SB();
-    if constexpr (NP == 8) { dma_piece(kt + 2, sa2, 6); G3_SB(); }
+    G3_PIECE_MID(kt + 2, sa2, 6, 3)
     mfma_half(fa0, fb0, 1); G3_SB();
-    dma_piece(kt + 2, sa2, NP == 8 ? 7 : 3);  // sub-step 2
-    G3_SB();
+    G3_PIECE_END(kt + 2, sa2, 7, 3)  // sub-step 2
     // barrier #kt: my fragment reads of tile kt are complete (lgkmcnt(0)) and my DMA pieces of tile kt+1 have landed
     // (vmcnt(NP): only tile kt+2's are still in flight).  After it: B stage sb and A slot sa are free, tile kt+1 is complete.
     if constexpr (NP == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
@@ -325,12 +326,13 @@ __global__ __launch_bounds__((MW + 4) * 64) void gemm3_kernel(const GemmParams p
     read_frags(sa1, sb ^ 1, 0, fa0, fb0);  // past the last tile: stages nobody uses
     G3_SB();
     mfma_half(fa1, fb1, 0); G3_SB();
-    if constexpr (NP == 8) { dma_piece(kt + 3, sa, 0); G3_SB(); }
+    G3_PIECE_MID(kt + 3, sa, 0, 0)
     mfma_half(fa1, fb1, 1); G3_SB();
-    dma_piece(kt + 3, sa, NP == 8 ? 1 : 0);  // sub-step 3
-    G3_SB();
+    G3_PIECE_END(kt + 3, sa, 1, 0)  // sub-step 3
     sa = sa1;
   }
+#undef G3_PIECE_MID
+#undef G3_PIECE_END
 #undef G3_SB
   __builtin_amdgcn_s_setprio(0);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // stray DMA pieces past the last tile: land before the LDS is reused

@@ -92,10 +92,8 @@ static void free_layer(Layer &L) {
 struct Variant { const char *name; const char *g4; const char *mw; const char *pm, *pd, *pl; const char *abl; const char *dw = "4"; };
 static const Variant variants[] = {
     {"gemm3 mw8", "-1", "8", "2", "0", "0", "0"},
-    {"gemm3 mw8 dw8", "-1", "8", "2", "0", "0", "0", "8"},
     {"g4 mw8+4+4", "1", "8", "2", "0", "0", "0"},
-    {"g4 mw8A+4", "4", "8", "2", "0", "0", "0"},
-    {"g4 mw8A+8", "5", "8", "2", "0", "0", "0"},
+    {"g4 mw4+4", "0", "4", "2", "0", "0", "0"},
 };
 static const int NV = sizeof(variants) / sizeof(variants[0]);
 static void select_variant(const Variant &v) {
