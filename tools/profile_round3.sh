@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-3 evidence run on the GPU box (one gpurun call, profiling only):  bash tools/profile_round3.sh [tag]
+# Round-3 / round-4 evidence run on the GPU box (one gpurun call, profiling only):  bash tools/profile_round3.sh [tag]
 #   1. rocprofv3 --kernel-trace --stats of `bench.py --no-extra` (the headline decode step), then FETCH_SIZE / WRITE_SIZE in
 #      their own passes                                             -> gpurun_out/prof_<tag>/{trace,pmc_fetch,pmc_write}
 #   2. BASELINE configs[3] (tools/hqq_leg.py): kernel trace + FETCH_SIZE / WRITE_SIZE passes   -> .../hqq_{trace,fetch,write}
@@ -11,9 +11,9 @@ P=$R/gpurun_out/prof_$tag
 rm -rf $P; mkdir -p $P
 export TMPDIR=/tmp
 cd /tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $P/trace -o t -- python $R/bench.py --steps 20 --warmup 3 --no-extra > $P/bench_under_rocprof.json 2> $P/rocprof_trace.err
-timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $P/pmc_fetch -o f -- python $R/bench.py --steps 5 --warmup 2 --no-extra > /dev/null 2> $P/rocprof_fetch.err
-timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $P/pmc_write -o w -- python $R/bench.py --steps 5 --warmup 2 --no-extra > /dev/null 2> $P/rocprof_write.err
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $P/trace -o t -- python $R/bench.py --steps 20 --warmup 3 --no-extra --min-timed-s 0 > $P/bench_under_rocprof.json 2> $P/rocprof_trace.err
+timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $P/pmc_fetch -o f -- python $R/bench.py --steps 5 --warmup 2 --no-extra --min-timed-s 0 > /dev/null 2> $P/rocprof_fetch.err
+timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $P/pmc_write -o w -- python $R/bench.py --steps 5 --warmup 2 --no-extra --min-timed-s 0 > /dev/null 2> $P/rocprof_write.err
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $P/hqq_trace -o h -- python $R/tools/hqq_leg.py 10 > $P/hqq_leg.log 2> $P/rocprof_hqq.err
 timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $P/hqq_fetch -o f -- python $R/tools/hqq_leg.py 3 > /dev/null 2> $P/rocprof_hqq_fetch.err
 timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $P/hqq_write -o w -- python $R/tools/hqq_leg.py 3 > /dev/null 2> $P/rocprof_hqq_write.err
