@@ -91,3 +91,26 @@ def test_device_probe_fails_cleanly_without_gpu(lib):
         pytest.skip("GPU present")
     info = _lib.QllmDeviceInfo()
     assert lib.qllm_device_info(0, ctypes.byref(info)) == _lib.QLLM_ERR_DEVICE
+
+
+def test_comm_entry_points_validate_before_any_device_work(lib):
+    """One-shot all-reduce (csrc/comm.hip): the staging-buffer size is a pure function, and every argument check of the launch
+    entry point runs before the kernel is enqueued."""
+    slot = 16384
+    ctl = lib.qllm_comm_buffer_bytes(1, 0)            # the control block alone: flags [2][16] + epoch
+    assert ctl >= (2 * 16 + 1) * 4
+    for world in (1, 2, 8, 16):
+        assert lib.qllm_comm_buffer_bytes(world, slot) == 2 * world * slot + ctl
+    fake = ctypes.c_void_p(16)                        # never dereferenced: the calls below are refused first
+    call = lambda peers, rank, world, x, n, dt, sl: lib.qllm_allreduce_oneshot(peers, rank, world, x, n, dt, sl, None, None)  # noqa: E731
+    assert call(None, 0, 2, fake, 8192, _lib.DT_F16, slot) == _lib.QLLM_ERR_INVALID and "NULL" in _lib.last_error()
+    assert call(fake, 2, 2, fake, 8192, _lib.DT_F16, slot) == _lib.QLLM_ERR_INVALID and "rank" in _lib.last_error()
+    assert call(fake, 0, 17, fake, 8192, _lib.DT_F16, slot) == _lib.QLLM_ERR_INVALID
+    assert call(fake, 0, 2, fake, 8192, 7, slot) == _lib.QLLM_ERR_INVALID and "act_dtype" in _lib.last_error()
+    assert call(fake, 0, 2, fake, 8190, _lib.DT_F16, slot) == _lib.QLLM_ERR_UNSUPPORTED          # not a multiple of 8 elements
+    assert call(fake, 0, 2, fake, 16384, _lib.DT_BF16, slot) == _lib.QLLM_ERR_UNSUPPORTED        # 32 KB does not fit a 16 KB slot
+    assert call(fake, 0, 2, ctypes.c_void_p(24), 8192, _lib.DT_F16, slot) == _lib.QLLM_ERR_INVALID and "aligned" in _lib.last_error()
+    assert lib.qllm_comm_alloc(0, ctypes.byref(ctypes.c_void_p())) == _lib.QLLM_ERR_INVALID
+    assert lib.qllm_comm_export(None, None) == _lib.QLLM_ERR_INVALID
+    assert lib.qllm_comm_import(None, None) == _lib.QLLM_ERR_INVALID
+    assert lib.qllm_comm_free(None) == _lib.QLLM_OK and lib.qllm_comm_close(None) == _lib.QLLM_OK   # NULL: nothing to do
