@@ -211,7 +211,7 @@ int qllm_plan_describe(const qllm_weight_t *w, int32_t n_weights, int32_t M, int
  *     bias f16 [N] (natural order); g_idx must be NULL (act-order layers: sort the rows by group first, qllm_gather_columns)
  * Shapes: bits 3 or 4, K % 32 == 0, N % 16 == 0 (3-bit packed zero points: N % 32 == 0), group_size % 32 == 0, K % group_size == 0.
  * A descriptor with layout = QLLM_LAYOUT_NATIVE[_F16Z] is accepted by qllm_linear_forward / _grouped (M <= 64 with group size
- * 64 / 128; larger M: see qllm_plan_describe); qllm_dequant reads the reference layouts only (QLLM_ERR_UNSUPPORTED: convert
+ * 64 / 128, and -- 4 bits -- 32; larger M: see qllm_plan_describe); qllm_dequant reads the reference layouts only (QLLM_ERR_UNSUPPORTED: convert
  * back with qllm_unpack_native first).  Pure integer permutations: repack then unpack is the identity.  Counterpart in the reference: the load-time repacks of its own kernel formats (quant_linear_awq.py:95-140). */
 int qllm_native_sizes(const qllm_weight_t *src, size_t *qweight_bytes, size_t *scales_bytes, size_t *qzeros_bytes);
 int qllm_repack_native(const qllm_weight_t *src, void *qweight_out, void *scales_out, void *qzeros_out, void *stream);

@@ -93,9 +93,9 @@ def gemm_forward_cuda(x, qweight, scales, qzeros, split_k_iters):
     with torch.cuda.device(x.device):
         stream = torch.cuda.current_stream().cuda_stream
         g = K // scales.shape[0] if scales.shape[0] and K % scales.shape[0] == 0 else 0
-        # the native copy only where the strip kernels take it (group sizes 64 / 128); the caller's own qzeros tensor is the cache
+        # the native copy only where the strip kernels take it (group sizes 32 / 64 / 128); the caller's own qzeros tensor is the cache
         # key, so a non-contiguous one (its .contiguous() would be a fresh temporary per call) stays on the in-place path
-        if (0 < M <= _DECODE_MAX_M and g in (64, 128) and K % 32 == 0 and N % 16 == 0 and qweight.shape[0] == K
+        if (0 < M <= _DECODE_MAX_M and g in (32, 64, 128) and K % 32 == 0 and N % 16 == 0 and qweight.shape[0] == K
                 and scales.dtype == torch.float16 and qzeros.is_contiguous() and os.environ.get("QLLM_AWQ_DECODE_SHADOW", "1") != "0"):
             w = _native_copy(qweight, scales, s16, qzeros, K, N, g, stream)
         else:

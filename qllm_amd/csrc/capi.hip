@@ -144,9 +144,10 @@ static bool strip_plan(const qllm_weight_t *w, int n, int M, StripPlan *plan) {
     if (M > lim) return false;
   }
   if (M > 64 || strip_min_strips() <= 0) return false;
-  if (!strip_group_ok(w[0].group_size)) return false;
   const int bits = w[0].bits;
   if (bits != 4 && bits != 3) return false;
+  if (!strip_group_ok(w[0].group_size, sm, bits)) return false;
+  const bool g32 = w[0].group_size == 32;  // (native layout, 4 bits: one strip per block, lds-slab at batch 1, register-A above)
   for (int i = 0; i < n; ++i) {
     if (w[i].bits != bits || w[i].K % 32 != 0 || w[i].g_idx || is_native(w[i]) != sm) return false;
     // 3-bit: fp16 (HQQ), symmetric, or packed zero points (a column's field may straddle two words of the N*3/32-word row)
@@ -170,7 +171,7 @@ static bool strip_plan(const qllm_weight_t *w, int n, int M, StripPlan *plan) {
   // long K with 64-wide groups or 3 bits: the one-round slab variant (24 loads + 12 scale/zero pairs per lane) spills
   // 17-21 registers in a 16-wave block; the register-A variant (rounds of 8) does not
   const int ra_longk = knob("QLLM_STRIP_RA_LONGK", 1);
-  const bool longk = ra_longk && (w[0].group_size == 64 || bits == 3) && strip_spw(w[0].K, w[0].group_size, 16) > 8;
+  const bool longk = ra_longk && (w[0].group_size <= 64 || bits == 3) && strip_spw(w[0].K, w[0].group_size, 16) > 8;
   const int ra_base = (M >= ra_min) ? 1 : 0;
   if (sm) {
     // strip-major: 16-column strips only (every wave-load is 256 contiguous bytes whatever the width; narrow strips balance best)
@@ -181,7 +182,7 @@ static bool strip_plan(const qllm_weight_t *w, int n, int M, StripPlan *plan) {
     // (a register-A block re-reads all of x from L2; 64 columns share it instead of 16)
     const int sm_ra_cpl4 = knob("QLLM_SM_RA_CPL4", 1);
     // (3 bits: two strips -- four need more than 256 registers)
-    int cpl = (sm_ra_cpl4 && slab_nw == 0 && M >= 5 && M <= 16 && m64 && cols / 64 >= compute_units() / 2) ? (bits == 3 ? 2 : 4) : 1;
+    int cpl = (sm_ra_cpl4 && !g32 && slab_nw == 0 && M >= 5 && M <= 16 && m64 && cols / 64 >= compute_units() / 2) ? (bits == 3 ? 2 : 4) : 1;
     int nw = (M > 16 || cpl > 1) ? 8 : (slab_nw ? slab_nw : 16);
     // strip_dma.hpp (M = 5..32, K a multiple of 64): the activations go through LDS by DMA.  A block pulls the activations of its
     // k range through the CU's memory pipe once, a CU ingests ~55 GB/s here, so the launch costs about (rounds of blocks on the
@@ -200,7 +201,7 @@ static bool strip_plan(const qllm_weight_t *w, int n, int M, StripPlan *plan) {
       const int cus = compute_units();
       static const int cands4[] = {1, 2, 4, 6}, cands3[] = {1, 2, 4};
       const int *cands = bits == 4 ? cands4 : cands3;
-      const int n_cands = (M > 16) ? 1 : (bits == 4 ? 4 : 3);  // (two row tiles: one strip per block)
+      const int n_cands = (M > 16) ? 1 : (g32 ? 2 : (bits == 4 ? 4 : 3));  // (two row tiles: one strip per block; 3 bits: four strips at most; 32-wide groups: two)
       const double x_bytes = (double)M * w[0].K * 2, strip_bytes = (double)w[0].K * bits * 2 + (double)(w[0].K / w[0].group_size) * 64;
       int best = 1;
       double best_cost = 0;
@@ -214,9 +215,12 @@ static bool strip_plan(const qllm_weight_t *w, int n, int M, StripPlan *plan) {
         if (c == dma_cpl) { best = c; break; }                                    // (experiments: QLLM_DMA_CPL forces a width)
       }
       cpl = best;
+      // (32-wide groups, one strip per block, short K, few rows: the register-A form's 8-k-step rounds beat the three-slot ring --
+      //  4096 x 4096 at M = 4: 6.2 vs 7.7 us, M = 16: 7.8 both; tools/g32_bench.py, profiles/logs/r04r_g32_bench.log)
+      const bool g32_ra = g32 && cpl == 1 && M <= 8 && w[0].K <= 4096;
       nw = (cpl == 1 && M <= 16) ? 16 : 8;
-      const int spw = strip_spw(w[0].K, w[0].group_size, nw);
-      if (strip_lds_bytes(M, spw, nw, cpl, w[0].group_size, 2, 1) <= 156 * 1024) {
+      const int spw = (strip_spw(w[0].K, w[0].group_size, nw) + 1) & ~1;  // (the ring's slots are pairs of k-steps; only 32-wide groups can give an odd chunk)
+      if (!g32_ra && strip_lds_bytes(M, spw, nw, cpl, w[0].group_size, 2, 1) <= 156 * 1024) {
         plan->cpl = cpl;
         plan->nw = nw;
         plan->spw = spw;
@@ -572,7 +576,7 @@ int qllm_linear_forward_grouped(const qllm_weight_t *w, void *const *y, int32_t 
     if (!skinny_ok(w[i], M)) return set_error(QLLM_ERR_UNSUPPORTED, "grouped forward needs the decode kernel (4-bit, M<=%d, K%%32==0, no act-order)", skinny_max_m());
   }
   if (strip_ok(w, n_weights, M)) return run_strip(w, y, n_weights, x, M, act_dtype, (hipStream_t)stream);
-  if (is_native(w[0])) return set_error(QLLM_ERR_UNSUPPORTED, "grouped forward: native-layout layers are served for M <= 64 with group size 64 / 128 (M=%d g=%d)", M, w[0].group_size);
+  if (is_native(w[0])) return set_error(QLLM_ERR_UNSUPPORTED, "grouped forward: native-layout layers are served for M <= 64 with group size 64 / 128 (4 bits: also 32) (M=%d g=%d)", M, w[0].group_size);
   if (w[0].bits != 4) return set_error(QLLM_ERR_UNSUPPORTED, "grouped forward: no fused kernel for %d-bit weights in this shape", w[0].bits);
   return run_skinny(w, y, n_weights, x, M, act_dtype, workspace, workspace_bytes, (hipStream_t)stream);
 }

@@ -82,7 +82,7 @@ struct StripParams {
   int sm;           // 1: strip-major native layout (strip_kernel.hpp, SM): every prob[] pointer is a native-layout buffer
   uint64_t *dbg;    // diagnostics (qllm_debug_timeline): 24 timestamps for this launch (3 blocks x 8), or NULL
 };
-bool strip_group_ok(int group_size);
+bool strip_group_ok(int group_size, bool strip_major, int bits);
 int strip_nw(int K, int strips_total, int compute_units);
 int strip_sm_nw(int K, int M, int group_size, int bits);
 int strip_spw(int K, int group_size, int nw);
@@ -95,6 +95,7 @@ bool strip_x_ok(int M, int spw, int nw, int cpl, int sm);
 int launch_strip(const StripParams &p, int grid, hipStream_t stream);
 int launch_strip_sm(const StripParams &p, int grid, hipStream_t stream);     // strip_sm.hip
 int launch_strip_sm_ra(const StripParams &p, int grid, hipStream_t stream);  // strip_sm_ra.hip
+int launch_strip_dma_g32(const StripParams &p, int grid, hipStream_t stream);   // strip_dma_g32.hip
 int launch_strip_dma_g64(const StripParams &p, int grid, hipStream_t stream);   // strip_dma_g64.hip
 int launch_strip_dma_g128(const StripParams &p, int grid, hipStream_t stream);  // strip_dma_g128.hip
 

@@ -64,8 +64,11 @@ static int launch_strip_s(const StripParams &p, int grid, size_t lds, hipStream_
     return set_error(QLLM_ERR_UNSUPPORTED, "internal: g64 slab strips take chunks of <= 8 k-steps");
 }
 
-// group sizes the strip kernel serves: 64 and 128 (k-steps per group 2, 4); others use the split-K kernel
-bool strip_group_ok(int group_size) { return group_size == 64 || group_size == 128; }
+// group sizes the strip kernel serves: 64 and 128 (k-steps per group 2, 4) in every layout, 32 (one k-step per group; 4 bits) in the
+// native strip-major layout only (round 4: the TheBloke-style "32g" GPTQ checkpoints); others use the split-K kernel
+bool strip_group_ok(int group_size, bool strip_major, int bits) {
+  return group_size == 64 || group_size == 128 || (group_size == 32 && strip_major && bits == 4);
+}
 
 // row-stream waves per block: 8-wave blocks (4 per CU) when there are enough strips to need more than one round of 16-wave
 // blocks (2 per CU) and K is short enough for one 16-dword round per wave; else 16 waves

@@ -40,8 +40,12 @@ namespace qllm {
 
 // Ring slots of an instantiation: four; three for six 4-bit strips, or four 3-bit strips with packed zero points, of 64-wide groups
 // (four slots need more than 256 registers there).
-template <int CPL, int SPG, int BITS, bool ZF16>
-constexpr int strip_dma_ring() { return (SPG == 2 && (CPL >= 6 || (BITS == 3 && CPL >= 4 && !ZF16))) ? 3 : 4; }
+// 32-wide groups carry a scale / zero pair per k-step and strip: three slots for one strip, two for two strips or two row tiles.
+template <int CPL, int SPG, int BITS, bool ZF16, int MT = 1>
+constexpr int strip_dma_ring() {
+  if (SPG == 1) return (CPL >= 2 || MT >= 2) ? 2 : 3;
+  return (SPG == 2 && (CPL >= 6 || (BITS == 3 && CPL >= 4 && !ZF16))) ? 3 : 4;
+}
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -51,27 +55,27 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 // NW: waves per block; CPL: adjacent 16-column strips per block (lane (g, i) holds column i of each); SPG: k-steps per group
-// (group_size / 32: 2 or 4); BITS: 4 or 3; BF16: bf16 activations (converted after the fragment read); MT: 16-row tiles (M <= 16 MT);
+// (group_size / 32: 1 (4 bits only), 2 or 4); BITS: 4 or 3; BF16: bf16 activations (converted after the fragment read); MT: 16-row tiles (M <= 16 MT);
 // ZF16: every layer of the launch has fp16 zero points (HQQ: the native F16Z layout): the zero-point decode of a group is a shift and a
 //       conversion instead of the branch-free five-operation form that also serves packed and symmetric zeros (a sixth of the
 //       loop's VALU work at 64-wide groups).
 // All byte offsets are 32-bit: the host sends layers of 2 GB and more of packed words to the register-A form (strip_plan).
 template <int NW, int CPL, int SPG, int BITS, bool BF16, int MT, bool ZF16 = false>
 __global__ __launch_bounds__(NW * 64, NW / 4) void strip_dma_kernel(const StripParams p) {
-  static_assert(SPG == 2 || SPG == 4, "groups of 64 or 128");
-  constexpr int NS = strip_dma_ring<CPL, SPG, BITS, ZF16>();  // ring slots (stages of two k-steps)
+  static_assert(SPG == 1 || SPG == 2 || SPG == 4, "groups of 32, 64 or 128");
+  constexpr int NS = strip_dma_ring<CPL, SPG, BITS, ZF16, MT>();  // ring slots (stages of two k-steps)
   static_assert(NS >= 2 && NS <= 4 && (2 * NS) % SPG == 0, "a round of the ring is whole groups");
   constexpr int NG = 2 * NS / SPG;         // groups per round of the ring
   constexpr int TN = 16 * CPL;             // columns per block
   constexpr int WR = (BITS == 4) ? 4 : 3;  // word-rows per k-step
   constexpr int WL = (BITS == 4) ? 1 : 2;  // loads per weight fragment
   typedef __attribute__((address_space(3))) void lds_void_t;
-  // vector-memory operations of one stage request, in issue order: [the scale / zero words of the group that ENDS in this slot,]
-  // the DMA pieces, the weight words.  (SPG = 2: every slot ends a group; SPG = 4: the odd ones.)
+  // vector-memory operations of one stage request, in issue order: [the scale / zero words of the group(s) that END in this slot,]
+  // the DMA pieces, the weight words.  (SPG = 1: every slot holds two groups; SPG = 2: every slot ends one; SPG = 4: the odd ones.)
   constexpr bool Z2 = BITS == 3 && !ZF16;  // packed 3-bit zero points: the field may straddle into a second word
   constexpr int LZ = CPL * (2 + (Z2 ? 1 : 0));
   constexpr int LX = 2 * MT + 2 * CPL * WL;
-  constexpr int L_EVEN = LX + (SPG == 2 ? LZ : 0), L_ODD = LX + LZ;  // requests of an even / odd slot
+  constexpr int L_EVEN = LX + (SPG == 1 ? 2 * LZ : (SPG == 2 ? LZ : 0)), L_ODD = LX + (SPG == 1 ? 2 * LZ : LZ);  // requests of an even / odd slot
   constexpr int L_ALL = (NS / 2) * (L_EVEN + L_ODD) + (NS % 2) * L_EVEN;
   extern __shared__ __attribute__((aligned(16))) float red[];
 
@@ -195,14 +199,17 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void strip_dma_kernel(const StripP
     const bool live = kp < tend;      // wave-uniform
     const int kc = min(kp, T - 2);    // addresses stay inside the strip
     if ((2 * u + 1) % SPG == SPG - 1) {
-      const int j = (2 * u + 1) / SPG;
-      const int G = min((int)((unsigned)kc / SPG), Gmax);
 #pragma unroll
-      for (int c = 0; c < CPL; ++c) {
-        const int sg = g_strip[c] + G;
-        sc2[j][c / 2][c & 1] = __builtin_bit_cast(half_t, __builtin_amdgcn_raw_buffer_load_b16(rs_s, lane_s, sg * 32, 2));
-        zr[j][c] = __builtin_amdgcn_raw_buffer_load_b32(rs_z, lane_z, sg * z_group, 2);
-        if constexpr (Z2) zr2[j][c] = __builtin_amdgcn_raw_buffer_load_b32(rs_z, lane_z2, sg * z_group, 2);
+      for (int e = (SPG == 1 ? 0 : 1); e < 2; ++e) {  // (32-wide groups: both k-steps of the slot end a group)
+        const int j = (2 * u + e) / SPG;
+        const int G = min((int)((unsigned)(kc + (SPG == 1 ? e : 0)) / SPG), Gmax);
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+          const int sg = g_strip[c] + G;
+          sc2[j][c / 2][c & 1] = __builtin_bit_cast(half_t, __builtin_amdgcn_raw_buffer_load_b16(rs_s, lane_s, sg * 32, 2));
+          zr[j][c] = __builtin_amdgcn_raw_buffer_load_b32(rs_z, lane_z, sg * z_group, 2);
+          if constexpr (Z2) zr2[j][c] = __builtin_amdgcn_raw_buffer_load_b32(rs_z, lane_z2, sg * z_group, 2);
+        }
       }
     }
     const int so = 64 * kc;

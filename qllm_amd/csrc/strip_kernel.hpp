@@ -32,7 +32,7 @@ __device__ __forceinline__ float dpp_add(float v) {
 
 // NW: waves per block; CPL: columns per lane (1 -> 16-column strip; 4 -> 64-column strip, 256-byte row segments, 4 MFMAs per
 // k-step; row-stream only); MAXS: k-steps (weight loads) per lane per round; SPG: k-steps per quantisation group (group_size /
-// 32); XL: 16-byte activation chunks staged per lane.
+// 32: 4, 2, or -- strip-major only -- 1); XL: 16-byte activation chunks staged per lane.
 //
 // Arithmetic (the kernel was VALU-issue-bound with a per-weight fp16 dequant -- SQ_ACTIVE_INST_VALU ~ 0.9 of the SIMD issue
 // capacity -- so the per-weight work is cut to the bone):
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(NW * 64, (SM && !RA && NW <= 8) ? ((NW == 8 && MAXS
   static_assert(!ONER || (SM && !RA && XL <= 2), "one-round fold: strip-major batch-1 slab form");
   constexpr int NG = MAXS / SPG;   // groups per round (MAXS is a multiple of SPG; rounds start on a group boundary)
   constexpr int TN = 16 * CPL;     // columns per block
-  constexpr int GL = 4 * SPG;      // lanes (16-byte chunks) per group in the staging pass: 8 or 16
+  constexpr int GL = 4 * SPG;      // lanes (16-byte chunks) per group in the staging pass: 4, 8 or 16
   constexpr int WR = (BITS == 4) ? 4 : 3;  // word-rows per k-step
   typedef uint32_t wvec_t __attribute__((ext_vector_type(CPL)));
   typedef float float2_t __attribute__((ext_vector_type(2)));
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(NW * 64, (SM && !RA && NW <= 8) ? ((NW == 8 && MAXS
       // __shfl_xor's address VALU + ds_bpermute round trip (16 LDS ops per chunk at g128)
       sx = dpp_add<0xB1>(sx); sxp = dpp_add<0xB1>(sxp);
       sx = dpp_add<0x4E>(sx); sxp = dpp_add<0x4E>(sxp);
-      sx = dpp_add<0x141>(sx); sxp = dpp_add<0x141>(sxp);
+      if constexpr (GL >= 8) { sx = dpp_add<0x141>(sx); sxp = dpp_add<0x141>(sxp); }  // (GL = 4, 32-wide groups: the quad is the group)
       if constexpr (GL == 16) { sx = dpp_add<0x140>(sx); sxp = dpp_add<0x140>(sxp); }
       if (xdst[u] >= 0) {
         *(half8_t *)(xs + xdst[u]) = half8_t{q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, q3.x, q3.y};

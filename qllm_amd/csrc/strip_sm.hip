@@ -17,6 +17,10 @@ int strip_sm_nw(int K, int M, int group_size, int bits) {
   const int nw4 = knob("QLLM_SM_NW4", 0);
   const int T = K / 32;
   if (bits == 3) return T <= 128 ? 16 : 0;            // 16 waves x one round of 8 (longer chunks: register-A)
+  if (group_size == 32) {  // a scale / zero pair per k-step: batch 1, and only when a wave's chunk is exactly one round of 8 k-steps
+    if (M > 1) return 0;
+    return ((T + 3) / 4 == 8) ? 4 : (((T + 15) / 16 == 8) ? 16 : 0);   // K = 928..1024 / 3616..4096; else register-A
+  }
   if (group_size == 64) {                             // twice the scale / zero registers per round: short rounds, batch 1 only
     if (M > 1) return 0;
     return T <= 32 ? 4 : (T <= 128 ? 8 : 0);
@@ -39,6 +43,12 @@ static int launch_sm_slab(const StripParams &p, int grid, size_t lds, hipStream_
 #define QLLM_SM8(NW_, MAXS_) return launch_strip_t<NW_, 1, MAXS_, SPG, 8, BITS, false, false, 1, true, DBG>(p, grid, lds, stream)
   if constexpr (BITS == 3) {
     if (p.nw == 16 && maxs == 8) { if (small_x) { QLLM_SM1(16, 8); } else { QLLM_SM8(16, 8); } }
+  } else if constexpr (SPG == 1) {
+    // 32-wide groups: only the one-round forms (48 registers; the general-round forms spill at the 128 a 16-wave block may use)
+    if (small_x && p.spw == 8 && maxs == 8) {
+      if (p.nw == 4) return launch_strip_t<4, 1, 8, SPG, 2, BITS, false, false, 1, true, DBG, true>(p, grid, lds, stream);
+      if (p.nw == 16) return launch_strip_t<16, 1, 8, SPG, 2, BITS, false, false, 1, true, DBG, true>(p, grid, lds, stream);
+    }
   } else if constexpr (SPG == 2) {
     if (small_x) {
       if (p.nw == 4 && maxs == 8) { QLLM_SM1(4, 8); }
@@ -68,11 +78,13 @@ static int launch_sm_slab(const StripParams &p, int grid, size_t lds, hipStream_
 int launch_strip_sm(const StripParams &p, int grid, hipStream_t stream) {
   if (p.ra) return launch_strip_sm_ra(p, grid, stream);
   const size_t lds = strip_lds_bytes(p.M, p.spw, p.nw, 1, p.group_size, 0, 1);
+  if (p.bits == 3 && p.group_size == 32) return set_error(QLLM_ERR_UNSUPPORTED, "3-bit strips: group sizes 64 and 128");
   if (p.bits == 3) return p.group_size == 64 ? launch_sm_slab<2, 3, false>(p, grid, lds, stream) : launch_sm_slab<4, 3, false>(p, grid, lds, stream);
   if (p.dbg) {  // diagnostics instantiation (timeline stamps): g128 only
     if (p.group_size == 128) return launch_sm_slab<4, 4, true>(p, grid, lds, stream);
     return set_error(QLLM_ERR_UNSUPPORTED, "timeline diagnostics: group size 128 only");
   }
+  if (p.group_size == 32) return launch_sm_slab<1, 4, false>(p, grid, lds, stream);
   return p.group_size == 64 ? launch_sm_slab<2, 4, false>(p, grid, lds, stream) : launch_sm_slab<4, 4, false>(p, grid, lds, stream);
 }
 

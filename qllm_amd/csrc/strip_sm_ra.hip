@@ -26,9 +26,20 @@ static int launch_sm_ra(const StripParams &p, int grid, size_t lds, hipStream_t 
                    : launch_strip_t<16, 1, 8, SPG, 1, 4, true, BF, 1, true>(p, grid, lds, stream);
 }
 
+// 32-wide groups (4 bits): one strip per block only -- a scale / zero pair per k-step and strip leaves no registers for four
+template <bool BF>
+static int launch_sm_ra_g32(const StripParams &p, int grid, size_t lds, hipStream_t stream) {
+  if (p.bits != 4 || p.cpl != 1) return set_error(QLLM_ERR_UNSUPPORTED, "internal: g32 strip-major strips are 4-bit, one strip per block");
+  if (p.M > 32) return launch_strip_t<8, 1, 8, 1, 1, 4, true, BF, 4, true>(p, grid, lds, stream);
+  if (p.M > 16) return launch_strip_t<8, 1, 8, 1, 1, 4, true, BF, 2, true>(p, grid, lds, stream);
+  return p.nw == 8 ? launch_strip_t<8, 1, 8, 1, 1, 4, true, BF, 1, true>(p, grid, lds, stream)
+                   : launch_strip_t<16, 1, 8, 1, 1, 4, true, BF, 1, true>(p, grid, lds, stream);
+}
+
 int launch_strip_sm_ra(const StripParams &p, int grid, hipStream_t stream) {
-  if (p.ra == 2) return p.group_size == 64 ? launch_strip_dma_g64(p, grid, stream) : launch_strip_dma_g128(p, grid, stream);
+  if (p.ra == 2) return p.group_size == 32 ? launch_strip_dma_g32(p, grid, stream) : (p.group_size == 64 ? launch_strip_dma_g64(p, grid, stream) : launch_strip_dma_g128(p, grid, stream));
   const size_t lds = strip_lds_bytes(p.M, p.spw, p.nw, p.cpl, p.group_size, 1, 1);
+  if (p.group_size == 32) return p.act_bf16 ? launch_sm_ra_g32<true>(p, grid, lds, stream) : launch_sm_ra_g32<false>(p, grid, lds, stream);
   if (p.group_size == 64) return p.act_bf16 ? launch_sm_ra<2, true>(p, grid, lds, stream) : launch_sm_ra<2, false>(p, grid, lds, stream);
   return p.act_bf16 ? launch_sm_ra<4, true>(p, grid, lds, stream) : launch_sm_ra<4, false>(p, grid, lds, stream);
 }

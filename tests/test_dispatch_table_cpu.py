@@ -168,7 +168,26 @@ def test_native_layout_decode_routes(lib):
     assert plan(lib, [h3], 16).startswith("strip nw=16 cpl=1 spw=8 form=dma-A")
     assert plan(lib, [h3], 32).endswith("row_tiles=2" + sm)
     assert plan(lib, [h3], 48).startswith("gemm3") and "bits=3" in plan(lib, [h3], 48)   # (four 3-bit row tiles would need > 256 registers)
-    assert plan(lib, [W(4096, 4096, 32, layout=NATIVE)], 1).startswith("unsupported")   # group sizes the strips do not serve
+    # 32-wide groups (4 bits, native layout only): one-round lds-slab blocks at batch 1 when a wave's chunk is exactly 8 k-steps (else
+    # the register-A form); M = 2..32 the DMA form with shorter rings, blocks of one or two strips, chunks rounded to whole k-step pairs
+    g32 = lambda K, N: W(K, N, 32, layout=NATIVE)  # noqa: E731
+    assert plan(lib, [g32(4096, 4096)], 1) == "strip nw=16 cpl=1 spw=8 form=lds-slab row_tiles=1" + sm
+    assert plan(lib, [g32(4096, 4096)] * 3, 1) == "strip nw=16 cpl=1 spw=8 form=lds-slab row_tiles=1" + sm
+    assert plan(lib, [g32(1024, 8192)], 1) == "strip nw=4 cpl=1 spw=8 form=lds-slab row_tiles=1" + sm
+    assert plan(lib, [g32(11008, 4096)], 1) == "strip nw=16 cpl=1 spw=22 form=register-A row_tiles=1" + sm
+    assert plan(lib, [g32(2048, 4096)], 1) == "strip nw=16 cpl=1 spw=4 form=register-A row_tiles=1" + sm
+    for m in (2, 4, 8, 16):
+        # (one strip per block, K <= 4096, M <= 8: register-A measured faster than the three-slot ring)
+        assert plan(lib, [g32(4096, 4096)], m) == "strip nw=16 cpl=1 spw=8 form=%s row_tiles=1" % ("register-A" if m <= 8 else "dma-A") + sm
+        assert plan(lib, [g32(4096, 11008)] * 2, m) == "strip nw=8 cpl=2 spw=16 form=dma-A row_tiles=1" + sm
+        assert plan(lib, [g32(11008, 4096)], m) == "strip nw=16 cpl=1 spw=22 form=dma-A row_tiles=1" + sm
+    assert plan(lib, [g32(2112, 4096)], 16) == "strip nw=16 cpl=1 spw=6 form=dma-A row_tiles=1" + sm    # 66 k-steps over 16 waves: 5 -> 6
+    assert plan(lib, [g32(2112, 4096)], 4) == "strip nw=16 cpl=1 spw=5 form=register-A row_tiles=1" + sm
+    assert plan(lib, [g32(4096, 4096)], 32) == "strip nw=8 cpl=1 spw=16 form=dma-A row_tiles=2" + sm
+    assert plan(lib, [g32(4096, 4096)], 64) == "strip nw=8 cpl=1 spw=16 form=register-A row_tiles=4" + sm
+    assert plan(lib, [W(4096, 4096, 32, 3, NATIVE)], 1).startswith("unsupported")       # 3 bits: 64 / 128 only
+    assert plan(lib, [W(4096, 4096, 32)], 1).startswith("skinny")                       # reference layouts in place: the split-K kernel
+    assert plan(lib, [W(4096, 4096, 256, layout=NATIVE)], 1).startswith("unsupported")  # group sizes the strips do not serve
     assert plan(lib, [W(128, 4096, layout=NATIVE)], 1).startswith("unsupported")        # K shorter than one round of 8 k-steps
 
 

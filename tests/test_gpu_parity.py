@@ -212,8 +212,11 @@ def test_prefill_kernel_vs_oracle(layout, g, K, N, zk, act, bias):
         assert O.rel_err(y, ref.y64(x)) <= 2e-3, (layout, K, N, m)
 
 
-def test_act_order_decode_sizes():
-    d = synth("GPTQ", 4, 128, 4096, 4096, "asym", True, False, seed=21)
+@pytest.mark.parametrize("g", [128, 32])
+def test_act_order_decode_sizes(g):
+    """(g = 32: the "32g act-order" GPTQ checkpoints -- strips on the native copy of the group-sorted rows since round 4)"""
+    from qllm_amd import ops
+    d = synth("GPTQ", 4, g, 4096, 4096, "asym", True, False, seed=21)
     layer = to_layer(d, DEV)
     assert layer.act_order is None
     w = oracle_w(d)
@@ -222,6 +225,7 @@ def test_act_order_decode_sizes():
         y = layer(torch.from_numpy(x).to(DEV)).cpu().numpy()
         assert layer.act_order is True
         assert O.rel_err(y, oracle_y(d, x, w)) <= TOL
+        assert ops.plan_describe([layer.native_descriptor(0)], m).startswith("strip ")
 
 
 @pytest.mark.parametrize("g,K,N,zk", [(64, 4096, 4096, "asym"), (128, 4096, 11008, "asym"), (64, 11008, 4096, "sym")])

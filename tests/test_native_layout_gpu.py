@@ -1,7 +1,7 @@
 """-m gpu: the library's native (strip-major) layout.  qllm_repack_native against the numpy restatement of the layout
 (oracle/ref_cpu.native_layout, from the integer grids the oracle recovers from the reference-minted goldens), unpack(repack(x)) == x
 bit for bit for every source layout, and the decode kernels on native descriptors against the oracle (every zero-point kind, 3 and
-4 bits, g64 / g128, bias, AutoGPTQ offset, M = 1 .. 64, grouped launches)."""
+4 bits, g64 / g128 and -- 4 bits -- g32, bias, AutoGPTQ offset, M = 1 .. 64, grouped launches)."""
 import ctypes as C
 
 import numpy as np
@@ -65,6 +65,10 @@ CASES = [  # layout, bits, g, K, N, zero kind, bias
     ("GPTQ", 4, 128, 4096, 1024, "sym", True), ("HQQ", 4, 64, 4096, 4096, "asym", False), ("HQQ", 3, 64, 4096, 4096, "asym", True),
     ("GPTQ", 3, 128, 4096, 4096, "asym", False), ("GPTQ", 4, 64, 2048, 1152, "asym", False), ("GEMM", 4, 64, 1024, 512, "asym", True),
     ("GPTQ", 4, 128, 8192, 1024, "asym", False), ("HQQ", 4, 64, 11008, 4096, "asym", False), ("GPTQ", 4, 128, 1024, 8192, "asym", False),
+    # 32-wide groups (round 4): one-round lds-slab blocks at batch 1 (K = 4096: 16 waves, K = 1024: 4; other K: register-A), the DMA form with
+    # shorter rings at M = 2..32 (K = 2112: a 5-k-step chunk rounded to whole pairs), register-A above
+    ("GPTQ", 4, 32, 4096, 4096, "asym", False), ("GPTQ", 4, 32, 11008, 4096, "asym", True), ("GEMM", 4, 32, 1024, 512, "asym", True),
+    ("HQQ", 4, 32, 2048, 1152, "asym", False), ("GPTQ", 4, 32, 4096, 1024, "sym", True), ("GPTQ", 4, 32, 2112, 4096, "asym", False),
 ]
 
 
@@ -100,10 +104,11 @@ def test_native_decode_kernels_vs_oracle(layout, bits, g, K, N, zk, bias):
             assert O.rel_err(yb, ref.y64(xb.float().cpu().numpy().astype(np.float16))) <= 2e-2, (mb, ops.plan_describe([w], mb))
 
 
-def test_native_grouped_launch_and_autogptq_offset():
+@pytest.mark.parametrize("g", [128, 32])
+def test_native_grouped_launch_and_autogptq_offset(g):
     """q/k/v-like group (unequal widths) in one launch on native descriptors; add_zero_bias = 1 (COMPATIBLE_WITH_AUTOGPTQ)."""
     from qllm_amd import ops
-    ds = [synth("GPTQ", 4, 128, 4096, n, seed=80 + i, bias=(i == 2)) for i, n in enumerate((4096, 1024, 512))]
+    ds = [synth("GPTQ", 4, g, 4096, n, seed=80 + i, bias=(i == 2)) for i, n in enumerate((4096, 1024, 512))]
     layers = [to_layer(d, DEV) for d in ds]
     for compat in (0, 1):
         ws = [l.native_descriptor(compat) for l in layers]
@@ -115,7 +120,7 @@ def test_native_grouped_launch_and_autogptq_offset():
                 assert O.rel_err(o.cpu().numpy(), Ref(dict(d, compat=compat)).y16(x)) <= 1e-2, (compat, m)
 
 
-@pytest.mark.parametrize("layout,bits,g", [("HQQ", 4, 64), ("HQQ", 3, 64), ("GPTQ", 3, 128), ("GEMM", 4, 128)])
+@pytest.mark.parametrize("layout,bits,g", [("HQQ", 4, 64), ("HQQ", 3, 64), ("GPTQ", 3, 128), ("GEMM", 4, 128), ("GPTQ", 4, 32)])
 @pytest.mark.parametrize("widths", [(4096, 4096, 4096), (11008, 11008), (5152, 5152)])
 def test_native_multi_strip_blocks_at_batch_16(layout, bits, g, widths):
     """M = 5..16 on wide grouped launches (BASELINE configs[3]: HQQ g64, mixed 3 / 4 bits, batch 16): blocks of several adjacent
@@ -128,9 +133,11 @@ def test_native_multi_strip_blocks_at_batch_16(layout, bits, g, widths):
     for m in (5, 16):
         plan = ops.plan_describe(ws, m)
         assert "form=dma-A" in plan and "layout=strip-major" in plan, plan
-        if widths[0] in (4096, 5152):
+        if g == 32:             # (32-wide groups: blocks of two strips at most)
+            assert "cpl=2" in plan, plan
+        elif widths[0] in (4096, 5152):
             assert "cpl=4" in plan, plan
-        if widths[0] == 11008:  # (3 bits: four strips at most, two when the activation rows are few)
+        elif widths[0] == 11008:  # (3 bits: four strips at most, two when the activation rows are few)
             assert ("cpl=6" in plan) if bits == 4 else ("cpl=4" in plan or "cpl=2" in plan), plan
         x = randx(m, 4096, seed=m)
         outs = ops.linear_forward_grouped(ws, torch.from_numpy(x).to(DEV))
