@@ -60,6 +60,27 @@ def test_repack_matches_the_layout_definition_and_round_trips(name):
             assert np.array_equal(O.gptq_int_zeros(oz.cpu().numpy(), 4, g["N"], 0), z)
 
 
+@pytest.mark.parametrize("layout,g,K,N", [("GPTQ", 32, 1024, 512), ("GEMM", 32, 2048, 1152), ("HQQ", 32, 1024, 1024), ("GPTQ", 256, 1024, 512)])
+def test_repack_of_other_group_sizes_matches_the_layout_definition(layout, g, K, N):
+    """The goldens stop at g64 / g128; the layout is generic in the group size (any multiple of 32): 32-wide groups (served by the
+    strip kernels since round 4) and 256-wide ones (held natively, decoded by the prefill kernels only) on synthetic layers."""
+    from qllm_amd import ops
+    d = synth(layout, 4, g, K, N, seed=g + K)
+    layer = to_layer(d, DEV)
+    layer._descriptor(None, 0)
+    nat, nkeep = ops.repack_native(layer._desc, layer._desc_keep)
+    q, z, zf = _ints(dict(d, layout=layout, bits=4))
+    want_q, want_s, want_z = O.native_layout(q, d["scales"], z, 4, zf)
+    assert np.array_equal(nkeep[0].cpu().numpy().reshape(want_q.shape), want_q.view(np.int32))
+    assert np.array_equal(nkeep[1].cpu().numpy().reshape(want_s.shape).view(np.uint16), want_s.view(np.uint16))
+    got_z = nkeep[2].cpu().numpy().reshape(want_z.shape)
+    assert np.array_equal(got_z.view(np.uint16) if zf else got_z, want_z.view(np.uint16) if zf else want_z)
+    back = ops.unpack_native(nat, nkeep, layout)
+    assert torch.equal(back[0], layer.qweight.reshape(back[0].shape))
+    assert torch.equal(back[1].view(torch.int16), layer.scales.view(torch.int16))
+    assert torch.equal(back[2].view(torch.int16) if zf else back[2], layer.qzeros.view(torch.int16) if zf else layer.qzeros)
+
+
 CASES = [  # layout, bits, g, K, N, zero kind, bias
     ("GPTQ", 4, 128, 4096, 4096, "asym", False), ("GPTQ", 4, 128, 11008, 4096, "asym", True), ("GEMM", 4, 128, 4096, 11008, "asym", False),
     ("GPTQ", 4, 128, 4096, 1024, "sym", True), ("HQQ", 4, 64, 4096, 4096, "asym", False), ("HQQ", 3, 64, 4096, 4096, "asym", True),
