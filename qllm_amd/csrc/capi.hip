@@ -7,6 +7,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+
 #include "kernels.hpp"
 
 namespace qllm {
@@ -128,6 +130,9 @@ struct StripPlan {
 static uint64_t *g_timeline = nullptr;
 static int g_timeline_slots = 0, g_timeline_next = 0;
 
+// the mid-batch panel kernel (panel.hip): native 4-bit layers, M from QLLM_PANEL_MIN_M (33) to 128 rows
+static int panel_min_m() { return knob("QLLM_PANEL_MIN_M", 33); }
+
 static bool strip_plan(const qllm_weight_t *w, int n, int M, StripPlan *plan) {
   // measured (graph replay, us; split-K kernel -> strips with 2 / 4 row tiles): M=32: 4096x4096 28.3 -> 13.4, 4096x11008 54.9 -> 36.3,
   // 11008x4096 50.1 -> 30.3; M=64: 33.8 -> 22.6, 52.5 -> 61.5, 48.1 -> 53.9 -- four row tiles only pay on the small shape
@@ -142,6 +147,10 @@ static bool strip_plan(const qllm_weight_t *w, int n, int M, StripPlan *plan) {
     //  40 on the 11008-wide shapes: the same line as for the reference layouts)
     const int lim = max_m ? max_m : ((w[0].K <= 4096 && cols_all <= 4096 && !(sm && w[0].bits == 3)) ? 64 : 32);
     if (M > lim) return false;
+    // (single native 4-bit layers: the panel kernel takes over where it is served -- panel.hip; grouped launches stay here)
+    if (n == 1 && sm && w[0].bits == 4 && knob("QLLM_PANEL", 1) && M >= panel_min_m() && w[0].K % 64 == 0 && w[0].N % 64 == 0 && !w[0].g_idx &&
+        (w[0].group_size == 32 || w[0].group_size == 64 || w[0].group_size == 128))
+      return false;  // (M <= 64 here: every such layer is served by panel_ok)
   }
   if (M > 64 || strip_min_strips() <= 0) return false;
   const int bits = w[0].bits;
@@ -481,10 +490,28 @@ static int run_tile_gemm(GemmParams &p, int layout, void *workspace, size_t work
 }
 
 // prefill-sized calls (M > 64) on native-layout layers: the same tile GEMMs, their staging waves reading the strip-major words
+static bool panel_serves(const qllm_weight_t *w, const GemmParams &p) {
+  return knob("QLLM_PANEL", 1) && w->bits == 4 && is_native(*w) && p.M >= panel_min_m() && panel_ok(p);
+}
+static int run_panel(GemmParams &p, void *workspace, size_t workspace_bytes, hipStream_t stream) {
+  // split-K when the panels alone leave CUs idle and the caller's workspace can hold the partial panels (else: no split)
+  const int S = panel_split_k(p.M, p.N, p.K, p.group_size);
+  const size_t need = kCounterBytes + panel_slab_bytes(p.M, p.N, S);
+  p.split_k = 1;
+  p.slabs = nullptr;
+  p.counters = nullptr;
+  if (S > 1 && workspace && workspace_bytes >= need && (uintptr_t)workspace % 256 == 0 && p.N / 64 <= (int)(kCounterBytes / sizeof(int))) {
+    p.split_k = S;
+    p.counters = (int *)workspace;
+    p.slabs = (float *)((char *)workspace + kCounterBytes);
+  }
+  return launch_panel(p, stream);
+}
+
 static bool native_prefill_ok(const qllm_weight_t *w, GemmParams &p) {
   if ((uintptr_t)w->qweight % 16 || (uintptr_t)w->scales % 16 || (w->qzeros && (uintptr_t)w->qzeros % 8)) return false;
   if (w->bits == 3) return gemm3_ok(p, kGemm3Rows3Bit);
-  return w->bits == 4 && gemm2_ok(p, QLLM_LAYOUT_GPTQ);
+  return w->bits == 4 && (panel_serves(w, p) || gemm2_ok(p, QLLM_LAYOUT_GPTQ));
 }
 static int native_prefill(const qllm_weight_t *w, const void *x, void *y, int M, int act_dtype, void *workspace, size_t workspace_bytes,
                           hipStream_t stream) {
@@ -497,6 +524,7 @@ static int native_prefill(const qllm_weight_t *w, const void *x, void *y, int M,
     gemm3_use_split(p, workspace, workspace_bytes);
     return launch_gemm3(p, kGemm3Rows3Bit, stream);
   }
+  if (panel_serves(w, p)) return run_panel(p, workspace, workspace_bytes, stream);
   return run_tile_gemm(p, QLLM_LAYOUT_GPTQ, workspace, workspace_bytes, stream);
 }
 
@@ -546,6 +574,7 @@ size_t qllm_workspace_bytes_act(const qllm_weight_t *w, int32_t M, int32_t act_d
     p.g_idx = nullptr;
     const bool g3 = gemm3_ok(p, w->bits == 3 ? kGemm3Rows3Bit : (w->layout == QLLM_LAYOUT_AWQ_GEMM ? QLLM_LAYOUT_AWQ_GEMM : QLLM_LAYOUT_GPTQ));
     tiles = align_up(gemm2_slab_bytes(M, w->N, gemm2_split_k(M, w->N, w->K)), 256) + (g3 ? bf16_copy_bytes(M, w->K, act_dtype == QLLM_BF16) : 0);
+    if (M <= 128 && w->N % 64 == 0) tiles = std::max(tiles, align_up(panel_slab_bytes(M, w->N, panel_split_k(M, w->N, w->K, w->group_size)), 256));
     if (M > 64) return kCounterBytes + tiles;
   }
   const size_t slabs = align_up((size_t)skinny_max_split(M) * M * w->N * sizeof(float), 256);
@@ -735,6 +764,9 @@ int qllm_plan_describe(const qllm_weight_t *w, int32_t n_weights, int32_t M, int
       const int S = have_workspace ? gemm3_split_k(M, w[0].N, w[0].K) : 1;
       if (S > 1) snprintf(buf, buflen, "gemm3 tile=256x128 matrix-waves=8 staging-waves=4 bits=3 split_k=%d layout=strip-major", S);
       else snprintf(buf, buflen, "gemm3 tile=256x128 matrix-waves=8 staging-waves=4 bits=3 layout=strip-major");
+    } else if (panel_serves(&w[0], p)) {
+      snprintf(buf, buflen, "panel cols=64 row_tiles=%d k_halves=%d split_k=%d layout=strip-major", M <= 64 ? 4 : 8, panel_kh(M),
+               have_workspace ? panel_split_k(M, w[0].N, w[0].K, w[0].group_size) : 1);
     } else {
       const int S2 = gemm2_split_k(M, w[0].N, w[0].K), S3 = gemm3_split_k(M, w[0].N, w[0].K);
       if (gemm3_ok(p, QLLM_LAYOUT_GPTQ) && (S2 == 1 || (have_workspace && S3 > 1))) {

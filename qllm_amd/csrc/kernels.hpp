@@ -136,6 +136,13 @@ int gemm2_tile_n(int M, int N, int split_k);
 size_t gemm2_slab_bytes(int M, int N, int S);
 int launch_gemm2(const GemmParams &p, int layout, hipStream_t stream);
 
+// ---- panel.hip (33 <= M <= 128 on the native layout: 64-column panels, A tiles shared through LDS, B fragments from registers) ----
+bool panel_ok(const GemmParams &p);
+int panel_kh(int M);
+int panel_split_k(int M, int N, int K, int group_size);
+size_t panel_slab_bytes(int M, int N, int S);
+int launch_panel(const GemmParams &p, hipStream_t stream);
+
 // ---- gemm3.hip (256x128 tile, 4 matrix waves + 4 staging waves; no split-K) ---------------------------------------------
 constexpr int kGemm3Rows3Bit = 100;  // `layout` value for launch_gemm3 / gemm3_ok: GPTQ / HQQ row stream with 3-bit weights
 bool gemm3_ok(const GemmParams &p, int layout);

@@ -148,11 +148,22 @@ def test_native_layout_decode_routes(lib):
     assert plan(lib, [W(8192, 28672, layout=NATIVE)] * 2, 16) == "strip nw=8 cpl=6 spw=32 form=dma-A row_tiles=1" + sm
     assert plan(lib, [W(28672, 8192, layout=NATIVE)], 16) == "strip nw=8 cpl=2 spw=112 form=dma-A row_tiles=1" + sm
     assert plan(lib, [W(8192, 1024, layout=NATIVE), W(8192, 128, layout=NATIVE), W(8192, 128, layout=NATIVE)], 16) == "strip nw=16 cpl=1 spw=16 form=dma-A row_tiles=1" + sm
-    assert plan(lib, [attn], 64) == "strip nw=8 cpl=1 spw=16 form=register-A row_tiles=4" + sm
+    # 33 <= M <= 128, single 4-bit layers: the panel kernel (panel.hip, round 4): 64-column panels, two K halves per block up to 64
+    # rows, split over K until the panels cover the CUs (at least two K-tiles per part); grouped launches keep the four-row-tile strips
+    assert plan(lib, [attn], 33) == plan(lib, [attn], 64) == "panel cols=64 row_tiles=4 k_halves=2 split_k=4" + sm
+    assert plan(lib, [attn], 65) == plan(lib, [attn], 128) == "panel cols=64 row_tiles=8 k_halves=1 split_k=4" + sm
+    assert plan(lib, [attn], 64, have_ws=0) == "panel cols=64 row_tiles=4 k_halves=2 split_k=1" + sm      # no workspace: no split
+    assert plan(lib, [attn], 129) == "gemm2 tile=256x128 split_k=8" + sm
+    assert plan(lib, [W(4096, 1024, layout=NATIVE)] * 3, 64) == "strip nw=8 cpl=1 spw=16 form=register-A row_tiles=4" + sm
+    assert plan(lib, [attn] * 3, 64).startswith("unsupported")   # (wide grouped launches above 32 rows: the modules call layer by layer)
+    assert plan(lib, [W(4096, 4096, 64, layout=NATIVE_F16Z)], 48) == "panel cols=64 row_tiles=4 k_halves=2 split_k=4" + sm
+    assert plan(lib, [W(4096, 4032, layout=NATIVE)], 48) == "panel cols=64 row_tiles=4 k_halves=2 split_k=4" + sm   # N % 64 == 0 is enough
+    assert plan(lib, [W(4096, 4048, layout=NATIVE)], 48).startswith("strip ")                                        # ... N % 16 is not
     # strip_dma's byte offsets are 32-bit: a layer of 2 GB of packed words stays on the register-A form (64-bit pointers)
     assert "form=register-A" in plan(lib, [W(65536, 65536, layout=NATIVE)], 16) and "form=dma-A" in plan(lib, [W(65536, 32768, layout=NATIVE)], 16)
-    assert plan(lib, [up], 64) == "gemm2 tile=256x128 split_k=2" + sm      # 33..64 rows on the wide shapes: the tile GEMM
-    assert plan(lib, [down], 33) == "gemm2 tile=256x128 split_k=8" + sm
+    assert plan(lib, [up], 64) == "panel cols=64 row_tiles=4 k_halves=2 split_k=1" + sm     # 172 panels: no cross-block sum at all
+    assert plan(lib, [down], 33) == "panel cols=64 row_tiles=4 k_halves=2 split_k=4" + sm   # 344 k-steps in 8 parts of 44
+    assert plan(lib, [up], 128) == "panel cols=64 row_tiles=8 k_halves=1 split_k=1" + sm
     # shard shapes of Llama-2-70B (TP = 8): short K -> 4-wave blocks, K = 8192 -> 8 waves x one round of 32
     assert plan(lib, [W(1024, 8192, layout=NATIVE)], 1).startswith("strip nw=4 cpl=1 spw=8 form=lds-slab")
     assert plan(lib, [W(8192, 1024, layout=NATIVE)], 1).startswith("strip nw=8 cpl=1 spw=32 form=lds-slab")
@@ -184,7 +195,9 @@ def test_native_layout_decode_routes(lib):
     assert plan(lib, [g32(2112, 4096)], 16) == "strip nw=16 cpl=1 spw=6 form=dma-A row_tiles=1" + sm    # 66 k-steps over 16 waves: 5 -> 6
     assert plan(lib, [g32(2112, 4096)], 4) == "strip nw=16 cpl=1 spw=5 form=register-A row_tiles=1" + sm
     assert plan(lib, [g32(4096, 4096)], 32) == "strip nw=8 cpl=1 spw=16 form=dma-A row_tiles=2" + sm
-    assert plan(lib, [g32(4096, 4096)], 64) == "strip nw=8 cpl=1 spw=16 form=register-A row_tiles=4" + sm
+    assert plan(lib, [g32(4096, 4096)], 64) == "panel cols=64 row_tiles=4 k_halves=2 split_k=4" + sm
+    assert plan(lib, [g32(4096, 4096)], 65) == "gemm2 tile=256x128 split_k=8" + sm   # (eight row tiles of 32-wide groups are not built)
+    assert plan(lib, [g32(4096, 1024)] * 2, 64) == "strip nw=8 cpl=1 spw=16 form=register-A row_tiles=4" + sm
     assert plan(lib, [W(4096, 4096, 32, 3, NATIVE)], 1).startswith("unsupported")       # 3 bits: 64 / 128 only
     assert plan(lib, [W(4096, 4096, 32)], 1).startswith("skinny")                       # reference layouts in place: the split-K kernel
     assert plan(lib, [W(4096, 4096, 256, layout=NATIVE)], 1).startswith("unsupported")  # group sizes the strips do not serve

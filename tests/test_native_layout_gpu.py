@@ -172,6 +172,51 @@ def test_native_multi_strip_blocks_at_batch_16(layout, bits, g, widths):
         assert O.rel_err(o.float().cpu().numpy(), Ref(d).y64(xb.float().cpu().numpy().astype(np.float16))) <= 2e-2
 
 
+PANEL_CASES = [  # layout, g, K, N, zero kind, bias
+    ("GPTQ", 128, 4096, 4096, "asym", False), ("GPTQ", 128, 11008, 4096, "asym", True), ("GEMM", 128, 4096, 11008, "asym", False),
+    ("HQQ", 64, 4096, 4096, "asym", True), ("GPTQ", 32, 2048, 1152, "asym", False), ("GPTQ", 128, 4096, 1024, "sym", True),
+    ("GPTQ", 64, 2112, 4096, "asym", False), ("GEMM", 64, 1024, 512, "asym", True),
+]
+
+
+@pytest.mark.parametrize("layout,g,K,N,zk,bias", PANEL_CASES)
+def test_panel_kernel_vs_oracle(layout, g, K, N, zk, bias):
+    """33 <= M <= 128 on native 4-bit layers: the panel kernel (csrc/panel.hip: 64-column panels, A tiles shared through LDS, B
+    fragments q - z from registers, split-K partial panels through the workspace).  Every zero-point kind, g32 / g64 / g128, a K whose
+    k-steps do not fill the last K-tile or split (2112 = 66 k-steps), bias, fp16 and bf16 activations, against the oracle."""
+    from qllm_amd import ops
+    d = synth(layout, 4, g, K, N, zk, False, bias, seed=K + N + g)
+    d["scales"] = (d["scales"].astype(np.float32) * (4096 / K) ** 0.5 * 0.5).astype(np.float16)
+    layer = to_layer(d, DEV)
+    if zk == "sym":
+        layer._descriptor(None, 0)
+        src = ops.make_weight("GPTQ", layer.qweight, layer.scales, None, None, layer.bias, K, N, g, 4, 0)
+        w, keep = ops.repack_native(*src)[0:2]
+    else:
+        w = layer.native_descriptor(0)
+    ref = Ref(d)
+    for m in (33, 48, 64, 65, 100, 128):
+        if g == 32 and m > 64:   # (eight row tiles of 32-wide groups are not built: the 256-row tiles take over at 65 rows)
+            assert ops.plan_describe([w], m).startswith("gemm"), (m, ops.plan_describe([w], m))
+            continue
+        assert ops.plan_describe([w], m).startswith("panel "), (m, ops.plan_describe([w], m))
+        x = randx(m, K, seed=m)
+        y = ops.linear_forward(w, torch.from_numpy(x).to(DEV)).cpu().numpy()
+        assert np.isfinite(y.astype(np.float32)).all()
+        assert O.rel_err(y, ref.y16(x)) <= 1e-2, (m, ops.plan_describe([w], m))
+        assert O.rel_err(y.astype(np.float64), ref.y64(x)) <= 2e-3, (m, ops.plan_describe([w], m))
+    # repeated calls re-use the workspace's arrival counters (the last arriver re-arms them)
+    x = randx(64, K, seed=5)
+    xt = torch.from_numpy(x).to(DEV)
+    y0 = ops.linear_forward(w, xt)
+    for _ in range(3):
+        assert torch.equal(ops.linear_forward(w, xt), y0)
+    for mb in (40, 128 if g != 32 else 64):
+        xb = torch.from_numpy(randx(mb, K, seed=9)).to(DEV).to(torch.bfloat16)
+        yb = ops.linear_forward(w, xb).float().cpu().numpy()
+        assert O.rel_err(yb, ref.y64(xb.float().cpu().numpy().astype(np.float16))) <= 2e-2, mb
+
+
 def test_native_layout_is_what_the_modules_decode_from():
     """The module path: decode-sized forwards stream the native copy (plan text), prefill-sized ones the reference buffers; the
     state dict is untouched and QLLM_NATIVE_LAYOUT=0 keeps everything in place."""
