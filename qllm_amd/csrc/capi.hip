@@ -130,8 +130,14 @@ struct StripPlan {
 static uint64_t *g_timeline = nullptr;
 static int g_timeline_slots = 0, g_timeline_next = 0;
 
-// the mid-batch panel kernel (panel.hip): native 4-bit layers, M from QLLM_PANEL_MIN_M (33) to 128 rows
-static int panel_min_m() { return knob("QLLM_PANEL_MIN_M", 33); }
+// the mid-batch panel kernel (panel.hip): single native 4-bit layers, M from QLLM_PANEL_MIN_M (17) to 128 rows -- and from 9 rows
+// where K >= 2 N (one-strip strip blocks pull all of x through every CU there).  us per linear, strips -> panel
+// (profiles/r04_mid_m.md): M = 32: 11.0 -> 10.7 (4096 x 4096), 23.8 -> 15.9 (4096 x 11008), 20.8 -> 16.0 (11008 x 4096);
+// M = 16: 8.0 -> 8.2, 11.5 -> 12.9, 13.4 -> 12.0 (g64: 15.6 -> 13.3); M = 8: 7.3 -> 8.2, 11.0 -> 13.0, 12.3 -> 12.0
+static bool panel_rows_ok(int M, int K, int N) {
+  const int min_m = knob("QLLM_PANEL_MIN_M", 17);
+  return M >= min_m || (min_m == 17 && M >= 9 && K >= 2 * N);
+}
 
 static bool strip_plan(const qllm_weight_t *w, int n, int M, StripPlan *plan) {
   // measured (graph replay, us; split-K kernel -> strips with 2 / 4 row tiles): M=32: 4096x4096 28.3 -> 13.4, 4096x11008 54.9 -> 36.3,
@@ -148,7 +154,7 @@ static bool strip_plan(const qllm_weight_t *w, int n, int M, StripPlan *plan) {
     const int lim = max_m ? max_m : ((w[0].K <= 4096 && cols_all <= 4096 && !(sm && w[0].bits == 3)) ? 64 : 32);
     if (M > lim) return false;
     // (single native 4-bit layers: the panel kernel takes over where it is served -- panel.hip; grouped launches stay here)
-    if (n == 1 && sm && w[0].bits == 4 && knob("QLLM_PANEL", 1) && M >= panel_min_m() && w[0].K % 64 == 0 && w[0].N % 64 == 0 && !w[0].g_idx &&
+    if (n == 1 && sm && w[0].bits == 4 && knob("QLLM_PANEL", 1) && panel_rows_ok(M, w[0].K, w[0].N) && w[0].K % 64 == 0 && w[0].N % 64 == 0 && !w[0].g_idx &&
         (w[0].group_size == 32 || w[0].group_size == 64 || w[0].group_size == 128))
       return false;  // (M <= 64 here: every such layer is served by panel_ok)
   }
@@ -491,7 +497,7 @@ static int run_tile_gemm(GemmParams &p, int layout, void *workspace, size_t work
 
 // prefill-sized calls (M > 64) on native-layout layers: the same tile GEMMs, their staging waves reading the strip-major words
 static bool panel_serves(const qllm_weight_t *w, const GemmParams &p) {
-  return knob("QLLM_PANEL", 1) && w->bits == 4 && is_native(*w) && p.M >= panel_min_m() && panel_ok(p);
+  return knob("QLLM_PANEL", 1) && w->bits == 4 && is_native(*w) && panel_rows_ok(p.M, p.K, p.N) && panel_ok(p);
 }
 static int run_panel(GemmParams &p, void *workspace, size_t workspace_bytes, hipStream_t stream) {
   // split-K when the panels alone leave CUs idle and the caller's workspace can hold the partial panels (else: no split)
@@ -574,9 +580,11 @@ size_t qllm_workspace_bytes_act(const qllm_weight_t *w, int32_t M, int32_t act_d
     p.g_idx = nullptr;
     const bool g3 = gemm3_ok(p, w->bits == 3 ? kGemm3Rows3Bit : (w->layout == QLLM_LAYOUT_AWQ_GEMM ? QLLM_LAYOUT_AWQ_GEMM : QLLM_LAYOUT_GPTQ));
     tiles = align_up(gemm2_slab_bytes(M, w->N, gemm2_split_k(M, w->N, w->K)), 256) + (g3 ? bf16_copy_bytes(M, w->K, act_dtype == QLLM_BF16) : 0);
-    if (M <= 128 && w->N % 64 == 0) tiles = std::max(tiles, align_up(panel_slab_bytes(M, w->N, panel_split_k(M, w->N, w->K, w->group_size)), 256));
-    if (M > 64) return kCounterBytes + tiles;
+    if (M > 64 && M > 128) return kCounterBytes + tiles;
   }
+  // the panel kernel's partial panels (single native 4-bit layers, 9..128 rows)
+  if (M >= 9 && M <= 128 && w->N % 64 == 0) tiles = std::max(tiles, align_up(panel_slab_bytes(M, w->N, panel_split_k(M, w->N, w->K, w->group_size)), 256));
+  if (M > 64) return kCounterBytes + tiles;
   const size_t slabs = align_up((size_t)skinny_max_split(M) * M * w->N * sizeof(float), 256);
   return kCounterBytes + (tiles > slabs ? tiles : slabs);
 }
@@ -765,7 +773,7 @@ int qllm_plan_describe(const qllm_weight_t *w, int32_t n_weights, int32_t M, int
       if (S > 1) snprintf(buf, buflen, "gemm3 tile=256x128 matrix-waves=8 staging-waves=4 bits=3 split_k=%d layout=strip-major", S);
       else snprintf(buf, buflen, "gemm3 tile=256x128 matrix-waves=8 staging-waves=4 bits=3 layout=strip-major");
     } else if (panel_serves(&w[0], p)) {
-      snprintf(buf, buflen, "panel cols=64 row_tiles=%d k_halves=%d split_k=%d layout=strip-major", M <= 64 ? 4 : 8, panel_kh(M),
+      snprintf(buf, buflen, "panel cols=64 row_tiles=%d k_halves=%d split_k=%d layout=strip-major", panel_mt(M), panel_kh(M),
                have_workspace ? panel_split_k(M, w[0].N, w[0].K, w[0].group_size) : 1);
     } else {
       const int S2 = gemm2_split_k(M, w[0].N, w[0].K), S3 = gemm3_split_k(M, w[0].N, w[0].K);

@@ -136,8 +136,9 @@ int gemm2_tile_n(int M, int N, int split_k);
 size_t gemm2_slab_bytes(int M, int N, int S);
 int launch_gemm2(const GemmParams &p, int layout, hipStream_t stream);
 
-// ---- panel.hip (33 <= M <= 128 on the native layout: 64-column panels, A tiles shared through LDS, B fragments from registers) ----
+// ---- panel.hip (17 <= M <= 128, and long-K layers from 9 rows, on the native layout: 64-column panels, A tiles shared through LDS, B fragments from registers) ----
 bool panel_ok(const GemmParams &p);
+int panel_mt(int M);
 int panel_kh(int M);
 int panel_split_k(int M, int N, int K, int group_size);
 size_t panel_slab_bytes(int M, int N, int S);

@@ -1,4 +1,5 @@
-// Mid-batch "panel" kernel (round 4): y[M, N] = x[M, K] . dequant(W4) for 33 <= M <= 128 on the strip-major native layout.
+// Mid-batch "panel" kernel (round 4): y[M, N] = x[M, K] . dequant(W4) for 17 <= M <= 128 (from 9 rows where K >= 2 N) on the
+// strip-major native layout.
 //
 // Why: between the strip kernels (M <= 32: every block re-reads ALL of x, which grows with M) and the 256-row prefill tiles there
 // was a hole -- gemm2 / gemm3 run 27-40 us per Llama-2-7B linear from M = 33 to M = 256 whatever M is, because their B tiles go
@@ -8,7 +9,7 @@
 //   * block = a PANEL of 64 columns (wave w: the 16-column strip 4 panel + w) over a K range: all of K, or one of S splits when
 //     the panels alone do not cover the CUs; up to 64 rows the block has EIGHT waves -- waves 4..7 run the same four strips over
 //     the second half of the block's K range with A buffers of their own, and the two halves are summed through LDS (half the
-//     cross-block splits for the same waves in flight); 16 MT rows (MT = 4 or 8 row tiles of v_mfma_f32_16x16x32_f16);
+//     cross-block splits for the same waves in flight); 16 MT rows (MT = 1, 2, 4 or 8 row tiles of v_mfma_f32_16x16x32_f16);
 //   * A: K-tiles of 8 k-steps go into LDS ONCE per block by LDS-DMA (1 KB pieces of 8 rows x 128 B, the
 //     XOR-swizzled [k-pair][row tile][16 rows][128 B] image of strip_dma.hpp, a quarter of the pieces per wave), double-buffered:
 //     tile t+1 is requested right after the barrier that publishes tile t; all four waves read the same fragments (ds_read_b128,
@@ -46,7 +47,7 @@ __global__ __launch_bounds__(kPanelWaves * KH * 64, 1) void panel_kernel(const G
   constexpr int NGT = KTS / SPG;              // groups per tile
   constexpr int TILE_BYTES = KP * MT * 2048;  // one A buffer: [k-pair][row tile][16 rows][128 B]
   constexpr int PPW = KP * MT * 2 / NW;       // 1 KB DMA pieces per wave and tile
-  constexpr int NMT = MT / 2;                 // distinct row tiles among a wave's pieces
+  constexpr int NMT = MT >= 2 ? MT / 2 : 1;   // distinct row tiles among a wave's pieces
   constexpr int PCOLS = 16 * CPL * NW;        // columns of a panel
   constexpr int EPS = PCOLS + 8;              // epilogue row stride in halves (16-byte aligned, bank-spread)
   static_assert(KTS % SPG == 0 && PPW * NW == KP * MT * 2, "tile geometry");
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(kPanelWaves * KH * 64, 1) void panel_kernel(const G
   int a_voff[NMT];
 #pragma unroll
   for (int u = 0; u < NMT; ++u) {
-    const int mt = ((wave >> 1) + 2 * u) % MT;
+    const int mt = (MT == 1) ? 0 : ((wave >> 1) + 2 * u) % MT;
     const int r = 8 * ph + (lane >> 3);
     a_voff[u] = min(16 * mt + r, M - 1) * p.K * 2 + (((lane & 7) ^ lds_row_swizzle(r)) << 4);
   }
@@ -259,7 +260,7 @@ __global__ __launch_bounds__(kPanelWaves * KH * 64, 1) void panel_kernel(const G
 
   // ---- split-K: fp32 partial panels through write-through slabs + one ticket per panel; the last arriver sums in split order ----
   if (S > 1 && !(abl & 8)) {
-    int &s_ticket = *(int *)(smem + 48 * 1024);  // (past the epilogue's staging rows, inside the smallest A allocation of 64 KB)
+    int &s_ticket = *(int *)(smem + MT * 4096);  // (past the hand-off area of the K halves and the epilogue's staging rows; the A buffers are MT x 16 KB or more)
     constexpr int WREGS = MT * CPL * 4;
     float *slab = p.slabs + ((size_t)panel * S + ksplit) * (size_t)(NW * WREGS * 64) + (size_t)wave * (WREGS * 64) + lane;
     if (kh == 0) {
@@ -348,11 +349,13 @@ int launch_g(const GemmParams &p, int grid, hipStream_t stream) {
 
 // native strip-major 4-bit layers, whole 64-column panels, whole k-step pairs, the group sizes of the strips
 bool panel_ok(const GemmParams &p) {
-  return p.sm && !p.g_idx && p.M >= 17 && p.M <= 128 && p.K % 64 == 0 && p.N % 64 == 0 &&
+  return p.sm && !p.g_idx && p.M >= 2 && p.M <= 128 && p.K % 64 == 0 && p.N % 64 == 0 &&
          ((p.group_size == 32 && p.M <= 64) || p.group_size == 64 || p.group_size == 128) && p.K % p.group_size == 0 &&
          (double)p.K * p.N / 2 < 2147483648.0;
 }
 
+// row tiles of 16 the kernel is built for: 1, 2, 4, 8
+int panel_mt(int M) { return M <= 16 ? 1 : (M <= 32 ? 2 : (M <= 64 ? 4 : 8)); }
 // K halves inside a block: two up to 64 rows (128 KB of A buffers), one above (eight row tiles: two halves would not fit)
 int panel_kh(int M) { return M <= 64 ? 2 : 1; }
 // blocks per panel along K: one block per CU; at least two K-tiles (16 k-steps) per K part (split x half); at most 8
@@ -365,7 +368,7 @@ int panel_split_k(int M, int N, int K, int group_size) {
   if (S > max_s) S = max_s < 1 ? 1 : max_s;
   return S;
 }
-size_t panel_slab_bytes(int M, int N, int S) { return S > 1 ? (size_t)(N / 64) * S * kPanelWaves * (M <= 64 ? 4 : 8) * 256 * sizeof(float) : 0; }
+size_t panel_slab_bytes(int M, int N, int S) { return S > 1 ? (size_t)(N / 64) * S * kPanelWaves * (M <= 64 ? 4 : 8) * 256 * sizeof(float) : 0; }  // (sized for four row tiles up to 64 rows)
 
 int launch_panel(const GemmParams &p, hipStream_t stream) {
   const int S = (p.split_k > 1 && p.slabs && p.counters) ? p.split_k : 1;
@@ -373,6 +376,8 @@ int launch_panel(const GemmParams &p, hipStream_t stream) {
   q.split_k = S;
   q.stagger = knob("QLLM_PANEL_ABL", 0);  // (lab builds: timing-only ablations)
   const int grid = (p.N / 64) * S;
+  if (p.M <= 16) return p.act_bf16 ? launch_g<1, 2, true>(q, grid, stream) : launch_g<1, 2, false>(q, grid, stream);
+  if (p.M <= 32) return p.act_bf16 ? launch_g<2, 2, true>(q, grid, stream) : launch_g<2, 2, false>(q, grid, stream);
   if (p.M <= 64) return p.act_bf16 ? launch_g<4, 2, true>(q, grid, stream) : launch_g<4, 2, false>(q, grid, stream);
   return p.act_bf16 ? launch_g<8, 1, true>(q, grid, stream) : launch_g<8, 1, false>(q, grid, stream);
 }

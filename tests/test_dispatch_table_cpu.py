@@ -131,7 +131,10 @@ def test_native_layout_decode_routes(lib):
     # M = 2..32: strip_dma.hpp (activations through LDS by DMA); one strip per 16-wave block while the strips fit one round of CUs
     for m in (2, 4, 5, 16):
         assert plan(lib, [attn], m) == "strip nw=16 cpl=1 spw=8 form=dma-A row_tiles=1" + sm
-        assert plan(lib, [down], m) == "strip nw=16 cpl=1 spw=24 form=dma-A row_tiles=1" + sm
+        # K >= 2 N from 9 rows: the panel kernel (a one-strip block pulls all of x through its CU: 13.4 -> 12.0 us at M = 16)
+        assert plan(lib, [down], m) == ("strip nw=16 cpl=1 spw=24 form=dma-A row_tiles=1" if m < 9 else "panel cols=64 row_tiles=1 k_halves=2 split_k=4") + sm
+    assert plan(lib, [W(11008, 4096, 64, 4, NATIVE_F16Z)], 16) == "panel cols=64 row_tiles=1 k_halves=2 split_k=4" + sm   # (BASELINE configs[3] down_proj)
+    assert plan(lib, [W(11008, 4096, 64, 3, NATIVE_F16Z)], 16).startswith("strip ")                                       # (3 bits: strips)
     # ... wide (grouped) launches: blocks of several adjacent strips share one activation stream -- as many as make the launch ONE
     # round of blocks: q/k/v 768 strips -> 192 blocks of four; gate/up 1376 strips -> 230 blocks of six, the last of each layer ragged
     assert plan(lib, [attn] * 3, 16) == "strip nw=8 cpl=4 spw=16 form=dma-A row_tiles=1" + sm
@@ -140,13 +143,16 @@ def test_native_layout_decode_routes(lib):
     assert plan(lib, [W(4096, 11008, 64, 4, NATIVE_F16Z)] * 2, 16) == "strip nw=8 cpl=6 spw=16 form=dma-A row_tiles=1" + sm
     assert plan(lib, [W(4096, 4096, 64, 3, NATIVE_F16Z)] * 3, 16) == "strip nw=8 cpl=4 spw=16 form=dma-A row_tiles=1" + sm
     assert plan(lib, [W(4096, 11008, 64, 3, NATIVE_F16Z)] * 2, 16) == "strip nw=8 cpl=4 spw=16 form=dma-A row_tiles=1" + sm  # 3 bits: four at most
-    assert plan(lib, [attn], 32) == "strip nw=8 cpl=1 spw=16 form=dma-A row_tiles=2" + sm
+    assert plan(lib, [attn], 32) == plan(lib, [attn], 17) == "panel cols=64 row_tiles=2 k_halves=2 split_k=4" + sm   # single layers from 17 rows
+    assert plan(lib, [up], 24) == "panel cols=64 row_tiles=2 k_halves=2 split_k=1" + sm
+    assert plan(lib, [attn] * 3, 32) == "strip nw=8 cpl=1 spw=16 form=dma-A row_tiles=2" + sm                          # grouped: strips
     # Llama-2-70B shapes at batch 16: 512 strips -> 256 blocks of two; q/k/v (GQA) 640 strips -> 160 blocks of four; gate/up 3584
     # strips -> six per block; the TP = 8 shards of q/k/v (80 strips) stay one strip per 16-wave block
     assert plan(lib, [W(8192, 8192, layout=NATIVE)], 16) == "strip nw=8 cpl=2 spw=32 form=dma-A row_tiles=1" + sm
     assert plan(lib, [W(8192, 8192, layout=NATIVE), W(8192, 1024, layout=NATIVE), W(8192, 1024, layout=NATIVE)], 16) == "strip nw=8 cpl=4 spw=32 form=dma-A row_tiles=1" + sm
     assert plan(lib, [W(8192, 28672, layout=NATIVE)] * 2, 16) == "strip nw=8 cpl=6 spw=32 form=dma-A row_tiles=1" + sm
-    assert plan(lib, [W(28672, 8192, layout=NATIVE)], 16) == "strip nw=8 cpl=2 spw=112 form=dma-A row_tiles=1" + sm
+    assert plan(lib, [W(28672, 8192, layout=NATIVE)], 8) == "strip nw=8 cpl=2 spw=112 form=dma-A row_tiles=1" + sm
+    assert plan(lib, [W(28672, 8192, layout=NATIVE)], 16) == "panel cols=64 row_tiles=1 k_halves=2 split_k=2" + sm   # K >= 2 N, 9+ rows
     assert plan(lib, [W(8192, 1024, layout=NATIVE), W(8192, 128, layout=NATIVE), W(8192, 128, layout=NATIVE)], 16) == "strip nw=16 cpl=1 spw=16 form=dma-A row_tiles=1" + sm
     # 33 <= M <= 128, single 4-bit layers: the panel kernel (panel.hip, round 4): 64-column panels, two K halves per block up to 64
     # rows, split over K until the panels cover the CUs (at least two K-tiles per part); grouped launches keep the four-row-tile strips
@@ -160,7 +166,7 @@ def test_native_layout_decode_routes(lib):
     assert plan(lib, [W(4096, 4032, layout=NATIVE)], 48) == "panel cols=64 row_tiles=4 k_halves=2 split_k=4" + sm   # N % 64 == 0 is enough
     assert plan(lib, [W(4096, 4048, layout=NATIVE)], 48).startswith("strip ")                                        # ... N % 16 is not
     # strip_dma's byte offsets are 32-bit: a layer of 2 GB of packed words stays on the register-A form (64-bit pointers)
-    assert "form=register-A" in plan(lib, [W(65536, 65536, layout=NATIVE)], 16) and "form=dma-A" in plan(lib, [W(65536, 32768, layout=NATIVE)], 16)
+    assert "form=register-A" in plan(lib, [W(65536, 65536, layout=NATIVE)], 16) and "form=dma-A" in plan(lib, [W(65536, 32768, layout=NATIVE)], 8)
     assert plan(lib, [up], 64) == "panel cols=64 row_tiles=4 k_halves=2 split_k=1" + sm     # 172 panels: no cross-block sum at all
     assert plan(lib, [down], 33) == "panel cols=64 row_tiles=4 k_halves=2 split_k=4" + sm   # 344 k-steps in 8 parts of 44
     assert plan(lib, [up], 128) == "panel cols=64 row_tiles=8 k_halves=1 split_k=1" + sm
@@ -191,10 +197,11 @@ def test_native_layout_decode_routes(lib):
         # (one strip per block, K <= 4096, M <= 8: register-A measured faster than the three-slot ring)
         assert plan(lib, [g32(4096, 4096)], m) == "strip nw=16 cpl=1 spw=8 form=%s row_tiles=1" % ("register-A" if m <= 8 else "dma-A") + sm
         assert plan(lib, [g32(4096, 11008)] * 2, m) == "strip nw=8 cpl=2 spw=16 form=dma-A row_tiles=1" + sm
-        assert plan(lib, [g32(11008, 4096)], m) == "strip nw=16 cpl=1 spw=22 form=dma-A row_tiles=1" + sm
+        assert plan(lib, [g32(11008, 4096)], m) == ("strip nw=16 cpl=1 spw=22 form=dma-A row_tiles=1" if m < 9 else "panel cols=64 row_tiles=1 k_halves=2 split_k=4") + sm
     assert plan(lib, [g32(2112, 4096)], 16) == "strip nw=16 cpl=1 spw=6 form=dma-A row_tiles=1" + sm    # 66 k-steps over 16 waves: 5 -> 6
     assert plan(lib, [g32(2112, 4096)], 4) == "strip nw=16 cpl=1 spw=5 form=register-A row_tiles=1" + sm
-    assert plan(lib, [g32(4096, 4096)], 32) == "strip nw=8 cpl=1 spw=16 form=dma-A row_tiles=2" + sm
+    assert plan(lib, [g32(4096, 4096)], 32) == "panel cols=64 row_tiles=2 k_halves=2 split_k=4" + sm
+    assert plan(lib, [g32(4096, 1024)] * 2, 32) == "strip nw=8 cpl=1 spw=16 form=dma-A row_tiles=2" + sm
     assert plan(lib, [g32(4096, 4096)], 64) == "panel cols=64 row_tiles=4 k_halves=2 split_k=4" + sm
     assert plan(lib, [g32(4096, 4096)], 65) == "gemm2 tile=256x128 split_k=8" + sm   # (eight row tiles of 32-wide groups are not built)
     assert plan(lib, [g32(4096, 1024)] * 2, 64) == "strip nw=8 cpl=1 spw=16 form=register-A row_tiles=4" + sm

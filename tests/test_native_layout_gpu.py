@@ -175,13 +175,13 @@ def test_native_multi_strip_blocks_at_batch_16(layout, bits, g, widths):
 PANEL_CASES = [  # layout, g, K, N, zero kind, bias
     ("GPTQ", 128, 4096, 4096, "asym", False), ("GPTQ", 128, 11008, 4096, "asym", True), ("GEMM", 128, 4096, 11008, "asym", False),
     ("HQQ", 64, 4096, 4096, "asym", True), ("GPTQ", 32, 2048, 1152, "asym", False), ("GPTQ", 128, 4096, 1024, "sym", True),
-    ("GPTQ", 64, 2112, 4096, "asym", False), ("GEMM", 64, 1024, 512, "asym", True),
+    ("GPTQ", 64, 2112, 4096, "asym", False), ("GEMM", 64, 1024, 512, "asym", True), ("HQQ", 64, 11008, 4096, "asym", False),
 ]
 
 
 @pytest.mark.parametrize("layout,g,K,N,zk,bias", PANEL_CASES)
 def test_panel_kernel_vs_oracle(layout, g, K, N, zk, bias):
-    """33 <= M <= 128 on native 4-bit layers: the panel kernel (csrc/panel.hip: 64-column panels, A tiles shared through LDS, B
+    """17 <= M <= 128 (from 9 rows where K >= 2 N) on native 4-bit layers: the panel kernel (csrc/panel.hip: 64-column panels, A tiles shared through LDS, B
     fragments q - z from registers, split-K partial panels through the workspace).  Every zero-point kind, g32 / g64 / g128, a K whose
     k-steps do not fill the last K-tile or split (2112 = 66 k-steps), bias, fp16 and bf16 activations, against the oracle."""
     from qllm_amd import ops
@@ -195,7 +195,10 @@ def test_panel_kernel_vs_oracle(layout, g, K, N, zk, bias):
     else:
         w = layer.native_descriptor(0)
     ref = Ref(d)
-    for m in (33, 48, 64, 65, 100, 128):
+    for m in (9, 16, 17, 24, 32, 33, 48, 64, 65, 100, 128):
+        if m < 17 and K < 2 * N:  # (few rows: only where K >= 2 N)
+            assert ops.plan_describe([w], m).startswith("strip "), (m, ops.plan_describe([w], m))
+            continue
         if g == 32 and m > 64:   # (eight row tiles of 32-wide groups are not built: the 256-row tiles take over at 65 rows)
             assert ops.plan_describe([w], m).startswith("gemm"), (m, ops.plan_describe([w], m))
             continue
