@@ -471,6 +471,12 @@ def main():
             g, _ = capture(lambda: [l(x) for l in ls])
             ms = time_events(g.replay, 20) / len(ls)
             extra[f"decode_{name}"] = {"us": round(ms * 1e3, 2), "GBps": round(alg_bytes(K, N, 1) / ms / 1e6, 1)}
+            # the same layers at batch 64 (between the BASELINE configs: continuous-batching decode; csrc/panel.hip since round 4)
+            x64 = torch.randn(64, K, device=dev, dtype=torch.float16)
+            g, _ = capture(lambda: [l(x64) for l in ls])
+            ms = time_events(g.replay, 20) / len(ls)
+            extra[f"batch64_{name}"] = {"us": round(ms * 1e3, 2), "GBps": round(alg_bytes(K, N, 64) / ms / 1e6, 1),
+                                        "TFLOPs": round(2.0 * 64 * K * N / ms / 1e9, 1)}
         # the other launch forms of the same step (all through the modules): 7 launches per layer; the reference buffers in place
         for tag, fz, native in (("ungrouped", False, True), ("fused_reference_layout_in_place", True, False)):
             stack.set_fused(fz)

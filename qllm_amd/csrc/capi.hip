@@ -157,6 +157,14 @@ static bool strip_plan(const qllm_weight_t *w, int n, int M, StripPlan *plan) {
     if (n == 1 && sm && w[0].bits == 4 && knob("QLLM_PANEL", 1) && panel_rows_ok(M, w[0].K, w[0].N) && w[0].K % 64 == 0 && w[0].N % 64 == 0 && !w[0].g_idx &&
         (w[0].group_size == 32 || w[0].group_size == 64 || w[0].group_size == 128))
       return false;  // (M <= 64 here: every such layer is served by panel_ok)
+    // (very wide groups -- gate/up of a 7B model, 22016 columns -- from 17 rows: layer by layer on the panel kernel beats the grouped
+    //  two-row-tile strips, 29.4 against 40-43.5 us; q/k/v, 12288 columns, stays grouped: 21.8-23.2 against 25.2.  r04_mid_m.md)
+    if (n > 1 && sm && w[0].bits == 4 && knob("QLLM_PANEL", 1) && M >= 17 && cols_all > 16384 && w[0].K % 64 == 0 &&
+        (w[0].group_size == 32 || w[0].group_size == 64 || w[0].group_size == 128)) {
+      bool all64 = true;
+      for (int i = 0; i < n; ++i) all64 = all64 && w[i].N % 64 == 0 && !w[i].g_idx;
+      if (all64) return false;
+    }
   }
   if (M > 64 || strip_min_strips() <= 0) return false;
   const int bits = w[0].bits;

@@ -35,6 +35,7 @@ class SiblingGroup:
         self._azb = 0
         self._parked: dict = {}
         self._misses = 0     # consecutive grouped launches whose parked outputs nobody collected (see forward_for)
+        self._refused_from = GROUP_MAX_M + 1  # smallest row count the grouped entry point refused for this group (see forward_for)
         self.grouped_launches = 0  # diagnostics / tests
 
     def describe(self, m: int = 1) -> str:
@@ -73,12 +74,18 @@ class SiblingGroup:
         if not self.enabled:
             return None
         x2d = x.reshape(-1, x.shape[-1])
-        if x2d.shape[0] > GROUP_MAX_M or x2d.shape[0] == 0 or not x2d.is_contiguous() or not self.compatible():
+        m = x2d.shape[0]
+        if m > GROUP_MAX_M or m >= self._refused_from or m == 0 or not x2d.is_contiguous() or not self.compatible():
             return None
         try:
             outs = ops.linear_forward_grouped([l.decode_descriptor(None, add_zero_bias) for l in self.layers], x2d)
         except ops.QllmUnsupported:
-            self.enabled = False  # this group's shape has no grouped kernel: never ask again
+            # no grouped kernel for this many rows (wide groups above 32 rows: the layers run one by one, panel.hip): do not ask
+            # again from here up -- but keep grouping the smaller batches.  (Round 4: this used to switch the group off for good,
+            # so one 40-token prefill cost every later decode step its grouped launches.)  Refused at one row: nothing to keep.
+            self._refused_from = m
+            if m == 1:
+                self.enabled = False
             return None
         self.grouped_launches += 1
         shape = x.shape[:-1]

@@ -181,6 +181,30 @@ def test_sibling_group_switches_itself_off_when_nobody_collects():
     assert not g.enabled
 
 
+def test_a_mid_batch_call_does_not_cost_the_group_its_decode_launches():
+    """Round 4: q/k/v of a 7B model (12288 columns) have no grouped kernel above 32 rows -- the layers then run one by one (the panel
+    kernel) -- and that refusal must not switch the group off: a 40-token prefill is followed by thousands of one-row decode steps."""
+    from qllm_amd.modeling.q_layers import fuse_siblings
+    ds = [synth("GEMM", 4, 128, H, H, seed=30 + i) for i in range(3)]
+    layers = [to_layer(d, DEV) for d in ds]
+    g = fuse_siblings(layers)
+    x1 = torch.from_numpy(randx(1, H, seed=1)).to(DEV)
+    [l(x1) for l in layers]
+    assert g.grouped_launches == 1
+    x40 = torch.from_numpy(randx(40, H, seed=2)).to(DEV)
+    outs = [l(x40) for l in layers]                        # refused by the grouped entry point: three launches of their own
+    assert g.grouped_launches == 1 and g.enabled
+    for o, d in zip(outs, ds):
+        assert O.rel_err(o.cpu().numpy(), Ref(d).y16(x40.cpu().numpy())) <= 1e-2
+    [l(x40.clone()) for l in layers]                       # ... and not asked again at that size
+    assert g.grouped_launches == 1
+    x1b = torch.from_numpy(randx(1, H, seed=3)).to(DEV)
+    outs = [l(x1b) for l in layers]
+    assert g.grouped_launches == 2 and g.enabled           # decode is grouped as before
+    for o, d in zip(outs, ds):
+        assert O.rel_err(o.cpu().numpy(), Ref(d).y16(x1b.cpu().numpy())) <= 1e-2
+
+
 def test_sibling_groups_use_one_grouped_launch_and_match_single_launches():
     from qllm_amd import ops
     from qllm_amd.modeling.q_layers import fuse_siblings

@@ -146,6 +146,8 @@ def test_native_layout_decode_routes(lib):
     assert plan(lib, [attn], 32) == plan(lib, [attn], 17) == "panel cols=64 row_tiles=2 k_halves=2 split_k=4" + sm   # single layers from 17 rows
     assert plan(lib, [up], 24) == "panel cols=64 row_tiles=2 k_halves=2 split_k=1" + sm
     assert plan(lib, [attn] * 3, 32) == "strip nw=8 cpl=1 spw=16 form=dma-A row_tiles=2" + sm                          # grouped: strips
+    assert plan(lib, [up] * 2, 16) == "strip nw=8 cpl=6 spw=16 form=dma-A row_tiles=1" + sm
+    assert plan(lib, [up] * 2, 17).startswith("unsupported")   # very wide groups from 17 rows: layer by layer on the panel kernel
     # Llama-2-70B shapes at batch 16: 512 strips -> 256 blocks of two; q/k/v (GQA) 640 strips -> 160 blocks of four; gate/up 3584
     # strips -> six per block; the TP = 8 shards of q/k/v (80 strips) stay one strip per 16-wave block
     assert plan(lib, [W(8192, 8192, layout=NATIVE)], 16) == "strip nw=8 cpl=2 spw=32 form=dma-A row_tiles=1" + sm
