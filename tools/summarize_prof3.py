@@ -26,7 +26,7 @@ ROLES = [("q/k/v (one grouped launch)", 3 * alg(H, H)), ("o_proj", alg(H, H)), (
 
 
 def short(name):
-    return name.split("(")[0].replace("void ", "")
+    return name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
 
 
 rows = list(csv.DictReader(open(glob.glob(f"{src}/trace/*kernel_stats.csv")[0])))
@@ -125,10 +125,12 @@ if ht:
         m = re.search(r"strip_dma_kernel<([^>]*)>", name)
         if m:
             return int(m.group(1).split(",")[3])
+        if "panel_kernel<" in name:  # csrc/panel.hip: 4 bits only
+            return 4
         m = re.search(r"strip_kernel<([^>]*)>", name)
         return int(m.group(1).split(",")[5]) if m else 0
     def ours(name):
-        return "qllm::strip_kernel" in name or "qllm::strip_dma_kernel" in name
+        return "qllm::strip_kernel" in name or "qllm::strip_dma_kernel" in name or "panel_kernel<" in name
     names = ["q/k/v (one grouped launch)", "o_proj", "gate/up (one grouped launch)", "down_proj"]
     shapes = [(H, 3 * H), (H, H), (H, 2 * I), (I, H)]
     tr = [r for r in csv.DictReader(open(ht[0])) if ours(r["Kernel_Name"])]
@@ -177,7 +179,8 @@ if ht:
             ta += a
         Q += ["", f"Sum of the four medians: {tm:.2f} us per decoder layer; algorithmic bytes per layer {ta / 1e6:.1f} MB = "
               f"{ta / tm / 1e6:.2f} TB/s = {ta / tm / 1e6 / 8.0:.3f} of 8 TB/s.",
-              "Template arguments of `strip_dma_kernel`: <waves per block, strips per block, k-steps per group, bits, bf16 activations, row tiles, fp16-zero-point form>.", ""]
+              "Template arguments of `strip_dma_kernel`: <waves per block, strips per block, k-steps per group, bits, bf16 activations, row tiles, fp16-zero-point form>; "
+              "of `panel_kernel` (csrc/panel.hip; round 4: down_proj, K >= 2 N): <row tiles, strips per wave, K halves per block, k-steps per group, bf16 activations, fp16-zero-point form>.", ""]
     notes = f"{out}/{tag}_hqq_notes.md"
     if os.path.exists(notes):
         Q += [l.rstrip("\n") for l in open(notes)]
