@@ -130,8 +130,9 @@ int qllm_workspace_init(void *workspace, size_t bytes, void *stream);
 /* ---- the hot path -------------------------------------------------------------------------------------- */
 /* y[M,N] = x[M,K] . dequant(w) (+ bias).  x, y in `act_dtype`; scales/bias stay f16 (bf16 activations are
  * converted on load, replacing the reference's bf16->f16 shims, ort_ops.cc:119-138, quant_linear_awq.py:29-36).
- * Dispatch: M <= 32 (<= 64 on small shapes) -> weight-streaming MFMA matvec (HBM-bound); larger M -> LDS-tiled MFMA GEMM
- * (qllm_plan_describe names the kernel; profiles/r03_mid_m.md holds the measurements behind the lines).
+ * Dispatch: M <= 32 (<= 64 on small shapes) -> weight-streaming MFMA matvec (HBM-bound); native 4-bit layers at 17 <= M <= 128 ->
+ * the panel kernel (activation tiles shared through LDS, weight fragments from registers); larger M -> LDS-tiled MFMA GEMM
+ * (qllm_plan_describe names the kernel; profiles/r03_mid_m.md, r04_mid_m.md hold the measurements behind the lines).
  * Fused widths: 4 bits everywhere; 3 bits (GPTQ / HQQ row stream; fp16, symmetric or packed zero points) for M <= 64 and, with
  * K % 64 == 0, N % 128 == 0 and fp16 activations, for every larger M; every other width / shape returns QLLM_ERR_UNSUPPORTED and the
  * caller takes the reference's own two-step branch (qllm_dequant + a dense GEMM, quant_linear_gptq.py:81-85).
@@ -141,7 +142,9 @@ int qllm_linear_forward(const qllm_weight_t *w, const void *x, void *y, int32_t 
 
 /* n_weights layers that share the SAME input x (q/k/v, gate/up) in ONE launch: y[i] = x . dequant(w[i]).
  * `w` and `y` are HOST arrays of length n_weights (<= 8); all w[i] must agree on K, bits, layout family and
- * group_size.  M <= 64 only (decode); QLLM_ERR_UNSUPPORTED otherwise. */
+ * group_size.  Decode and mid-batch sizes: M <= 32 (<= 64 for narrow groups) on the strip kernels; native 4-bit layers (N % 64 == 0,
+ * K % 64 == 0, group size 32 to 64 rows / 64 / 128) up to M = 128 in one launch of the panel kernel, split-K partials in the
+ * workspace (qllm_workspace_bytes of the widest layer x n_weights covers it); QLLM_ERR_UNSUPPORTED otherwise: call layer by layer. */
 int qllm_linear_forward_grouped(const qllm_weight_t *w, void *const *y, int32_t n_weights, const void *x,
                                 int32_t M, int32_t act_dtype, void *workspace, size_t workspace_bytes,
                                 void *stream);

@@ -157,12 +157,12 @@ static bool strip_plan(const qllm_weight_t *w, int n, int M, StripPlan *plan) {
     if (n == 1 && sm && w[0].bits == 4 && knob("QLLM_PANEL", 1) && panel_rows_ok(M, w[0].K, w[0].N) && w[0].K % 64 == 0 && w[0].N % 64 == 0 && !w[0].g_idx &&
         (w[0].group_size == 32 || w[0].group_size == 64 || w[0].group_size == 128))
       return false;  // (M <= 64 here: every such layer is served by panel_ok)
-    // (very wide groups -- gate/up of a 7B model, 22016 columns -- from 17 rows: layer by layer on the panel kernel beats the grouped
-    //  two-row-tile strips, 29.4 against 40-43.5 us; q/k/v, 12288 columns, stays grouped: 21.8-23.2 against 25.2.  r04_mid_m.md)
-    if (n > 1 && sm && w[0].bits == 4 && knob("QLLM_PANEL", 1) && M >= 17 && cols_all > 16384 && w[0].K % 64 == 0 &&
+    // (groups from 17 rows: ONE grouped launch of the panel kernel -- q/k/v 21.8-23.2 us on the two-row-tile strips, 25.2 layer by layer;
+    //  gate/up 40-43.5 / 29.4.  profiles/r04_mid_m.md)
+    if (n > 1 && sm && w[0].bits == 4 && knob("QLLM_PANEL", 1) && M >= knob("QLLM_PANEL_GROUP_MIN_M", 17) && w[0].K % 64 == 0 &&
         (w[0].group_size == 32 || w[0].group_size == 64 || w[0].group_size == 128)) {
       bool all64 = true;
-      for (int i = 0; i < n; ++i) all64 = all64 && w[i].N % 64 == 0 && !w[i].g_idx;
+      for (int i = 0; i < n; ++i) all64 = all64 && w[i].N % 64 == 0 && !w[i].g_idx && w[i].bits == 4 && is_native(w[i]);
       if (all64) return false;
     }
   }
@@ -504,17 +504,56 @@ static int run_tile_gemm(GemmParams &p, int layout, void *workspace, size_t work
 }
 
 // prefill-sized calls (M > 64) on native-layout layers: the same tile GEMMs, their staging waves reading the strip-major words
-static bool panel_serves(const qllm_weight_t *w, const GemmParams &p) {
-  return knob("QLLM_PANEL", 1) && w->bits == 4 && is_native(*w) && panel_rows_ok(p.M, p.K, p.N) && panel_ok(p);
+// every layer of the launch: native strip-major, 4 bits, no act-order, whole 64-column panels; the group: one K / group size
+static bool panel_layers_ok(const qllm_weight_t *w, int n, int M) {
+  if (!knob("QLLM_PANEL", 1) || n < 1 || n > kMaxProblems) return false;
+  for (int i = 0; i < n; ++i) {
+    if (w[i].bits != 4 || !is_native(w[i]) || w[i].g_idx || w[i].K != w[0].K || w[i].group_size != w[0].group_size) return false;
+    if (!panel_shape_ok(M, w[i].K, w[i].N, w[i].group_size)) return false;
+    if ((uintptr_t)w[i].qweight % 16 || (uintptr_t)w[i].scales % 16 || (w[i].qzeros && (uintptr_t)w[i].qzeros % 8)) return false;
+  }
+  return true;
 }
-static int run_panel(GemmParams &p, void *workspace, size_t workspace_bytes, hipStream_t stream) {
+static bool panel_serves(const qllm_weight_t *w, const GemmParams &p) { return panel_rows_ok(p.M, p.K, p.N) && panel_layers_ok(w, 1, p.M); }
+// grouped launches (q/k/v, gate/up): from 17 rows -- the strips keep the smaller batches (BASELINE configs[3] is tuned there)
+static bool panel_group_serves(const qllm_weight_t *w, int n, int M) { return n > 1 && M >= knob("QLLM_PANEL_GROUP_MIN_M", 17) && panel_layers_ok(w, n, M); }
+static int panels_of(const qllm_weight_t *w, int n) {
+  int t = 0;
+  for (int i = 0; i < n; ++i) t += w[i].N / 64;
+  return t;
+}
+static int run_panel(const qllm_weight_t *w, void *const *y, int n, const void *x, int M, int act_dtype, void *workspace, size_t workspace_bytes,
+                     hipStream_t stream) {
+  PanelParams p;
+  memset(&p, 0, sizeof(p));
+  p.x = x;
+  p.M = M;
+  p.K = w[0].K;
+  p.group_size = w[0].group_size;
+  p.n_groups = (w[0].K + w[0].group_size - 1) / w[0].group_size;
+  p.add_zero_bias = w[0].add_zero_bias;
+  p.act_bf16 = (act_dtype == QLLM_BF16);
+  p.n_prob = n;
+  p.abl = knob("QLLM_PANEL_ABL", 0);  // (lab builds: timing-only ablations)
+  int begin = 0;
+  for (int i = 0; i < n; ++i) {
+    PanelProblem &q = p.prob[i];
+    q.qweight = (const uint32_t *)w[i].qweight;
+    q.scales = (const half_t *)w[i].scales;
+    q.qzeros = w[i].qzeros;
+    q.bias = (const half_t *)w[i].bias;
+    q.y = y[i];
+    q.N = w[i].N;
+    q.zero_kind = zero_kind_of(w[i]);
+    q.panel_begin = begin;
+    begin += w[i].N / 64;
+  }
+  p.n_panels = begin;
   // split-K when the panels alone leave CUs idle and the caller's workspace can hold the partial panels (else: no split)
-  const int S = panel_split_k(p.M, p.N, p.K, p.group_size);
-  const size_t need = kCounterBytes + panel_slab_bytes(p.M, p.N, S);
+  const int S = panel_split_k(M, begin, p.K);
+  const size_t need = kCounterBytes + panel_slab_bytes(M, begin, S);
   p.split_k = 1;
-  p.slabs = nullptr;
-  p.counters = nullptr;
-  if (S > 1 && workspace && workspace_bytes >= need && (uintptr_t)workspace % 256 == 0 && p.N / 64 <= (int)(kCounterBytes / sizeof(int))) {
+  if (S > 1 && workspace && workspace_bytes >= need && (uintptr_t)workspace % 256 == 0 && begin <= (int)(kCounterBytes / sizeof(int))) {
     p.split_k = S;
     p.counters = (int *)workspace;
     p.slabs = (float *)((char *)workspace + kCounterBytes);
@@ -538,7 +577,7 @@ static int native_prefill(const qllm_weight_t *w, const void *x, void *y, int M,
     gemm3_use_split(p, workspace, workspace_bytes);
     return launch_gemm3(p, kGemm3Rows3Bit, stream);
   }
-  if (panel_serves(w, p)) return run_panel(p, workspace, workspace_bytes, stream);
+  if (panel_serves(w, p)) return run_panel(w, &y, 1, x, M, act_dtype, workspace, workspace_bytes, stream);
   return run_tile_gemm(p, QLLM_LAYOUT_GPTQ, workspace, workspace_bytes, stream);
 }
 
@@ -591,7 +630,7 @@ size_t qllm_workspace_bytes_act(const qllm_weight_t *w, int32_t M, int32_t act_d
     if (M > 64 && M > 128) return kCounterBytes + tiles;
   }
   // the panel kernel's partial panels (single native 4-bit layers, 9..128 rows)
-  if (M >= 9 && M <= 128 && w->N % 64 == 0) tiles = std::max(tiles, align_up(panel_slab_bytes(M, w->N, panel_split_k(M, w->N, w->K, w->group_size)), 256));
+  if (M >= 9 && M <= 128 && w->N % 64 == 0) tiles = std::max(tiles, align_up(panel_slab_bytes(M, w->N / 64, panel_split_k(M, w->N / 64, w->K)), 256));
   if (M > 64) return kCounterBytes + tiles;
   const size_t slabs = align_up((size_t)skinny_max_split(M) * M * w->N * sizeof(float), 256);
   return kCounterBytes + (tiles > slabs ? tiles : slabs);
@@ -621,7 +660,8 @@ int qllm_linear_forward_grouped(const qllm_weight_t *w, void *const *y, int32_t 
     if (!skinny_ok(w[i], M)) return set_error(QLLM_ERR_UNSUPPORTED, "grouped forward needs the decode kernel (4-bit, M<=%d, K%%32==0, no act-order)", skinny_max_m());
   }
   if (strip_ok(w, n_weights, M)) return run_strip(w, y, n_weights, x, M, act_dtype, (hipStream_t)stream);
-  if (is_native(w[0])) return set_error(QLLM_ERR_UNSUPPORTED, "grouped forward: native-layout layers are served for M <= 64 with group size 64 / 128 (4 bits: also 32) (M=%d g=%d)", M, w[0].group_size);
+  if (panel_group_serves(w, n_weights, M)) return run_panel(w, y, n_weights, x, M, act_dtype, workspace, workspace_bytes, (hipStream_t)stream);
+  if (is_native(w[0])) return set_error(QLLM_ERR_UNSUPPORTED, "grouped forward: native-layout layers are served for M <= 32 (4 bits: <= 128) with group size 64 / 128 (4 bits: also 32) (M=%d g=%d)", M, w[0].group_size);
   if (w[0].bits != 4) return set_error(QLLM_ERR_UNSUPPORTED, "grouped forward: no fused kernel for %d-bit weights in this shape", w[0].bits);
   return run_skinny(w, y, n_weights, x, M, act_dtype, workspace, workspace_bytes, (hipStream_t)stream);
 }
@@ -774,7 +814,10 @@ int qllm_plan_describe(const qllm_weight_t *w, int32_t n_weights, int32_t M, int
   if (is_native(w[0])) {
     GemmParams p;
     fill_gemm_params(p, &w[0], nullptr, nullptr, M, QLLM_F16);
-    if (n_weights != 1 || !native_prefill_ok(&w[0], p)) {
+    if (panel_group_serves(w, n_weights, M)) {
+      snprintf(buf, buflen, "panel cols=64 row_tiles=%d k_halves=%d split_k=%d layers=%d layout=strip-major", panel_mt(M), panel_kh(M),
+               have_workspace ? panel_split_k(M, panels_of(w, n_weights), w[0].K) : 1, n_weights);
+    } else if (n_weights != 1 || !native_prefill_ok(&w[0], p)) {
       snprintf(buf, buflen, "unsupported (native layout: decode sizes, or M > 64 with K %% 64 == 0, N %% 128 == 0)");
     } else if (w[0].bits == 3) {
       const int S = have_workspace ? gemm3_split_k(M, w[0].N, w[0].K) : 1;
@@ -782,7 +825,7 @@ int qllm_plan_describe(const qllm_weight_t *w, int32_t n_weights, int32_t M, int
       else snprintf(buf, buflen, "gemm3 tile=256x128 matrix-waves=8 staging-waves=4 bits=3 layout=strip-major");
     } else if (panel_serves(&w[0], p)) {
       snprintf(buf, buflen, "panel cols=64 row_tiles=%d k_halves=%d split_k=%d layout=strip-major", panel_mt(M), panel_kh(M),
-               have_workspace ? panel_split_k(M, w[0].N, w[0].K, w[0].group_size) : 1);
+               have_workspace ? panel_split_k(M, w[0].N / 64, w[0].K) : 1);
     } else {
       const int S2 = gemm2_split_k(M, w[0].N, w[0].K), S3 = gemm3_split_k(M, w[0].N, w[0].K);
       if (gemm3_ok(p, QLLM_LAYOUT_GPTQ) && (S2 == 1 || (have_workspace && S3 > 1))) {

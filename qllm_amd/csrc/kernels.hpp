@@ -136,13 +136,29 @@ int gemm2_tile_n(int M, int N, int split_k);
 size_t gemm2_slab_bytes(int M, int N, int S);
 int launch_gemm2(const GemmParams &p, int layout, hipStream_t stream);
 
-// ---- panel.hip (17 <= M <= 128, and long-K layers from 9 rows, on the native layout: 64-column panels, A tiles shared through LDS, B fragments from registers) ----
-bool panel_ok(const GemmParams &p);
+// ---- panel.hip (17 <= M <= 128, and long-K layers from 9 rows, on the native layout: 64-column panels, A tiles shared through LDS,
+//      B fragments from registers; up to 8 layers sharing x in one launch) ----------------------------------------------------------
+struct PanelProblem {
+  const uint32_t *qweight;
+  const half_t *scales;
+  const void *qzeros;
+  const half_t *bias;
+  void *y;
+  int N, zero_kind, panel_begin, pad_;
+};
+struct PanelParams {
+  const void *x;
+  int M, K, n_groups, group_size, add_zero_bias, act_bf16, n_prob, split_k, abl, n_panels;
+  float *slabs;   // split-K: [panels][split_k][4 waves x row tiles x 4 x 64] fp32 partial panels
+  int *counters;  // split-K: one arrival counter per panel (zero before and after the launch)
+  PanelProblem prob[kMaxProblems];
+};
+bool panel_shape_ok(int M, int K, int N, int group_size);
 int panel_mt(int M);
 int panel_kh(int M);
-int panel_split_k(int M, int N, int K, int group_size);
-size_t panel_slab_bytes(int M, int N, int S);
-int launch_panel(const GemmParams &p, hipStream_t stream);
+int panel_split_k(int M, int n_panels, int K);
+size_t panel_slab_bytes(int M, int n_panels, int S);
+int launch_panel(const PanelParams &p, hipStream_t stream);
 
 // ---- gemm3.hip (256x128 tile, 4 matrix waves + 4 staging waves; no split-K) ---------------------------------------------
 constexpr int kGemm3Rows3Bit = 100;  // `layout` value for launch_gemm3 / gemm3_ok: GPTQ / HQQ row stream with 3-bit weights

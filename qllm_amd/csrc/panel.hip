@@ -40,7 +40,7 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 // range with A buffers of their own; the halves are summed through LDS before the epilogue -- half the global splits for the same
 // number of waves in flight (the cross-block sum costs ~6 us when it is needed at all: profiles/r04_mid_m.md).
 template <int MT, int CPL, int KH, int SPG, bool BF16, bool ZF16>
-__global__ __launch_bounds__(kPanelWaves * KH * 64, 1) void panel_kernel(const GemmParams p) {
+__global__ __launch_bounds__(kPanelWaves * KH * 64, 1) void panel_kernel(const PanelParams p) {
   constexpr int NW = kPanelWaves;             // waves of one K half = strips of the panel / CPL
   constexpr int KTS = kPanelKTS;              // (MT = 4: 64 KB of A buffers -> two blocks per CU; MT = 8: 128 KB)
   constexpr int KP = KTS / 2;                 // k-pairs per tile
@@ -58,8 +58,16 @@ __global__ __launch_bounds__(kPanelWaves * KH * 64, 1) void panel_kernel(const G
   const int wave = wave_all & (NW - 1), kh = wave_all / NW;  // strip of the panel, K half
   const int g = lane >> 4, i = lane & 15;
   const int S = p.split_k;
-  const int ksplit = (int)blockIdx.x % S, panel = (int)blockIdx.x / S;
-  const int M = p.M, N = p.N, T = p.K >> 5;
+  const int ksplit = (int)blockIdx.x % S, gpanel = (int)blockIdx.x / S;  // (panel index over all layers of the launch)
+  int pi = 0;
+  if (p.n_prob > 1) {
+#pragma unroll
+    for (int q = 1; q < kMaxProblems; ++q)
+      if (q < p.n_prob && gpanel >= p.prob[q].panel_begin) pi = q;
+  }
+  const PanelProblem pr = p.prob[pi];
+  const int panel = gpanel - pr.panel_begin;
+  const int M = p.M, N = pr.N, T = p.K >> 5;
   // K parts: S splits x KH halves; this wave's k-steps [t0, t1): whole groups and whole pairs.  Every wave of the block runs the same
   // number of tiles (the barriers are block-wide); a part that ends early multiplies zeros.
   constexpr int ALIGN = SPG < 2 ? 2 : SPG;
@@ -67,7 +75,7 @@ __global__ __launch_bounds__(kPanelWaves * KH * 64, 1) void panel_kernel(const G
   const int t0 = (ksplit * KH + kh) * chunk, t1 = min(t0 + chunk, T);
   const int tiles = (chunk + KTS - 1) / KTS;
 #ifdef QLLM_LAB
-  const int abl = p.stagger;  // timing-only ablations (QLLM_PANEL_ABL): 1 no activation pieces, 2 no word loads, 4 no compute, 8 no split-K sum
+  const int abl = p.abl;  // timing-only ablations (QLLM_PANEL_ABL): 1 no activation pieces, 2 no word loads, 4 no compute, 8 no split-K sum
 #else
   constexpr int abl = 0;
 #endif
@@ -76,11 +84,11 @@ __global__ __launch_bounds__(kPanelWaves * KH * 64, 1) void panel_kernel(const G
   const int strip0 = (panel * NW + wave) * CPL;  // this wave's first 16-column strip
   const int strip_bytes = T * 256;
   const int gtab = p.n_groups, Gmax = gtab - 1;
-  const int zk = p.zero_kind;
+  const int zk = pr.zero_kind;
   const int zgroup = (zk == ZK_PACKED) ? 8 : 32;  // zero-point bytes per (strip, group); symmetric layers re-read their scales
-  const auto rs_w = __builtin_amdgcn_make_buffer_rsrc((void *)p.qweight, 0, (int)min((size_t)(N >> 4) * strip_bytes, (size_t)0x7fffffff), 0x00020000);
-  const auto rs_s = __builtin_amdgcn_make_buffer_rsrc((void *)p.scales, 0, (N >> 4) * gtab * 32, 0x00020000);
-  const auto rs_z = __builtin_amdgcn_make_buffer_rsrc((zk == ZK_SYM) ? (void *)p.scales : (void *)p.qzeros, 0, (N >> 4) * gtab * zgroup, 0x00020000);
+  const auto rs_w = __builtin_amdgcn_make_buffer_rsrc((void *)pr.qweight, 0, (int)min((size_t)(N >> 4) * strip_bytes, (size_t)0x7fffffff), 0x00020000);
+  const auto rs_s = __builtin_amdgcn_make_buffer_rsrc((void *)pr.scales, 0, (N >> 4) * gtab * 32, 0x00020000);
+  const auto rs_z = __builtin_amdgcn_make_buffer_rsrc((zk == ZK_SYM) ? (void *)pr.scales : (void *)pr.qzeros, 0, (N >> 4) * gtab * zgroup, 0x00020000);
   const auto rs_x = __builtin_amdgcn_make_buffer_rsrc((void *)p.x, 0, (int)min((size_t)M * p.K * 2, (size_t)0x7fffffff), 0x00020000);
   const int lane_w = (g * 16 + i) * 4, lane_s = i * 2;
   const int lane_z = (zk == ZK_PACKED) ? (i >> 3) * 4 : ((zk == ZK_F16) ? (i >> 1) * 4 : 0);
@@ -262,7 +270,7 @@ __global__ __launch_bounds__(kPanelWaves * KH * 64, 1) void panel_kernel(const G
   if (S > 1 && !(abl & 8)) {
     int &s_ticket = *(int *)(smem + MT * 4096);  // (past the hand-off area of the K halves and the epilogue's staging rows; the A buffers are MT x 16 KB or more)
     constexpr int WREGS = MT * CPL * 4;
-    float *slab = p.slabs + ((size_t)panel * S + ksplit) * (size_t)(NW * WREGS * 64) + (size_t)wave * (WREGS * 64) + lane;
+    float *slab = p.slabs + ((size_t)gpanel * S + ksplit) * (size_t)(NW * WREGS * 64) + (size_t)wave * (WREGS * 64) + lane;
     if (kh == 0) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
@@ -273,7 +281,7 @@ __global__ __launch_bounds__(kPanelWaves * KH * 64, 1) void panel_kernel(const G
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(p.counters + panel, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(p.counters + gpanel, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     if (s_ticket != S - 1) return;
 #pragma unroll
@@ -281,7 +289,7 @@ __global__ __launch_bounds__(kPanelWaves * KH * 64, 1) void panel_kernel(const G
 #pragma unroll
       for (int c = 0; c < CPL; ++c) yacc[mt][c] = float4_t{0.f, 0.f, 0.f, 0.f};
     for (int s = 0; s < S && kh == 0; ++s) {
-      const float *src = p.slabs + ((size_t)panel * S + s) * (size_t)(NW * WREGS * 64) + (size_t)wave * (WREGS * 64) + lane;
+      const float *src = p.slabs + ((size_t)gpanel * S + s) * (size_t)(NW * WREGS * 64) + (size_t)wave * (WREGS * 64) + lane;
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -289,7 +297,7 @@ __global__ __launch_bounds__(kPanelWaves * KH * 64, 1) void panel_kernel(const G
 #pragma unroll
           for (int r = 0; r < 4; ++r) yacc[mt][c][r] += ld_sc1(src + ((mt * CPL + c) * 4 + r) * 64);
     }
-    if (threadIdx.x == 0) __hip_atomic_store(p.counters + panel, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) __hip_atomic_store(p.counters + gpanel, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
   }
 
@@ -300,7 +308,7 @@ __global__ __launch_bounds__(kPanelWaves * KH * 64, 1) void panel_kernel(const G
 #pragma unroll
   for (int c = 0; c < CPL; ++c) {
     const int col = (wave * CPL + c) * 16 + i;
-    const float bv = p.bias ? (float)p.bias[n0 + col] : 0.f;
+    const float bv = pr.bias ? (float)pr.bias[n0 + col] : 0.f;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -313,14 +321,16 @@ __global__ __launch_bounds__(kPanelWaves * KH * 64, 1) void panel_kernel(const G
   constexpr int CPR = PCOLS / 8;  // 16-byte chunks per row
   for (int c = threadIdx.x; c < M * CPR; c += NW * KH * 64) {
     const int row = c / CPR, ch = c - row * CPR;
-    *(uint4_t *)((uint16_t *)p.y + (size_t)row * N + n0 + ch * 8) = *(const uint4_t *)(ep + row * EPS + ch * 8);
+    *(uint4_t *)((uint16_t *)pr.y + (size_t)row * N + n0 + ch * 8) = *(const uint4_t *)(ep + row * EPS + ch * 8);
   }
 }
 
 template <int MT, int KH, int SPG, bool BF16>
-int launch_z(const GemmParams &p, int grid, hipStream_t stream) {
+int launch_z(const PanelParams &p, int grid, hipStream_t stream) {
   const size_t lds = (size_t)KH * 2 * (kPanelKTS / 2) * MT * 2048;
-  if (p.zero_kind == ZK_F16) {
+  bool all_f16 = true;  // (the fp16-zero-point form: every layer of the launch)
+  for (int i = 0; i < p.n_prob; ++i) all_f16 = all_f16 && p.prob[i].zero_kind == ZK_F16;
+  if (all_f16) {
     static DeviceLatch done;
     if (int rc = lds_optin(done, (const void *)panel_kernel<MT, 1, KH, SPG, BF16, true>)) return rc;
     hipLaunchKernelGGL((panel_kernel<MT, 1, KH, SPG, BF16, true>), dim3(grid), dim3(kPanelWaves * KH * 64), lds, stream, p);
@@ -336,7 +346,7 @@ int launch_z(const GemmParams &p, int grid, hipStream_t stream) {
 // (two strips per wave -- 128-column panels -- are written and measured: 4096 -> 11008 at M = 64 21.8-22.4 us against 19.7-21.1 with
 //  64-column panels, 11008 -> 4096 24.2-24.7 against 21.4-22.2; not built)
 template <int MT, int KH, bool BF16>
-int launch_g(const GemmParams &p, int grid, hipStream_t stream) {
+int launch_g(const PanelParams &p, int grid, hipStream_t stream) {
   if (p.group_size == 32) {
     if constexpr (MT > 4) return set_error(QLLM_ERR_UNSUPPORTED, "internal: 32-wide groups are served up to 64 rows");  // (eight row tiles spill there)
     else return launch_z<MT, KH, 1, BF16>(p, grid, stream);
@@ -347,11 +357,10 @@ int launch_g(const GemmParams &p, int grid, hipStream_t stream) {
 
 }  // namespace
 
-// native strip-major 4-bit layers, whole 64-column panels, whole k-step pairs, the group sizes of the strips
-bool panel_ok(const GemmParams &p) {
-  return p.sm && !p.g_idx && p.M >= 2 && p.M <= 128 && p.K % 64 == 0 && p.N % 64 == 0 &&
-         ((p.group_size == 32 && p.M <= 64) || p.group_size == 64 || p.group_size == 128) && p.K % p.group_size == 0 &&
-         (double)p.K * p.N / 2 < 2147483648.0;
+// whole 64-column panels, whole k-step pairs, the group sizes of the strips (callers: native strip-major 4-bit layers, no g_idx)
+bool panel_shape_ok(int M, int K, int N, int group_size) {
+  return M >= 2 && M <= 128 && K % 64 == 0 && N % 64 == 0 && ((group_size == 32 && M <= 64) || group_size == 64 || group_size == 128) &&
+         K % group_size == 0 && (double)K * N / 2 < 2147483648.0;
 }
 
 // row tiles of 16 the kernel is built for: 1, 2, 4, 8
@@ -359,27 +368,23 @@ int panel_mt(int M) { return M <= 16 ? 1 : (M <= 32 ? 2 : (M <= 64 ? 4 : 8)); }
 // K halves inside a block: two up to 64 rows (128 KB of A buffers), one above (eight row tiles: two halves would not fit)
 int panel_kh(int M) { return M <= 64 ? 2 : 1; }
 // blocks per panel along K: one block per CU; at least two K-tiles (16 k-steps) per K part (split x half); at most 8
-int panel_split_k(int M, int N, int K, int group_size) {
-  (void)group_size;
-  const int panels = N / 64, kh = panel_kh(M);
-  int S = compute_units() / (panels > 0 ? panels : 1);
+int panel_split_k(int M, int n_panels, int K) {
+  const int kh = panel_kh(M);
+  int S = compute_units() / (n_panels > 0 ? n_panels : 1);
   S = S < 1 ? 1 : (S > 8 ? 8 : S);
   const int max_s = (K / 32) / 16 / kh;
   if (S > max_s) S = max_s < 1 ? 1 : max_s;
   return S;
 }
-size_t panel_slab_bytes(int M, int N, int S) { return S > 1 ? (size_t)(N / 64) * S * kPanelWaves * (M <= 64 ? 4 : 8) * 256 * sizeof(float) : 0; }  // (sized for four row tiles up to 64 rows)
 
-int launch_panel(const GemmParams &p, hipStream_t stream) {
-  const int S = (p.split_k > 1 && p.slabs && p.counters) ? p.split_k : 1;
-  GemmParams q = p;
-  q.split_k = S;
-  q.stagger = knob("QLLM_PANEL_ABL", 0);  // (lab builds: timing-only ablations)
-  const int grid = (p.N / 64) * S;
-  if (p.M <= 16) return p.act_bf16 ? launch_g<1, 2, true>(q, grid, stream) : launch_g<1, 2, false>(q, grid, stream);
-  if (p.M <= 32) return p.act_bf16 ? launch_g<2, 2, true>(q, grid, stream) : launch_g<2, 2, false>(q, grid, stream);
-  if (p.M <= 64) return p.act_bf16 ? launch_g<4, 2, true>(q, grid, stream) : launch_g<4, 2, false>(q, grid, stream);
-  return p.act_bf16 ? launch_g<8, 1, true>(q, grid, stream) : launch_g<8, 1, false>(q, grid, stream);
+size_t panel_slab_bytes(int M, int n_panels, int S) { return S > 1 ? (size_t)n_panels * S * kPanelWaves * (M <= 64 ? 4 : 8) * 256 * sizeof(float) : 0; }  // (sized for four row tiles up to 64 rows)
+
+int launch_panel(const PanelParams &p, hipStream_t stream) {
+  const int grid = p.n_panels * p.split_k;
+  if (p.M <= 16) return p.act_bf16 ? launch_g<1, 2, true>(p, grid, stream) : launch_g<1, 2, false>(p, grid, stream);
+  if (p.M <= 32) return p.act_bf16 ? launch_g<2, 2, true>(p, grid, stream) : launch_g<2, 2, false>(p, grid, stream);
+  if (p.M <= 64) return p.act_bf16 ? launch_g<4, 2, true>(p, grid, stream) : launch_g<4, 2, false>(p, grid, stream);
+  return p.act_bf16 ? launch_g<8, 1, true>(p, grid, stream) : launch_g<8, 1, false>(p, grid, stream);
 }
 
 }  // namespace qllm

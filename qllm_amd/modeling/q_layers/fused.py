@@ -20,7 +20,7 @@ import torch
 from ... import ops
 from ._hip_forward import tensor_version
 
-GROUP_MAX_M = 64  # the grouped entry point serves decode sizes only (include/qllm_mi355x.h)
+GROUP_MAX_M = 128  # the grouped entry point serves decode and mid-batch sizes (strips to 32 rows, the panel kernel to 128)
 
 # attribute names of siblings inside one parent module (Llama / Mistral / Qwen2, OPT, Falcon-style MLPs, ...)
 SIBLING_PATTERNS = (("q_proj", "k_proj", "v_proj"), ("gate_proj", "up_proj"), ("w1", "w3"))

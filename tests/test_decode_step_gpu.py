@@ -181,28 +181,52 @@ def test_sibling_group_switches_itself_off_when_nobody_collects():
     assert not g.enabled
 
 
-def test_a_mid_batch_call_does_not_cost_the_group_its_decode_launches():
-    """Round 4: q/k/v of a 7B model (12288 columns) have no grouped kernel above 32 rows -- the layers then run one by one (the panel
-    kernel) -- and that refusal must not switch the group off: a 40-token prefill is followed by thousands of one-row decode steps."""
+def test_a_refused_mid_batch_call_does_not_cost_the_group_its_decode_launches():
+    """Round 4: a grouped call the library has no kernel for (here: 32-wide groups above 64 rows; before the grouped panel launch
+    also every q/k/v call above 32 rows) must not switch the group off: a prefill chunk is followed by thousands of one-row decode steps."""
     from qllm_amd.modeling.q_layers import fuse_siblings
-    ds = [synth("GEMM", 4, 128, H, H, seed=30 + i) for i in range(3)]
+    ds = [synth("GPTQ", 4, 32, H, 1024, seed=30 + i) for i in range(3)]
     layers = [to_layer(d, DEV) for d in ds]
     g = fuse_siblings(layers)
     x1 = torch.from_numpy(randx(1, H, seed=1)).to(DEV)
     [l(x1) for l in layers]
     assert g.grouped_launches == 1
-    x40 = torch.from_numpy(randx(40, H, seed=2)).to(DEV)
-    outs = [l(x40) for l in layers]                        # refused by the grouped entry point: three launches of their own
+    x100 = torch.from_numpy(randx(100, H, seed=2)).to(DEV)
+    outs = [l(x100) for l in layers]                       # refused by the grouped entry point: three launches of their own
     assert g.grouped_launches == 1 and g.enabled
     for o, d in zip(outs, ds):
-        assert O.rel_err(o.cpu().numpy(), Ref(d).y16(x40.cpu().numpy())) <= 1e-2
-    [l(x40.clone()) for l in layers]                       # ... and not asked again at that size
+        assert O.rel_err(o.cpu().numpy(), Ref(d).y16(x100.cpu().numpy())) <= 1e-2
+    [l(x100.clone()) for l in layers]                      # ... and not asked again at that size
     assert g.grouped_launches == 1
     x1b = torch.from_numpy(randx(1, H, seed=3)).to(DEV)
     outs = [l(x1b) for l in layers]
     assert g.grouped_launches == 2 and g.enabled           # decode is grouped as before
     for o, d in zip(outs, ds):
         assert O.rel_err(o.cpu().numpy(), Ref(d).y16(x1b.cpu().numpy())) <= 1e-2
+
+
+def test_sibling_groups_take_one_panel_launch_from_17_rows():
+    """q/k/v and gate/up at 17..128 rows: ONE grouped launch of the panel kernel (csrc/panel.hip) for the whole group."""
+    from qllm_amd import ops
+    from qllm_amd.modeling.q_layers import fuse_siblings
+    for widths, layout, g_ in (((H, 1024, 1024), "GPTQ", 128), ((I, I), "GEMM", 128), ((H, H, H), "HQQ", 64)):
+        ds = [synth(layout, 4, g_, H, n, seed=50 + i, bias=(i == 1)) for i, n in enumerate(widths)]
+        layers = [to_layer(d, DEV) for d in ds]
+        grp = fuse_siblings(layers)
+        for m in (17, 40, 64, 100, 128):
+            assert grp.describe(m).startswith("panel ") and f"layers={len(widths)}" in grp.describe(m), grp.describe(m)
+            x = torch.from_numpy(randx(m, H, seed=m)).to(DEV)
+            before = grp.grouped_launches
+            outs = [l(x) for l in layers]
+            assert grp.grouped_launches == before + 1
+            for o, d in zip(outs, ds):
+                ref = Ref(d)
+                assert O.rel_err(o.cpu().numpy(), ref.y16(x.cpu().numpy())) <= 1e-2, (widths, m)
+                assert O.rel_err(o.cpu().numpy().astype(np.float64), ref.y64(x.cpu().numpy())) <= 2e-3, (widths, m)
+        xb = torch.from_numpy(randx(48, H, seed=9)).to(DEV).to(torch.bfloat16)
+        outs = [l(xb) for l in layers]
+        for o, d in zip(outs, ds):
+            assert O.rel_err(o.float().cpu().numpy(), Ref(d).y64(xb.float().cpu().numpy().astype(np.float16))) <= 2e-2
 
 
 def test_sibling_groups_use_one_grouped_launch_and_match_single_launches():

@@ -145,9 +145,13 @@ def test_native_layout_decode_routes(lib):
     assert plan(lib, [W(4096, 11008, 64, 3, NATIVE_F16Z)] * 2, 16) == "strip nw=8 cpl=4 spw=16 form=dma-A row_tiles=1" + sm  # 3 bits: four at most
     assert plan(lib, [attn], 32) == plan(lib, [attn], 17) == "panel cols=64 row_tiles=2 k_halves=2 split_k=4" + sm   # single layers from 17 rows
     assert plan(lib, [up], 24) == "panel cols=64 row_tiles=2 k_halves=2 split_k=1" + sm
-    assert plan(lib, [attn] * 3, 32) == "strip nw=8 cpl=1 spw=16 form=dma-A row_tiles=2" + sm                          # grouped: strips
+    assert plan(lib, [attn] * 3, 32) == "panel cols=64 row_tiles=2 k_halves=2 split_k=1 layers=3" + sm
     assert plan(lib, [up] * 2, 16) == "strip nw=8 cpl=6 spw=16 form=dma-A row_tiles=1" + sm
-    assert plan(lib, [up] * 2, 17).startswith("unsupported")   # very wide groups from 17 rows: layer by layer on the panel kernel
+    assert plan(lib, [up] * 2, 17) == "panel cols=64 row_tiles=2 k_halves=2 split_k=1 layers=2" + sm   # groups from 17 rows: ONE panel launch
+    assert plan(lib, [attn] * 3, 17) == "panel cols=64 row_tiles=2 k_halves=2 split_k=1 layers=3" + sm
+    assert plan(lib, [attn] * 3, 128) == "panel cols=64 row_tiles=8 k_halves=1 split_k=1 layers=3" + sm
+    assert plan(lib, [W(4096, 1024, layout=NATIVE)] * 3, 64) == "panel cols=64 row_tiles=4 k_halves=2 split_k=4 layers=3" + sm   # 48 panels x 4
+    assert plan(lib, [attn] * 3, 129).startswith("unsupported")
     # Llama-2-70B shapes at batch 16: 512 strips -> 256 blocks of two; q/k/v (GQA) 640 strips -> 160 blocks of four; gate/up 3584
     # strips -> six per block; the TP = 8 shards of q/k/v (80 strips) stay one strip per 16-wave block
     assert plan(lib, [W(8192, 8192, layout=NATIVE)], 16) == "strip nw=8 cpl=2 spw=32 form=dma-A row_tiles=1" + sm
@@ -162,8 +166,7 @@ def test_native_layout_decode_routes(lib):
     assert plan(lib, [attn], 65) == plan(lib, [attn], 128) == "panel cols=64 row_tiles=8 k_halves=1 split_k=4" + sm
     assert plan(lib, [attn], 64, have_ws=0) == "panel cols=64 row_tiles=4 k_halves=2 split_k=1" + sm      # no workspace: no split
     assert plan(lib, [attn], 129) == "gemm2 tile=256x128 split_k=8" + sm
-    assert plan(lib, [W(4096, 1024, layout=NATIVE)] * 3, 64) == "strip nw=8 cpl=1 spw=16 form=register-A row_tiles=4" + sm
-    assert plan(lib, [attn] * 3, 64).startswith("unsupported")   # (wide grouped launches above 32 rows: the modules call layer by layer)
+    assert plan(lib, [W(4096, 1024, 128, 3, NATIVE)] * 3, 32).startswith("strip ")                 # (3 bits: strips, up to 32 rows)
     assert plan(lib, [W(4096, 4096, 64, layout=NATIVE_F16Z)], 48) == "panel cols=64 row_tiles=4 k_halves=2 split_k=4" + sm
     assert plan(lib, [W(4096, 4032, layout=NATIVE)], 48) == "panel cols=64 row_tiles=4 k_halves=2 split_k=4" + sm   # N % 64 == 0 is enough
     assert plan(lib, [W(4096, 4048, layout=NATIVE)], 48).startswith("strip ")                                        # ... N % 16 is not
@@ -203,10 +206,12 @@ def test_native_layout_decode_routes(lib):
     assert plan(lib, [g32(2112, 4096)], 16) == "strip nw=16 cpl=1 spw=6 form=dma-A row_tiles=1" + sm    # 66 k-steps over 16 waves: 5 -> 6
     assert plan(lib, [g32(2112, 4096)], 4) == "strip nw=16 cpl=1 spw=5 form=register-A row_tiles=1" + sm
     assert plan(lib, [g32(4096, 4096)], 32) == "panel cols=64 row_tiles=2 k_halves=2 split_k=4" + sm
-    assert plan(lib, [g32(4096, 1024)] * 2, 32) == "strip nw=8 cpl=1 spw=16 form=dma-A row_tiles=2" + sm
+    assert plan(lib, [g32(4096, 1024)] * 2, 32) == "panel cols=64 row_tiles=2 k_halves=2 split_k=4 layers=2" + sm
+    assert plan(lib, [g32(4096, 1024)] * 2, 16) == "strip nw=16 cpl=1 spw=8 form=dma-A row_tiles=1" + sm
     assert plan(lib, [g32(4096, 4096)], 64) == "panel cols=64 row_tiles=4 k_halves=2 split_k=4" + sm
     assert plan(lib, [g32(4096, 4096)], 65) == "gemm2 tile=256x128 split_k=8" + sm   # (eight row tiles of 32-wide groups are not built)
-    assert plan(lib, [g32(4096, 1024)] * 2, 64) == "strip nw=8 cpl=1 spw=16 form=register-A row_tiles=4" + sm
+    assert plan(lib, [g32(4096, 1024)] * 2, 64) == "panel cols=64 row_tiles=4 k_halves=2 split_k=4 layers=2" + sm
+    assert plan(lib, [g32(4096, 1024)] * 2, 65).startswith("unsupported")
     assert plan(lib, [W(4096, 4096, 32, 3, NATIVE)], 1).startswith("unsupported")       # 3 bits: 64 / 128 only
     assert plan(lib, [W(4096, 4096, 32)], 1).startswith("skinny")                       # reference layouts in place: the split-K kernel
     assert plan(lib, [W(4096, 4096, 256, layout=NATIVE)], 1).startswith("unsupported")  # group sizes the strips do not serve
