@@ -477,6 +477,19 @@ def main():
             ms = time_events(g.replay, 20) / len(ls)
             extra[f"batch64_{name}"] = {"us": round(ms * 1e3, 2), "GBps": round(alg_bytes(K, N, 64) / ms / 1e6, 1),
                                         "TFLOPs": round(2.0 * 64 * K * N / ms / 1e9, 1)}
+        # the whole stack at batch 64 through the modules (sibling groups: q/k/v and gate/up one grouped panel launch each, round 4)
+        try:
+            stack.set_fused(fused)
+            h64 = torch.randn(64, HIDDEN, device=dev, dtype=torch.float16) * 0.1
+            gg, o64 = capture(decode_step_fn(stack, h64))
+            ms = time_events(gg.replay, 10)
+            del gg
+            extra["batch64_stack"] = {"ms_per_step": round(ms, 4), "tokens_per_s": round(64e3 / ms, 1), "us_per_layer": round(ms * 1e3 / n_layers, 2),
+                                      "TFLOPs": round(2.0 * 64 * (4 * HIDDEN * HIDDEN + 3 * HIDDEN * INTER) * n_layers / ms / 1e9, 1),
+                                      "finite": bool(torch.isfinite(o64.float()).all())}
+        except Exception as e:  # noqa: BLE001  (a side leg must not take the headline down with it)
+            extra["batch64_stack"] = {"error": f"{type(e).__name__}: {e}"}
+            torch.cuda.synchronize()
         # the other launch forms of the same step (all through the modules): 7 launches per layer; the reference buffers in place
         for tag, fz, native in (("ungrouped", False, True), ("fused_reference_layout_in_place", True, False)):
             stack.set_fused(fz)

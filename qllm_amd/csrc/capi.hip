@@ -514,9 +514,23 @@ static bool panel_layers_ok(const qllm_weight_t *w, int n, int M) {
   }
   return true;
 }
-static bool panel_serves(const qllm_weight_t *w, const GemmParams &p) { return panel_rows_ok(p.M, p.K, p.N) && panel_layers_ok(w, 1, p.M); }
+// 65..128 rows (eight row tiles, one K half per block): only where it pays whatever the activation type -- us per linear, fp16 / bf16,
+// against gemm2's 28 / 40 / 41 (+1-2 for bf16): 4096 x 4096 19 / 25; 4096 x 11008 36-38 / 50; 11008 x 4096 35 / 44 -> layers of up to
+// 2^25 weights; groups (three launches become one: q/k/v 41 against 84) of up to 16384 columns.  profiles/r04_mid_m.md
+static bool panel_serves(const qllm_weight_t *w, const GemmParams &p) {
+  if (p.M > 64 && (double)p.K * p.N > 33554432.0) return false;
+  return panel_rows_ok(p.M, p.K, p.N) && panel_layers_ok(w, 1, p.M);
+}
 // grouped launches (q/k/v, gate/up): from 17 rows -- the strips keep the smaller batches (BASELINE configs[3] is tuned there)
-static bool panel_group_serves(const qllm_weight_t *w, int n, int M) { return n > 1 && M >= knob("QLLM_PANEL_GROUP_MIN_M", 17) && panel_layers_ok(w, n, M); }
+static bool panel_group_serves(const qllm_weight_t *w, int n, int M) {
+  if (n <= 1 || M < knob("QLLM_PANEL_GROUP_MIN_M", 17) || !panel_layers_ok(w, n, M)) return false;
+  if (M > 64) {
+    int cols = 0;
+    for (int i = 0; i < n; ++i) cols += w[i].N;
+    if (cols > 16384) return false;
+  }
+  return true;
+}
 static int panels_of(const qllm_weight_t *w, int n) {
   int t = 0;
   for (int i = 0; i < n; ++i) t += w[i].N / 64;

@@ -185,11 +185,9 @@ __global__ __launch_bounds__(kPanelWaves * KH * 64, 1) void panel_kernel(const P
           }
         }
       }
-      half8_t av[MT];
+      half8_t av[MT];  // (bf16 activations: the tile was converted to fp16 in place when it landed -- convert_tile)
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        if constexpr (BF16) av[mt] = bf16x8_to_h8(ar[s & 1][mt]); else av[mt] = __builtin_bit_cast(half8_t, ar[s & 1][mt]);
-      }
+      for (int mt = 0; mt < MT; ++mt) av[mt] = __builtin_bit_cast(half8_t, ar[s & 1][mt]);
 #pragma unroll
       for (int c = 0; c < CPL; ++c) {
         const uint32_t wv = w[set][s][c], w8 = wv >> 8;
@@ -223,6 +221,17 @@ __global__ __launch_bounds__(kPanelWaves * KH * 64, 1) void panel_kernel(const P
     }
   };
 
+  // bf16 activations: the landed tile is converted to fp16 IN PLACE, once per block (each wave of the K half a quarter of it), instead
+  // of once per fragment and wave in the loop (12 VALU x MT fragments x 8 k-steps per wave and tile; the reference's own bf16 path
+  // casts x to fp16 as well: quant_linear_awq.py:29-36); one more barrier per tile
+  auto convert_tile = [&](const int buf) __attribute__((always_inline)) {
+    uint8_t *tb = smem + (kh * 2 + buf) * TILE_BYTES + wave * (TILE_BYTES / NW) + lane * 16;
+#pragma unroll
+    for (int r = 0; r < TILE_BYTES / NW / 1024; ++r) {
+      const uint4_t v = *(const uint4_t *)(tb + r * 1024);
+      *(half8_t *)(tb + r * 1024) = bf16x8_to_h8(v);
+    }
+  };
   // ---- main loop: [tile kt landed] barrier [request tile kt+1 into the buffer / register set tile kt-1 used] compute tile kt ----
   // (requesting the words two tiles ahead with a counted vmcnt, and a group's scale step deferred by a k-step, measured nothing:
   //  profiles/r04_mid_m.md)
@@ -231,6 +240,7 @@ __global__ __launch_bounds__(kPanelWaves * KH * 64, 1) void panel_kernel(const P
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (kt + 1 < tiles) request(kt + 1, 1);
+    if constexpr (BF16) { convert_tile(0); __syncthreads(); }
     __builtin_amdgcn_sched_barrier(0);
     if (!(abl & 4)) compute(0, 0);
     __builtin_amdgcn_sched_barrier(0);
@@ -238,6 +248,7 @@ __global__ __launch_bounds__(kPanelWaves * KH * 64, 1) void panel_kernel(const P
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (kt + 2 < tiles) request(kt + 2, 0);
+      if constexpr (BF16) { convert_tile(1); __syncthreads(); }
       __builtin_amdgcn_sched_barrier(0);
       if (!(abl & 4)) compute(1, 1);
       __builtin_amdgcn_sched_barrier(0);

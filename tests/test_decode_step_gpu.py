@@ -214,6 +214,9 @@ def test_sibling_groups_take_one_panel_launch_from_17_rows():
         layers = [to_layer(d, DEV) for d in ds]
         grp = fuse_siblings(layers)
         for m in (17, 40, 64, 100, 128):
+            if m > 64 and sum(widths) > 16384:   # (65..128 rows: groups of up to 16384 columns)
+                assert grp.describe(m).startswith("unsupported")
+                continue
             assert grp.describe(m).startswith("panel ") and f"layers={len(widths)}" in grp.describe(m), grp.describe(m)
             x = torch.from_numpy(randx(m, H, seed=m)).to(DEV)
             before = grp.grouped_launches

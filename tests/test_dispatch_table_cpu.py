@@ -174,7 +174,9 @@ def test_native_layout_decode_routes(lib):
     assert "form=register-A" in plan(lib, [W(65536, 65536, layout=NATIVE)], 16) and "form=dma-A" in plan(lib, [W(65536, 32768, layout=NATIVE)], 8)
     assert plan(lib, [up], 64) == "panel cols=64 row_tiles=4 k_halves=2 split_k=1" + sm     # 172 panels: no cross-block sum at all
     assert plan(lib, [down], 33) == "panel cols=64 row_tiles=4 k_halves=2 split_k=4" + sm   # 344 k-steps in 8 parts of 44
-    assert plan(lib, [up], 128) == "panel cols=64 row_tiles=8 k_halves=1 split_k=1" + sm
+    assert plan(lib, [up], 128) == "gemm2 tile=256x128 split_k=2" + sm   # 65..128 rows: layers of up to 2^25 weights only (bf16 loses above)
+    assert plan(lib, [down], 100) == "gemm2 tile=256x128 split_k=8" + sm
+    assert plan(lib, [up] * 2, 128).startswith("unsupported")              # ... groups of up to 16384 columns
     # shard shapes of Llama-2-70B (TP = 8): short K -> 4-wave blocks, K = 8192 -> 8 waves x one round of 32
     assert plan(lib, [W(1024, 8192, layout=NATIVE)], 1).startswith("strip nw=4 cpl=1 spw=8 form=lds-slab")
     assert plan(lib, [W(8192, 1024, layout=NATIVE)], 1).startswith("strip nw=8 cpl=1 spw=32 form=lds-slab")
