@@ -42,7 +42,7 @@ _lib.qllm_repack_native.restype = ctypes.c_int
 _lib.qllm_last_error.restype = ctypes.c_char_p
 _ws = {}
 _native = {}  # id(qweight) -> (weakrefs of (qweight, scales, qzeros), their versions, descriptor, tensors it points into)
-_DECODE_MAX_M = 64
+_DECODE_MAX_M = 128  # strips to 32 rows, the panel kernel to 128 (csrc/panel.hip): both stream the native copy
 
 
 def _check(rc):

@@ -83,12 +83,12 @@ def test_awq_inference_engine_stub():
 
 
 def test_awq_inference_engine_stub_decode_uses_a_native_copy():
-    """M <= 64 through the stub: served from a cached native-layout copy of the caller's integers (strip kernel); the copy follows
+    """M <= 128 through the stub: served from a cached native-layout copy of the caller's integers (strip / panel kernels); the copy follows
     in-place updates of the caller's tensors (keyed on identity AND version), dies with them, and can be switched off."""
     eng = _load_stub("awq_inference_engine")
     d = synth("GEMM", 4, 128, 4096, 4096, seed=7)
     qweight, scales, qzeros = _t(d, "qweight", "scales", "qzeros")
-    for m in (1, 5, 64):
+    for m in (1, 5, 64, 100):
         x = randx(m, 4096, seed=m)
         y = eng.gemm_forward_cuda(torch.from_numpy(x).to(DEV), qweight, scales, qzeros, 8)
         assert O.rel_err(y.cpu().numpy(), Ref(d).y16(x)) <= 1e-2 and O.rel_err(y.float().cpu().numpy(), Ref(d).y64(x)) <= 2e-3
