@@ -105,3 +105,18 @@ def test_prefill_kernels_do_not_spill():
     for n in names:
         vgpr, spill = res[n]
         assert spill == 0 and vgpr <= 256, (n, vgpr, spill)
+
+
+def test_panel_kernel_budget():
+    """csrc/panel.hip (round 4): every instantiation that is built is spill-free; the eight-wave forms (two K halves, up to 64 rows)
+    fit two waves per SIMD (<= 256 registers), the four-wave eight-row-tile forms one (<= 512).  32-wide groups stop at four row
+    tiles (eight spill) and are checked to be absent above."""
+    res = {n: v for n, v in _resources("panel.hip").items() if "panel_kernel" in n}
+    assert len(res) >= 36  # {1, 2, 4 row tiles} x {g32, g64, g128} x {fp16, bf16} x {packed / fp16 zeros} + 8 row tiles x {g64, g128} x ...
+    for n, (vgpr, spill) in res.items():
+        m = re.search(r"panel_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", n)   # <row tiles, strips per wave, K halves, k-steps per group, ...>
+        mt, cpl, kh, spg = (int(v) for v in m.groups())
+        assert spill == 0, (n, vgpr, spill)
+        assert cpl == 1 and kh == (2 if mt <= 4 else 1), n
+        assert not (mt == 8 and spg == 1), n
+        assert vgpr <= (256 if kh == 2 else 512), (n, vgpr)
