@@ -32,8 +32,9 @@ Extra objects on the JSON line:
   cpu_baseline the reference's CPU torch formulation (oracle/ref_torch.py: shift/mask dequant + fp16 torch.matmul,
                bit-identical to the oracle) timed on this host's cores over one decoder layer (3 warm + 5 timed calls per
                shape, thread count picked by a short sweep and stated), extrapolated x32.
-  extra        per-shape decode GB/s, the other launch forms, M=2048 prefill TFLOP/s (AWQ; act-order GPTQ = configs[2]),
-               HQQ g64 M=16 (configs[3]) and the Llama-2-70B per-rank shard shapes of configs[4].
+  extra        per-shape decode GB/s (+ the same layers and the whole stack at batch 64: the mid-batch panel kernel), the other
+               launch forms, M=2048 prefill TFLOP/s (AWQ; act-order GPTQ = configs[2]), HQQ g64 M=16 (configs[3]) and the
+               Llama-2-70B per-rank shard shapes of configs[4].
 """
 import argparse
 import csv
