@@ -154,16 +154,16 @@ static bool strip_plan(const qllm_weight_t *w, int n, int M, StripPlan *plan) {
     const int lim = max_m ? max_m : ((w[0].K <= 4096 && cols_all <= 4096 && !(sm && w[0].bits == 3)) ? 64 : 32);
     if (M > lim) return false;
     // (single native 4-bit layers: the panel kernel takes over where it is served -- panel.hip; grouped launches stay here)
-    if (n == 1 && sm && w[0].bits == 4 && knob("QLLM_PANEL", 1) && panel_rows_ok(M, w[0].K, w[0].N) && w[0].K % 64 == 0 && w[0].N % 64 == 0 && !w[0].g_idx &&
-        (w[0].group_size == 32 || w[0].group_size == 64 || w[0].group_size == 128))
-      return false;  // (M <= 64 here: every such layer is served by panel_ok)
+    if (n == 1 && sm && knob("QLLM_PANEL", 1) && panel_rows_ok(M, w[0].K, w[0].N) && !w[0].g_idx &&
+        panel_shape_ok(M, w[0].K, w[0].N, w[0].group_size, w[0].bits))
+      return false;  // (M <= 64 here)
     // (groups from 17 rows: ONE grouped launch of the panel kernel -- q/k/v 21.8-23.2 us on the two-row-tile strips, 25.2 layer by layer;
     //  gate/up 40-43.5 / 29.4.  profiles/r04_mid_m.md)
-    if (n > 1 && sm && w[0].bits == 4 && knob("QLLM_PANEL", 1) && M >= knob("QLLM_PANEL_GROUP_MIN_M", 17) && w[0].K % 64 == 0 &&
-        (w[0].group_size == 32 || w[0].group_size == 64 || w[0].group_size == 128)) {
-      bool all64 = true;
-      for (int i = 0; i < n; ++i) all64 = all64 && w[i].N % 64 == 0 && !w[i].g_idx && w[i].bits == 4 && is_native(w[i]);
-      if (all64) return false;
+    if (n > 1 && sm && knob("QLLM_PANEL", 1) && M >= knob("QLLM_PANEL_GROUP_MIN_M", 17)) {
+      bool all_ok = true;
+      for (int i = 0; i < n; ++i)
+        all_ok = all_ok && !w[i].g_idx && w[i].bits == w[0].bits && is_native(w[i]) && panel_shape_ok(M, w[i].K, w[i].N, w[i].group_size, w[i].bits);
+      if (all_ok) return false;
     }
   }
   if (M > 64 || strip_min_strips() <= 0) return false;
@@ -508,8 +508,8 @@ static int run_tile_gemm(GemmParams &p, int layout, void *workspace, size_t work
 static bool panel_layers_ok(const qllm_weight_t *w, int n, int M) {
   if (!knob("QLLM_PANEL", 1) || n < 1 || n > kMaxProblems) return false;
   for (int i = 0; i < n; ++i) {
-    if (w[i].bits != 4 || !is_native(w[i]) || w[i].g_idx || w[i].K != w[0].K || w[i].group_size != w[0].group_size) return false;
-    if (!panel_shape_ok(M, w[i].K, w[i].N, w[i].group_size)) return false;
+    if ((w[i].bits != 4 && w[i].bits != 3) || w[i].bits != w[0].bits || !is_native(w[i]) || w[i].g_idx || w[i].K != w[0].K || w[i].group_size != w[0].group_size) return false;
+    if (!panel_shape_ok(M, w[i].K, w[i].N, w[i].group_size, w[i].bits)) return false;
     if ((uintptr_t)w[i].qweight % 16 || (uintptr_t)w[i].scales % 16 || (w[i].qzeros && (uintptr_t)w[i].qzeros % 8)) return false;
   }
   return true;
@@ -544,6 +544,7 @@ static int run_panel(const qllm_weight_t *w, void *const *y, int n, const void *
   p.M = M;
   p.K = w[0].K;
   p.group_size = w[0].group_size;
+  p.bits = w[0].bits;
   p.n_groups = (w[0].K + w[0].group_size - 1) / w[0].group_size;
   p.add_zero_bias = w[0].add_zero_bias;
   p.act_bf16 = (act_dtype == QLLM_BF16);
@@ -577,8 +578,9 @@ static int run_panel(const qllm_weight_t *w, void *const *y, int n, const void *
 
 static bool native_prefill_ok(const qllm_weight_t *w, GemmParams &p) {
   if ((uintptr_t)w->qweight % 16 || (uintptr_t)w->scales % 16 || (w->qzeros && (uintptr_t)w->qzeros % 8)) return false;
+  if (panel_serves(w, p)) return true;
   if (w->bits == 3) return gemm3_ok(p, kGemm3Rows3Bit);
-  return w->bits == 4 && (panel_serves(w, p) || gemm2_ok(p, QLLM_LAYOUT_GPTQ));
+  return w->bits == 4 && gemm2_ok(p, QLLM_LAYOUT_GPTQ);
 }
 static int native_prefill(const qllm_weight_t *w, const void *x, void *y, int M, int act_dtype, void *workspace, size_t workspace_bytes,
                           hipStream_t stream) {
@@ -587,11 +589,11 @@ static int native_prefill(const qllm_weight_t *w, const void *x, void *y, int M,
   if (!native_prefill_ok(w, p))
     return set_error(QLLM_ERR_UNSUPPORTED, "native-layout layer: no fused kernel for M=%d K=%d N=%d g=%d bits=%d (decode sizes, and M > 64 with "
                      "K %% 64 == 0, N %% 128 == 0 and a power-of-two group size, are served)", M, w->K, w->N, w->group_size, w->bits);
+  if (panel_serves(w, p)) return run_panel(w, &y, 1, x, M, act_dtype, workspace, workspace_bytes, stream);
   if (w->bits == 3) {
     gemm3_use_split(p, workspace, workspace_bytes);
     return launch_gemm3(p, kGemm3Rows3Bit, stream);
   }
-  if (panel_serves(w, p)) return run_panel(w, &y, 1, x, M, act_dtype, workspace, workspace_bytes, stream);
   return run_tile_gemm(p, QLLM_LAYOUT_GPTQ, workspace, workspace_bytes, stream);
 }
 
@@ -829,17 +831,17 @@ int qllm_plan_describe(const qllm_weight_t *w, int32_t n_weights, int32_t M, int
     GemmParams p;
     fill_gemm_params(p, &w[0], nullptr, nullptr, M, QLLM_F16);
     if (panel_group_serves(w, n_weights, M)) {
-      snprintf(buf, buflen, "panel cols=64 row_tiles=%d k_halves=%d split_k=%d layers=%d layout=strip-major", panel_mt(M), panel_kh(M),
-               have_workspace ? panel_split_k(M, panels_of(w, n_weights), w[0].K) : 1, n_weights);
+      snprintf(buf, buflen, "panel cols=64 row_tiles=%d k_halves=%d split_k=%d layers=%d%s layout=strip-major", panel_mt(M), panel_kh(M),
+               have_workspace ? panel_split_k(M, panels_of(w, n_weights), w[0].K) : 1, n_weights, w[0].bits == 3 ? " bits=3" : "");
     } else if (n_weights != 1 || !native_prefill_ok(&w[0], p)) {
       snprintf(buf, buflen, "unsupported (native layout: decode sizes, or M > 64 with K %% 64 == 0, N %% 128 == 0)");
+    } else if (panel_serves(&w[0], p)) {
+      snprintf(buf, buflen, "panel cols=64 row_tiles=%d k_halves=%d split_k=%d%s layout=strip-major", panel_mt(M), panel_kh(M),
+               have_workspace ? panel_split_k(M, w[0].N / 64, w[0].K) : 1, w[0].bits == 3 ? " bits=3" : "");
     } else if (w[0].bits == 3) {
       const int S = have_workspace ? gemm3_split_k(M, w[0].N, w[0].K) : 1;
       if (S > 1) snprintf(buf, buflen, "gemm3 tile=256x128 matrix-waves=8 staging-waves=4 bits=3 split_k=%d layout=strip-major", S);
       else snprintf(buf, buflen, "gemm3 tile=256x128 matrix-waves=8 staging-waves=4 bits=3 layout=strip-major");
-    } else if (panel_serves(&w[0], p)) {
-      snprintf(buf, buflen, "panel cols=64 row_tiles=%d k_halves=%d split_k=%d layout=strip-major", panel_mt(M), panel_kh(M),
-               have_workspace ? panel_split_k(M, w[0].N / 64, w[0].K) : 1);
     } else {
       const int S2 = gemm2_split_k(M, w[0].N, w[0].K), S3 = gemm3_split_k(M, w[0].N, w[0].K);
       if (gemm3_ok(p, QLLM_LAYOUT_GPTQ) && (S2 == 1 || (have_workspace && S3 > 1))) {

@@ -148,12 +148,12 @@ struct PanelProblem {
 };
 struct PanelParams {
   const void *x;
-  int M, K, n_groups, group_size, add_zero_bias, act_bf16, n_prob, split_k, abl, n_panels;
+  int M, K, n_groups, group_size, bits, add_zero_bias, act_bf16, n_prob, split_k, abl, n_panels;
   float *slabs;   // split-K: [panels][split_k][4 waves x row tiles x 4 x 64] fp32 partial panels
   int *counters;  // split-K: one arrival counter per panel (zero before and after the launch)
   PanelProblem prob[kMaxProblems];
 };
-bool panel_shape_ok(int M, int K, int N, int group_size);
+bool panel_shape_ok(int M, int K, int N, int group_size, int bits);
 int panel_mt(int M);
 int panel_kh(int M);
 int panel_split_k(int M, int n_panels, int K);

@@ -23,7 +23,8 @@
 //   * split-K: fp32 partial panels through write-through slabs + one ticket per panel, summed by the last arriver in split order
 //     (the protocol of gemm2.hip / skinny.hip: deterministic; ~6 us when it is needed: profiles/r04_mid_m.md);
 //   * epilogue through LDS: 128-byte row-contiguous stores.
-// K % 64 == 0, N % 64 == 0, 4 bits, group size 32 / 64 / 128.  Replaces, for these batch sizes, the dequantise-then-matmul forward
+// K % 64 == 0, N % 64 == 0; 4 bits with group size 32 / 64 / 128, or the 3-bit stream with 64 / 128 (up to 64 rows: patterns minus
+// 1024 + f z, times 1 / f -- exact q - z as well).  Replaces, for these batch sizes, the dequantise-then-matmul forward
 // of /root/reference/qllm/modeling/q_layers/quant_linear_gptq.py:81-85 (and quant_linear_hqq.py, quant_linear_awq.py through the
 // native copy).
 #include "kernels.hpp"
@@ -39,7 +40,7 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 // KH: K halves per block (1 or 2).  KH = 2: eight waves, waves 4..7 run the same four strips over the second half of the block's K
 // range with A buffers of their own; the halves are summed through LDS before the epilogue -- half the global splits for the same
 // number of waves in flight (the cross-block sum costs ~6 us when it is needed at all: profiles/r04_mid_m.md).
-template <int MT, int CPL, int KH, int SPG, bool BF16, bool ZF16>
+template <int MT, int CPL, int KH, int SPG, int BITS, bool BF16, bool ZF16>
 __global__ __launch_bounds__(kPanelWaves * KH * 64, 1) void panel_kernel(const PanelParams p) {
   constexpr int NW = kPanelWaves;             // waves of one K half = strips of the panel / CPL
   constexpr int KTS = kPanelKTS;              // (MT = 4: 64 KB of A buffers -> two blocks per CU; MT = 8: 128 KB)
@@ -51,6 +52,9 @@ __global__ __launch_bounds__(kPanelWaves * KH * 64, 1) void panel_kernel(const P
   constexpr int PCOLS = 16 * CPL * NW;        // columns of a panel
   constexpr int EPS = PCOLS + 8;              // epilogue row stride in halves (16-byte aligned, bank-spread)
   static_assert(KTS % SPG == 0 && PPW * NW == KP * MT * 2, "tile geometry");
+  static_assert(BITS == 4 || BITS == 3, "4 bits, or the 3-bit stream of the strips (32 k = 3 words per column)");
+  constexpr int WR = (BITS == 4) ? 4 : 3;     // word rows per k-step
+  constexpr bool Z2 = BITS == 3 && !ZF16;     // packed 3-bit zero points: the field may straddle into a second word
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // A[KH][2][TILE_BYTES]; the epilogue re-uses it
 
   const int lane = threadIdx.x & 63;
@@ -82,7 +86,7 @@ __global__ __launch_bounds__(kPanelWaves * KH * 64, 1) void panel_kernel(const P
 
   // ---- addressing: raw buffer loads, per-lane byte offset (loop constant) + wave-uniform scalar offset ---------------------
   const int strip0 = (panel * NW + wave) * CPL;  // this wave's first 16-column strip
-  const int strip_bytes = T * 256;
+  const int strip_bytes = T * WR * 64;
   const int gtab = p.n_groups, Gmax = gtab - 1;
   const int zk = pr.zero_kind;
   const int zgroup = (zk == ZK_PACKED) ? 8 : 32;  // zero-point bytes per (strip, group); symmetric layers re-read their scales
@@ -91,8 +95,15 @@ __global__ __launch_bounds__(kPanelWaves * KH * 64, 1) void panel_kernel(const P
   const auto rs_z = __builtin_amdgcn_make_buffer_rsrc((zk == ZK_SYM) ? (void *)pr.scales : (void *)pr.qzeros, 0, (N >> 4) * gtab * zgroup, 0x00020000);
   const auto rs_x = __builtin_amdgcn_make_buffer_rsrc((void *)p.x, 0, (int)min((size_t)M * p.K * 2, (size_t)0x7fffffff), 0x00020000);
   const int lane_w = (g * 16 + i) * 4, lane_s = i * 2;
-  const int lane_z = (zk == ZK_PACKED) ? (i >> 3) * 4 : ((zk == ZK_F16) ? (i >> 1) * 4 : 0);
-  const uint32_t zsh = (zk == ZK_PACKED) ? (uint32_t)(4 * (i & 7)) : (uint32_t)(16 * (i & 1));
+  // 3 bits: lane group g needs stream bits [24 g, 24 g + 24) of the k-step's 96 = words {0,0,1,2}[g] and {0,1,2,2}[g], funnel-shifted
+  const int lane_w3_lo = ((g == 0 ? 0 : g - 1) * 16 + i) * 4, lane_w3_hi = ((g == 3 ? 2 : g) * 16 + i) * 4;
+  const uint32_t shift3 = (uint32_t)((32 - 8 * g) & 31);
+  // zero points: the word holding this lane's column -- packed 4-bit: nibble i%8 of word i/8; packed 3-bit: bit 3i of the 64-bit pair
+  // (the field may straddle into the second word); fp16: half i%2 of word i/2
+  const int zoff = (zk == ZK_PACKED) ? (BITS == 3 ? (i * 3) >> 5 : (i >> 3)) : ((zk == ZK_F16) ? (i >> 1) : 0);
+  const int lane_z = zoff * 4;
+  const int lane_z2 = (BITS == 3 && zk == ZK_PACKED && zoff == 0) ? 4 : lane_z;
+  const uint32_t zsh = (zk == ZK_PACKED) ? (uint32_t)((BITS == 3 ? 3 * i : 4 * i) & 31) : (uint32_t)(16 * (i & 1));
   // A pieces of this wave: q = wave + NW r  ->  half h = wave & 1, row tile (q >> 1) % MT, k-pair (q >> 1) / MT
   const int ph = wave & 1;
   int a_voff[NMT];
@@ -109,7 +120,12 @@ __global__ __launch_bounds__(kPanelWaves * KH * 64, 1) void panel_kernel(const P
   const uint32_t mask_lo = nib_mask_vgpr(), mask_hi = mask_lo << 4;
   constexpr uint32_t kMagic64 = 0x54005400u;  // (64.0h, 64.0h): a nibble at bits 4-7 of an fp16 in [64, 128) weighs exactly 1
 
-  uint32_t w[2][KTS][CPL], zr[2][NGT][CPL];
+  // 3-bit field masks, derived from the opaque VGPR so hipcc can fuse each (x & m) | magic into one v_and_or_b32 (strip_kernel.hpp)
+  const uint32_t m3a = ((mask_lo & 0x7u) << 1) | (mask_lo & 0x00070000u);  // 0x0007000E
+  const uint32_t m3b = m3a << 3, m3c = m3a << 6;
+  const uint32_t m3d = mask_lo & 0x00000007u, m3e = mask_lo & 0x00070000u;
+
+  uint32_t w[2][KTS][CPL], w_hi[2][BITS == 3 ? KTS : 1][CPL], zr[2][NGT][CPL], zr2[2][Z2 ? NGT : 1][CPL];
   half_t sc[2][NGT][CPL];
   float4_t yacc[MT][CPL];
 #pragma unroll
@@ -143,13 +159,21 @@ __global__ __launch_bounds__(kPanelWaves * KH * 64, 1) void panel_kernel(const P
         const int sg = (strip0 + c) * gtab + G;
         sc[set][j][c] = __builtin_bit_cast(half_t, __builtin_amdgcn_raw_buffer_load_b16(rs_s, lane_s, sg * 32, 2));
         zr[set][j][c] = __builtin_amdgcn_raw_buffer_load_b32(rs_z, lane_z, sg * zgroup, 2);
+        if constexpr (Z2) zr2[set][j][c] = __builtin_amdgcn_raw_buffer_load_b32(rs_z, lane_z2, sg * zgroup, 2);
       }
     }
 #pragma unroll
     for (int s = 0; s < KTS; ++s)
 #pragma unroll
-      for (int c = 0; c < CPL; ++c)
-        w[set][s][c] = __builtin_amdgcn_raw_buffer_load_b32(rs_w, lane_w, (strip0 + c) * strip_bytes + min(tb + s, T - 1) * 256, 2);
+      for (int c = 0; c < CPL; ++c) {
+        const int so = (strip0 + c) * strip_bytes + min(tb + s, T - 1) * (WR * 64);
+        if constexpr (BITS == 4) {
+          w[set][s][c] = __builtin_amdgcn_raw_buffer_load_b32(rs_w, lane_w, so, 2);
+        } else {
+          w[set][s][c] = __builtin_amdgcn_raw_buffer_load_b32(rs_w, lane_w3_lo, so, 2);
+          w_hi[set][s][c] = __builtin_amdgcn_raw_buffer_load_b32(rs_w, lane_w3_hi, so, 2);
+        }
+      }
   };
 
   // One K-tile.  The issue order is pinned (sched_barrier): left alone, hipcc sinks every fragment read to just above its first use
@@ -158,7 +182,9 @@ __global__ __launch_bounds__(kPanelWaves * KH * 64, 1) void panel_kernel(const P
     const uint8_t *ab = smem + (kh * 2 + buf) * TILE_BYTES;
     float4_t gacc[MT][CPL];
     uint4_t ar[2][MT];
-    half2_t nz_lo[CPL], nz_hi[CPL];  // minus (bias + z) of the current group (ZF16: minus z)
+    // minus (bias + f z) of the current group for the four slot pairs (ZF16: minus z).  4 bits: pairs 0 / 2 carry bias 1024, pairs
+    // 1 / 3 bias 64, f = 1; 3 bits: bias 1024 everywhere, slot factors (2,1 | 16,8 | 128,64 | 1,1) on slots (k0,k5 | k1,k6 | k2,k7 | k3,k4)
+    half2_t nz[CPL][4];
     auto read_a = [&](const int s, uint4_t (&dst)[MT]) __attribute__((always_inline)) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) dst[mt] = *(const uint4_t *)(ab + ((s >> 1) * MT + mt) * 2048 + a_rd[s & 1]);
@@ -173,15 +199,23 @@ __global__ __launch_bounds__(kPanelWaves * KH * 64, 1) void panel_kernel(const P
       if (s % SPG == 0) {
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
-          const uint32_t field = zr[set][j][c] >> zsh;
+          uint32_t field;
+          if constexpr (Z2) field = (uint32_t)(((((uint64_t)zr2[set][j][c]) << 32) | zr[set][j][c]) >> zsh);
+          else field = zr[set][j][c] >> zsh;
           if constexpr (ZF16) {
             const half_t z = __builtin_bit_cast(half_t, (uint16_t)field);
-            nz_lo[c] = splat2(-z);
-            nz_hi[c] = nz_lo[c];
+            nz[c][0] = nz[c][1] = nz[c][2] = nz[c][3] = splat2(-z);
           } else {
-            const float zf = (zk == ZK_PACKED) ? (float)((field + (uint32_t)p.add_zero_bias) & 15u) : 8.f;
-            nz_lo[c] = splat2((half_t)(-1024.f - zf));  // exact: integers below 2048
-            nz_hi[c] = splat2((half_t)(-64.f - zf));
+            const float zf = (zk == ZK_PACKED) ? (float)((field + (uint32_t)p.add_zero_bias) & (uint32_t)((1 << BITS) - 1)) : (float)(1 << (BITS - 1));
+            if constexpr (BITS == 4) {
+              nz[c][0] = nz[c][2] = splat2((half_t)(-1024.f - zf));  // exact: integers below 2048
+              nz[c][1] = nz[c][3] = splat2((half_t)(-64.f - zf));
+            } else {
+              nz[c][0] = half2_t{(half_t)(-1024.f - 2.f * zf), (half_t)(-1024.f - zf)};
+              nz[c][1] = half2_t{(half_t)(-1024.f - 16.f * zf), (half_t)(-1024.f - 8.f * zf)};
+              nz[c][2] = half2_t{(half_t)(-1024.f - 128.f * zf), (half_t)(-1024.f - 64.f * zf)};
+              nz[c][3] = splat2((half_t)(-1024.f - zf));
+            }
           }
         }
       }
@@ -190,19 +224,43 @@ __global__ __launch_bounds__(kPanelWaves * KH * 64, 1) void panel_kernel(const P
       for (int mt = 0; mt < MT; ++mt) av[mt] = __builtin_bit_cast(half8_t, ar[s & 1][mt]);
 #pragma unroll
       for (int c = 0; c < CPL; ++c) {
-        const uint32_t wv = w[set][s][c], w8 = wv >> 8;
-        half2_t b0 = as_h2((wv & mask_lo) | kMagic), b1 = as_h2((wv & mask_hi) | kMagic64);
-        half2_t b2 = as_h2((w8 & mask_lo) | kMagic), b3 = as_h2((w8 & mask_hi) | kMagic64);
-        if constexpr (ZF16) {
-          const half2_t m1024 = splat2((half_t)-1024.f), m64 = splat2((half_t)-64.f);
-          b0 = (b0 + m1024) + nz_lo[c]; b1 = (b1 + m64) + nz_lo[c]; b2 = (b2 + m1024) + nz_lo[c]; b3 = (b3 + m64) + nz_lo[c];
+        half2_t b0, b1, b2, b3;
+        uint32_t c0, c1, c2, c3;
+        if constexpr (BITS == 4) {
+          const uint32_t wv = w[set][s][c], w8 = wv >> 8;
+          b0 = as_h2((wv & mask_lo) | kMagic); b1 = as_h2((wv & mask_hi) | kMagic64);
+          b2 = as_h2((w8 & mask_lo) | kMagic); b3 = as_h2((w8 & mask_hi) | kMagic64);
+          if constexpr (ZF16) {
+            const half2_t m1024 = splat2((half_t)-1024.f), m64 = splat2((half_t)-64.f);
+            b0 = (b0 + m1024) + nz[c][0]; b1 = (b1 + m64) + nz[c][1]; b2 = (b2 + m1024) + nz[c][2]; b3 = (b3 + m64) + nz[c][3];
+          } else {
+            b0 = b0 + nz[c][0]; b1 = b1 + nz[c][1]; b2 = b2 + nz[c][2]; b3 = b3 + nz[c][3];
+          }
+          // registers hold (k0,k4) (k1,k5) (k2,k6) (k3,k7): four v_perm_b32 put them in natural order (k0,k1) (k2,k3) (k4,k5) (k6,k7):
+          // the permutation is paid once per k-step and strip here, not once per row tile on the A fragments
+          c0 = __builtin_amdgcn_perm(as_u32(b1), as_u32(b0), 0x05040100u); c2 = __builtin_amdgcn_perm(as_u32(b1), as_u32(b0), 0x07060302u);
+          c1 = __builtin_amdgcn_perm(as_u32(b3), as_u32(b2), 0x05040100u); c3 = __builtin_amdgcn_perm(as_u32(b3), as_u32(b2), 0x07060302u);
         } else {
-          b0 = b0 + nz_lo[c]; b1 = b1 + nz_hi[c]; b2 = b2 + nz_lo[c]; b3 = b3 + nz_hi[c];
+          // f: the lane's 8 three-bit values at bits 0,3,..,21 (strip_kernel.hpp): patterns 1024 + (2 q0, q5 | 16 q1, 8 q6 | 128 q2, 64 q7 |
+          // q3, q4); minus 1024 + f z: exact f (q - z); times 1 / f (powers of two): exact q - z
+          const uint32_t f = __builtin_amdgcn_alignbit(w_hi[set][s][c], w[set][s][c], shift3);
+          const uint32_t f1 = f << 1;
+          b0 = as_h2((f1 & m3a) | kMagic);
+          b1 = as_h2((f1 & m3b) | kMagic);
+          b2 = as_h2((f1 & m3c) | kMagic);
+          const uint32_t lo34 = ((f >> 9) & m3d) | kMagic;
+          b3 = as_h2(((f << 4) & m3e) | lo34);
+          const half2_t r0 = {(half_t)0.5f, (half_t)1.f}, r1 = {(half_t)0.0625f, (half_t)0.125f}, r2 = {(half_t)0.0078125f, (half_t)0.015625f};
+          if constexpr (ZF16) {
+            const half2_t m1024 = splat2((half_t)-1024.f);
+            b0 = (b0 + m1024) * r0 + nz[c][0]; b1 = (b1 + m1024) * r1 + nz[c][1]; b2 = (b2 + m1024) * r2 + nz[c][2]; b3 = (b3 + m1024) + nz[c][3];
+          } else {
+            b0 = (b0 + nz[c][0]) * r0; b1 = (b1 + nz[c][1]) * r1; b2 = (b2 + nz[c][2]) * r2; b3 = b3 + nz[c][3];
+          }
+          // slots (k0,k5) (k1,k6) (k2,k7) (k3,k4) -> natural order
+          c0 = __builtin_amdgcn_perm(as_u32(b1), as_u32(b0), 0x05040100u); c1 = __builtin_amdgcn_perm(as_u32(b3), as_u32(b2), 0x05040100u);
+          c2 = __builtin_amdgcn_perm(as_u32(b0), as_u32(b3), 0x07060302u); c3 = __builtin_amdgcn_perm(as_u32(b2), as_u32(b1), 0x07060302u);
         }
-        // registers hold (k0,k4) (k1,k5) (k2,k6) (k3,k7): four v_perm_b32 put them in natural order (k0,k1) (k2,k3) (k4,k5) (k6,k7):
-        // the permutation is paid once per k-step and strip here, not once per row tile on the A fragments
-        const uint32_t c0 = __builtin_amdgcn_perm(as_u32(b1), as_u32(b0), 0x05040100u), c2 = __builtin_amdgcn_perm(as_u32(b1), as_u32(b0), 0x07060302u);
-        const uint32_t c1 = __builtin_amdgcn_perm(as_u32(b3), as_u32(b2), 0x05040100u), c3 = __builtin_amdgcn_perm(as_u32(b3), as_u32(b2), 0x07060302u);
         const half8_t bf = __builtin_bit_cast(half8_t, uint4_t{c0, c1, c2, c3});
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) gacc[mt][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[mt], bf, (s % SPG == 0) ? zero4 : gacc[mt][c], 0, 0, 0);
@@ -336,19 +394,19 @@ __global__ __launch_bounds__(kPanelWaves * KH * 64, 1) void panel_kernel(const P
   }
 }
 
-template <int MT, int KH, int SPG, bool BF16>
+template <int MT, int KH, int SPG, int BITS, bool BF16>
 int launch_z(const PanelParams &p, int grid, hipStream_t stream) {
   const size_t lds = (size_t)KH * 2 * (kPanelKTS / 2) * MT * 2048;
   bool all_f16 = true;  // (the fp16-zero-point form: every layer of the launch)
   for (int i = 0; i < p.n_prob; ++i) all_f16 = all_f16 && p.prob[i].zero_kind == ZK_F16;
   if (all_f16) {
     static DeviceLatch done;
-    if (int rc = lds_optin(done, (const void *)panel_kernel<MT, 1, KH, SPG, BF16, true>)) return rc;
-    hipLaunchKernelGGL((panel_kernel<MT, 1, KH, SPG, BF16, true>), dim3(grid), dim3(kPanelWaves * KH * 64), lds, stream, p);
+    if (int rc = lds_optin(done, (const void *)panel_kernel<MT, 1, KH, SPG, BITS, BF16, true>)) return rc;
+    hipLaunchKernelGGL((panel_kernel<MT, 1, KH, SPG, BITS, BF16, true>), dim3(grid), dim3(kPanelWaves * KH * 64), lds, stream, p);
   } else {
     static DeviceLatch done;
-    if (int rc = lds_optin(done, (const void *)panel_kernel<MT, 1, KH, SPG, BF16, false>)) return rc;
-    hipLaunchKernelGGL((panel_kernel<MT, 1, KH, SPG, BF16, false>), dim3(grid), dim3(kPanelWaves * KH * 64), lds, stream, p);
+    if (int rc = lds_optin(done, (const void *)panel_kernel<MT, 1, KH, SPG, BITS, BF16, false>)) return rc;
+    hipLaunchKernelGGL((panel_kernel<MT, 1, KH, SPG, BITS, BF16, false>), dim3(grid), dim3(kPanelWaves * KH * 64), lds, stream, p);
   }
   QLLM_HIP_CHECK(hipGetLastError());
   return QLLM_OK;
@@ -358,19 +416,25 @@ int launch_z(const PanelParams &p, int grid, hipStream_t stream) {
 //  64-column panels, 11008 -> 4096 24.2-24.7 against 21.4-22.2; not built)
 template <int MT, int KH, bool BF16>
 int launch_g(const PanelParams &p, int grid, hipStream_t stream) {
+  if (p.bits == 3) {  // the 3-bit stream of the strips: 64- / 128-wide groups, up to 64 rows
+    if constexpr (MT > 4) return set_error(QLLM_ERR_UNSUPPORTED, "internal: 3-bit panels are served up to 64 rows");
+    else return p.group_size == 64 ? launch_z<MT, KH, 2, 3, BF16>(p, grid, stream) : launch_z<MT, KH, 4, 3, BF16>(p, grid, stream);
+  }
   if (p.group_size == 32) {
     if constexpr (MT > 4) return set_error(QLLM_ERR_UNSUPPORTED, "internal: 32-wide groups are served up to 64 rows");  // (eight row tiles spill there)
-    else return launch_z<MT, KH, 1, BF16>(p, grid, stream);
+    else return launch_z<MT, KH, 1, 4, BF16>(p, grid, stream);
   }
-  if (p.group_size == 64) return launch_z<MT, KH, 2, BF16>(p, grid, stream);
-  return launch_z<MT, KH, 4, BF16>(p, grid, stream);
+  if (p.group_size == 64) return launch_z<MT, KH, 2, 4, BF16>(p, grid, stream);
+  return launch_z<MT, KH, 4, 4, BF16>(p, grid, stream);
 }
 
 }  // namespace
 
 // whole 64-column panels, whole k-step pairs, the group sizes of the strips (callers: native strip-major 4-bit layers, no g_idx)
-bool panel_shape_ok(int M, int K, int N, int group_size) {
-  return M >= 2 && M <= 128 && K % 64 == 0 && N % 64 == 0 && ((group_size == 32 && M <= 64) || group_size == 64 || group_size == 128) &&
+bool panel_shape_ok(int M, int K, int N, int group_size, int bits) {
+  if (bits == 3) return M >= 2 && M <= 64 && K % 64 == 0 && N % 64 == 0 && (group_size == 64 || group_size == 128) && K % group_size == 0 &&
+                        (double)K * N * 3 / 8 < 2147483648.0;
+  return bits == 4 && M >= 2 && M <= 128 && K % 64 == 0 && N % 64 == 0 && ((group_size == 32 && M <= 64) || group_size == 64 || group_size == 128) &&
          K % group_size == 0 && (double)K * N / 2 < 2147483648.0;
 }
 

@@ -209,12 +209,12 @@ def test_sibling_groups_take_one_panel_launch_from_17_rows():
     """q/k/v and gate/up at 17..128 rows: ONE grouped launch of the panel kernel (csrc/panel.hip) for the whole group."""
     from qllm_amd import ops
     from qllm_amd.modeling.q_layers import fuse_siblings
-    for widths, layout, g_ in (((H, 1024, 1024), "GPTQ", 128), ((I, I), "GEMM", 128), ((H, H, H), "HQQ", 64)):
-        ds = [synth(layout, 4, g_, H, n, seed=50 + i, bias=(i == 1)) for i, n in enumerate(widths)]
+    for widths, layout, g_, bits in (((H, 1024, 1024), "GPTQ", 128, 4), ((I, I), "GEMM", 128, 4), ((H, H, H), "HQQ", 64, 4), ((H, H, H), "HQQ", 64, 3)):
+        ds = [synth(layout, bits, g_, H, n, seed=50 + i, bias=(i == 1)) for i, n in enumerate(widths)]
         layers = [to_layer(d, DEV) for d in ds]
         grp = fuse_siblings(layers)
         for m in (17, 40, 64, 100, 128):
-            if m > 64 and sum(widths) > 16384:   # (65..128 rows: groups of up to 16384 columns)
+            if m > 64 and (sum(widths) > 16384 or bits == 3):   # (65..128 rows: 4 bits, groups of up to 16384 columns)
                 assert grp.describe(m).startswith("unsupported")
                 continue
             assert grp.describe(m).startswith("panel ") and f"layers={len(widths)}" in grp.describe(m), grp.describe(m)

@@ -134,7 +134,8 @@ def test_native_layout_decode_routes(lib):
         # K >= 2 N from 9 rows: the panel kernel (a one-strip block pulls all of x through its CU: 13.4 -> 12.0 us at M = 16)
         assert plan(lib, [down], m) == ("strip nw=16 cpl=1 spw=24 form=dma-A row_tiles=1" if m < 9 else "panel cols=64 row_tiles=1 k_halves=2 split_k=4") + sm
     assert plan(lib, [W(11008, 4096, 64, 4, NATIVE_F16Z)], 16) == "panel cols=64 row_tiles=1 k_halves=2 split_k=4" + sm   # (BASELINE configs[3] down_proj)
-    assert plan(lib, [W(11008, 4096, 64, 3, NATIVE_F16Z)], 16).startswith("strip ")                                       # (3 bits: strips)
+    assert plan(lib, [W(11008, 4096, 64, 3, NATIVE_F16Z)], 16) == "panel cols=64 row_tiles=1 k_halves=2 split_k=4 bits=3" + sm   # (3 bits too)
+    assert plan(lib, [W(11008, 4096, 64, 3, NATIVE_F16Z)], 8).startswith("strip ")
     # ... wide (grouped) launches: blocks of several adjacent strips share one activation stream -- as many as make the launch ONE
     # round of blocks: q/k/v 768 strips -> 192 blocks of four; gate/up 1376 strips -> 230 blocks of six, the last of each layer ragged
     assert plan(lib, [attn] * 3, 16) == "strip nw=8 cpl=4 spw=16 form=dma-A row_tiles=1" + sm
@@ -166,7 +167,9 @@ def test_native_layout_decode_routes(lib):
     assert plan(lib, [attn], 65) == plan(lib, [attn], 128) == "panel cols=64 row_tiles=8 k_halves=1 split_k=4" + sm
     assert plan(lib, [attn], 64, have_ws=0) == "panel cols=64 row_tiles=4 k_halves=2 split_k=1" + sm      # no workspace: no split
     assert plan(lib, [attn], 129) == "gemm2 tile=256x128 split_k=8" + sm
-    assert plan(lib, [W(4096, 1024, 128, 3, NATIVE)] * 3, 32).startswith("strip ")                 # (3 bits: strips, up to 32 rows)
+    assert plan(lib, [W(4096, 1024, 128, 3, NATIVE)] * 3, 32) == "panel cols=64 row_tiles=2 k_halves=2 split_k=4 layers=3 bits=3" + sm
+    assert plan(lib, [W(4096, 1024, 128, 3, NATIVE)] * 3, 16).startswith("strip ")                 # (3 bits below 17 rows: strips)
+    assert plan(lib, [W(4096, 1024, 128, 3, NATIVE)] * 3, 65).startswith("unsupported")            # (3-bit panels stop at 64 rows)
     assert plan(lib, [W(4096, 4096, 64, layout=NATIVE_F16Z)], 48) == "panel cols=64 row_tiles=4 k_halves=2 split_k=4" + sm
     assert plan(lib, [W(4096, 4032, layout=NATIVE)], 48) == "panel cols=64 row_tiles=4 k_halves=2 split_k=4" + sm   # N % 64 == 0 is enough
     assert plan(lib, [W(4096, 4048, layout=NATIVE)], 48).startswith("strip ")                                        # ... N % 16 is not
@@ -190,8 +193,11 @@ def test_native_layout_decode_routes(lib):
     assert plan(lib, [W(11008, 4096, 64, 4, NATIVE_F16Z)], 1).startswith("strip nw=16 cpl=1 spw=22 form=register-A")
     assert plan(lib, [h3], 1).startswith("strip nw=16 cpl=1 spw=8 form=lds-slab")
     assert plan(lib, [h3], 16).startswith("strip nw=16 cpl=1 spw=8 form=dma-A")
-    assert plan(lib, [h3], 32).endswith("row_tiles=2" + sm)
-    assert plan(lib, [h3], 48).startswith("gemm3") and "bits=3" in plan(lib, [h3], 48)   # (four 3-bit row tiles would need > 256 registers)
+    # 3 bits from 17 rows: the panel kernel (exact q - z from the slot-scaled patterns), up to 64 rows; the 256-row tiles above
+    assert plan(lib, [h3], 32) == "panel cols=64 row_tiles=2 k_halves=2 split_k=4 bits=3" + sm
+    assert plan(lib, [h3], 48) == "panel cols=64 row_tiles=4 k_halves=2 split_k=4 bits=3" + sm
+    assert plan(lib, [h3], 65).startswith("gemm3") and "bits=3" in plan(lib, [h3], 65)
+    assert plan(lib, [W(4096, 4096, 128, 3, NATIVE)], 33) == "panel cols=64 row_tiles=4 k_halves=2 split_k=4 bits=3" + sm   # packed 3-bit zero points
     # 32-wide groups (4 bits, native layout only): one-round lds-slab blocks at batch 1 when a wave's chunk is exactly 8 k-steps (else
     # the register-A form); M = 2..32 the DMA form with shorter rings, blocks of one or two strips, chunks rounded to whole k-step pairs
     g32 = lambda K, N: W(K, N, 32, layout=NATIVE)  # noqa: E731

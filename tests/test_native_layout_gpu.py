@@ -177,20 +177,24 @@ PANEL_CASES = [  # layout, g, K, N, zero kind, bias
     ("HQQ", 64, 4096, 4096, "asym", True), ("GPTQ", 32, 2048, 1152, "asym", False), ("GPTQ", 128, 4096, 1024, "sym", True),
     ("GPTQ", 64, 2112, 4096, "asym", False), ("GEMM", 64, 1024, 512, "asym", True), ("HQQ", 64, 11008, 4096, "asym", False),
 ]
+PANEL_CASES_3BIT = [  # the 3-bit stream (up to 64 rows): fp16 (HQQ), packed and symmetric zero points, both group sizes, a ragged K
+    ("HQQ", 64, 4096, 4096, "asym", True), ("GPTQ", 128, 4096, 1024, "asym", False), ("HQQ", 64, 11008, 4096, "asym", False),
+    ("GPTQ", 64, 2112, 4096, "sym", True), ("GPTQ", 64, 1024, 512, "asym", False),
+]
 
 
-@pytest.mark.parametrize("layout,g,K,N,zk,bias", PANEL_CASES)
-def test_panel_kernel_vs_oracle(layout, g, K, N, zk, bias):
+@pytest.mark.parametrize("bits,layout,g,K,N,zk,bias", [(4,) + c for c in PANEL_CASES] + [(3,) + c for c in PANEL_CASES_3BIT])
+def test_panel_kernel_vs_oracle(bits, layout, g, K, N, zk, bias):
     """17 <= M <= 128 (from 9 rows where K >= 2 N) on native 4-bit layers: the panel kernel (csrc/panel.hip: 64-column panels, A tiles shared through LDS, B
     fragments q - z from registers, split-K partial panels through the workspace).  Every zero-point kind, g32 / g64 / g128, a K whose
     k-steps do not fill the last K-tile or split (2112 = 66 k-steps), bias, fp16 and bf16 activations, against the oracle."""
     from qllm_amd import ops
-    d = synth(layout, 4, g, K, N, zk, False, bias, seed=K + N + g)
+    d = synth(layout, bits, g, K, N, zk, False, bias, seed=K + N + g + bits)
     d["scales"] = (d["scales"].astype(np.float32) * (4096 / K) ** 0.5 * 0.5).astype(np.float16)
     layer = to_layer(d, DEV)
     if zk == "sym":
         layer._descriptor(None, 0)
-        src = ops.make_weight("GPTQ", layer.qweight, layer.scales, None, None, layer.bias, K, N, g, 4, 0)
+        src = ops.make_weight("GPTQ", layer.qweight, layer.scales, None, None, layer.bias, K, N, g, bits, 0)
         w, keep = ops.repack_native(*src)[0:2]
     else:
         w = layer.native_descriptor(0)
@@ -199,7 +203,7 @@ def test_panel_kernel_vs_oracle(layout, g, K, N, zk, bias):
         if m < 17 and K < 2 * N:  # (few rows: only where K >= 2 N)
             assert ops.plan_describe([w], m).startswith("strip "), (m, ops.plan_describe([w], m))
             continue
-        if m > 64 and (g == 32 or K * N > 2 ** 25):   # (eight row tiles: 64- / 128-wide groups, layers of up to 2^25 weights; else
+        if m > 64 and (g == 32 or bits == 3 or K * N > 2 ** 25):   # (eight row tiles: 4 bits, 64- / 128-wide groups, layers of up to 2^25 weights; else
             assert ops.plan_describe([w], m).startswith("gemm"), (m, ops.plan_describe([w], m))   # the 256-row tiles take over at 65 rows)
             continue
         assert ops.plan_describe([w], m).startswith("panel "), (m, ops.plan_describe([w], m))
@@ -214,7 +218,7 @@ def test_panel_kernel_vs_oracle(layout, g, K, N, zk, bias):
     y0 = ops.linear_forward(w, xt)
     for _ in range(3):
         assert torch.equal(ops.linear_forward(w, xt), y0)
-    for mb in (40, 128 if (g != 32 and K * N <= 2 ** 25) else 64):
+    for mb in (40, 128 if (g != 32 and bits == 4 and K * N <= 2 ** 25) else 64):
         xb = torch.from_numpy(randx(mb, K, seed=9)).to(DEV).to(torch.bfloat16)
         yb = ops.linear_forward(w, xb).float().cpu().numpy()
         assert O.rel_err(yb, ref.y64(xb.float().cpu().numpy().astype(np.float16))) <= 2e-2, mb
