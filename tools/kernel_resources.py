@@ -14,7 +14,7 @@ HIPCC = "/opt/rocm/bin/hipcc"
 
 def demangle(names):
     out = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout.split("\n")
-    return [o.replace("qllm::", "").split("(")[0].replace("void ", "") for o in out]
+    return [o.replace("(anonymous namespace)::", "").replace("qllm::", "").split("(")[0].replace("void ", "") for o in out]
 
 
 rows = []
