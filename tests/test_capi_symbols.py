@@ -114,3 +114,21 @@ def test_comm_entry_points_validate_before_any_device_work(lib):
     assert lib.qllm_comm_export(None, None) == _lib.QLLM_ERR_INVALID
     assert lib.qllm_comm_import(None, None) == _lib.QLLM_ERR_INVALID
     assert lib.qllm_comm_free(None) == _lib.QLLM_OK and lib.qllm_comm_close(None) == _lib.QLLM_OK   # NULL: nothing to do
+
+
+def test_workspace_bytes_cover_the_panel_kernels_partial_panels(lib):
+    """csrc/panel.hip splits K over blocks only if the caller's workspace holds the fp32 partial panels: a caller who sizes the
+    workspace with qllm_workspace_bytes() must get the split qllm_plan_describe() announces."""
+    import re
+    NATIVE = 3
+    buf = ctypes.create_string_buffer(256)
+    for K, N in ((4096, 4096), (4096, 11008), (11008, 4096), (8192, 1024), (1024, 8192)):
+        w = _lib.QllmWeight(16, 16, 16, None, None, K, N, 128, 4, NATIVE, 0)
+        for M in (9, 16, 17, 32, 33, 64, 65, 128):
+            assert lib.qllm_plan_describe(ctypes.byref(w), 1, M, 1, buf, 256) == 0
+            plan = buf.value.decode()
+            if not plan.startswith("panel "):
+                continue
+            S = int(re.search(r"split_k=(\d+)", plan).group(1))
+            slabs = (N // 64) * S * 4 * (4 if M <= 64 else 8) * 256 * 4 if S > 1 else 0
+            assert lib.qllm_workspace_bytes(ctypes.byref(w), M) >= 16384 + slabs, (K, N, M, plan)
