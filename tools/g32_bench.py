@@ -8,8 +8,8 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
-from gpu_util import synth, to_layer  # noqa: E402
+from bench import make_layer  # noqa: E402  (random packed layers straight on the device: no oracle involved)
+from qllm_amd.modeling.q_layers import QuantLinearGPTQ  # noqa: E402
 from qllm_amd import ops  # noqa: E402
 
 DEV = "cuda:0"
@@ -32,8 +32,8 @@ def timed(fn, iters=200):
 
 for g in (32, 128):
     for K, N in ((4096, 4096), (4096, 11008), (11008, 4096)):
-        d = synth("GPTQ", 4, g, K, N, seed=K + N)
-        layer = to_layer(d, DEV)
+        gen = torch.Generator(device=DEV).manual_seed(K + N)
+        layer = make_layer(QuantLinearGPTQ, K, N, DEV, gen, group=g)
         nat = layer.native_descriptor(0)
         layer._needs_reference = True
         layer.materialize_reference()

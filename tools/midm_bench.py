@@ -9,8 +9,8 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
-from gpu_util import synth, to_layer  # noqa: E402
+from bench import make_layer  # noqa: E402  (random packed layers straight on the device: no oracle involved)
+from qllm_amd.modeling.q_layers import QuantLinearGPTQ  # noqa: E402
 from qllm_amd import ops  # noqa: E402
 
 DEV = "cuda:0"
@@ -39,7 +39,8 @@ def timed(fns, iters=160):
 
 
 for K, N in ((4096, 4096), (4096, 11008), (11008, 4096)):
-    layers = [to_layer(synth("GPTQ", 4, G, K, N, seed=K + N + s), DEV) for s in range(SETS)]
+    gen = torch.Generator(device=DEV).manual_seed(K + N)
+    layers = [make_layer(QuantLinearGPTQ, K, N, DEV, gen, group=G) for _ in range(SETS)]
     nats = [l.native_descriptor(0) for l in layers]
     for l in layers:
         l._needs_reference = True
