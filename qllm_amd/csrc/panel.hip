@@ -1,5 +1,5 @@
-// Mid-batch "panel" kernel (round 4): y[M, N] = x[M, K] . dequant(W4) for 17 <= M <= 128 (from 9 rows where K >= 2 N) on the
-// strip-major native layout.
+// Mid-batch "panel" kernel (round 4): y[M, N] = x[M, K] . dequant(W) (4 bits, or 3) for 17 <= M <= 128 (from 9 rows where K >= 2 N)
+// on the strip-major native layout; one layer, or up to 8 layers sharing x (q/k/v, gate/up) in one launch.
 //
 // Why: between the strip kernels (M <= 32: every block re-reads ALL of x, which grows with M) and the 256-row prefill tiles there
 // was a hole -- gemm2 / gemm3 run 27-40 us per Llama-2-7B linear from M = 33 to M = 256 whatever M is, because their B tiles go
