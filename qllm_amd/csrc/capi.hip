@@ -125,6 +125,7 @@ static int strip_min_strips() {
 // cover the 256 CUs
 struct StripPlan {
   int cpl, nw, spw, ra, sm;
+  int one_nw, one_maxs;  // != 0: the batch-1 kernel (strip1_kernel.hpp) with this many waves x k-steps per wave
 };
 // diagnostics: timeline buffer handed to the native-layout decode launches (24 x u64 per launch), see qllm_debug_timeline()
 static uint64_t *g_timeline = nullptr;
@@ -140,6 +141,7 @@ static bool panel_rows_ok(int M, int K, int N) {
 }
 
 static bool strip_plan(const qllm_weight_t *w, int n, int M, StripPlan *plan) {
+  plan->one_nw = plan->one_maxs = 0;
   // measured (graph replay, us; split-K kernel -> strips with 2 / 4 row tiles): M=32: 4096x4096 28.3 -> 13.4, 4096x11008 54.9 -> 36.3,
   // 11008x4096 50.1 -> 30.3; M=64: 33.8 -> 22.6, 52.5 -> 61.5, 48.1 -> 53.9 -- four row tiles only pay on the small shape
   // M = 33..64 (four row tiles), us per linear, split-K kernel -> strips (profiles/r02_mid_m.md): 4096x4096 26.8/31.4/33.5 ->
@@ -264,6 +266,12 @@ static bool strip_plan(const qllm_weight_t *w, int n, int M, StripPlan *plan) {
         plan->spw = spw;
         plan->ra = ra;
         plan->sm = 1;
+        // batch 1, 4 bits, 128-wide groups: the specialised kernel (round 5; profiles/r05_decode_bisect.md)
+        int nw1 = 0, maxs1 = 0;
+        if (M == 1 && bits == 4 && w[0].group_size == 128 && knob("QLLM_STRIP1", 1) && strip1_shape(w[0].K, &nw1, &maxs1)) {
+          plan->one_nw = nw1;
+          plan->one_maxs = maxs1;
+        }
         return true;
       }
       if (nw == 16 || M > 16 || cpl > 1) break;
@@ -315,9 +323,34 @@ static bool strip_ok(const qllm_weight_t *w, int n, int M) {
   return strip_plan(w, n, M, &pl);
 }
 
+static int run_strip1(const StripPlan &pl, const qllm_weight_t *w, void *const *y, int n, const void *x, int act_dtype, hipStream_t stream) {
+  Strip1Params p;
+  memset(&p, 0, sizeof(p));
+  p.x = x;
+  p.T = w[0].K / 32;
+  p.n_groups = w[0].K / 128;
+  p.add_zero_bias = w[0].add_zero_bias;
+  p.act_bf16 = (act_dtype == QLLM_BF16);
+  p.dbg = (g_timeline && g_timeline_next < g_timeline_slots) ? g_timeline + 24 * (g_timeline_next++) : nullptr;
+  int max_strips = 0;
+  for (int i = 0; i < n; ++i) {
+    Strip1Problem &q = p.prob[i];
+    q.qweight = (const uint32_t *)w[i].qweight;
+    q.scales = (const half_t *)w[i].scales;
+    q.qzeros = w[i].qzeros;
+    q.bias = (const half_t *)w[i].bias;
+    q.y = y[i];
+    q.n_strips = w[i].N / 16;
+    q.zero_kind = zero_kind_of(w[i]);
+    max_strips = std::max(max_strips, q.n_strips);
+  }
+  return launch_strip1(p, pl.one_nw, pl.one_maxs, n, max_strips, stream);
+}
+
 static int run_strip(const qllm_weight_t *w, void *const *y, int n, const void *x, int M, int act_dtype, hipStream_t stream) {
   StripPlan pl;
   if (!strip_plan(w, n, M, &pl)) return set_error(QLLM_ERR_INVALID, "internal: strip plan");
+  if (pl.one_nw) return run_strip1(pl, w, y, n, x, act_dtype, stream);
   StripParams p;
   memset(&p, 0, sizeof(p));
   p.x = x;
@@ -823,6 +856,11 @@ int qllm_plan_describe(const qllm_weight_t *w, int32_t n_weights, int32_t M, int
   bool decode_ok = true;
   for (int i = 0; i < n_weights; ++i) decode_ok = decode_ok && (w[i].bits == 3 || is_native(w[i]) || skinny_ok(w[i], M));
   if ((n_weights > 1 || w[0].bits == 3 || is_native(w[0]) || skinny_ok(w[0], M)) && decode_ok && strip_plan(w, n_weights, M, &pl)) {
+    if (pl.one_nw) {
+      snprintf(buf, buflen, "strip1 nw=%d round=%d%s grid=strips x %d layout=strip-major", pl.one_nw, pl.one_maxs,
+               pl.one_nw * pl.one_maxs == w[0].K / 32 ? " exact" : "", n_weights);
+      return QLLM_OK;
+    }
     snprintf(buf, buflen, "strip nw=%d cpl=%d spw=%d form=%s row_tiles=%d%s", pl.nw, pl.cpl, pl.spw, pl.ra == 2 ? "dma-A" : (pl.ra ? "register-A" : "lds-slab"),
              M > 32 ? 4 : (M > 16 ? 2 : 1), pl.sm ? " layout=strip-major" : "");
     return QLLM_OK;

@@ -99,6 +99,28 @@ int launch_strip_dma_g32(const StripParams &p, int grid, hipStream_t stream);   
 int launch_strip_dma_g64(const StripParams &p, int grid, hipStream_t stream);   // strip_dma_g64.hip
 int launch_strip_dma_g128(const StripParams &p, int grid, hipStream_t stream);  // strip_dma_g128.hip
 
+// ---- strip1.hip (batch 1, native layout, 4 bits, 128-wide groups: strip1_kernel.hpp) -------------------------------------------
+struct Strip1Problem {  // 48 bytes
+  const uint32_t *qweight;  // native: [N/16][K/8][16] words
+  const half_t *scales;     // native: [N/16][K/128][16]
+  const void *qzeros;       // native: [N/16][K/128][2] words (packed), [N/16][K/128][16] halves (fp16), NULL (symmetric)
+  const half_t *bias;
+  void *y;
+  int n_strips;             // N / 16
+  int zero_kind;
+};
+struct Strip1Params {
+  const void *x;
+  int T;          // K / 32
+  int n_groups;   // K / 128
+  int add_zero_bias;
+  int act_bf16;
+  uint64_t *dbg;  // diagnostics (qllm_debug_timeline): 24 timestamps for this launch (3 blocks x 8), or NULL
+  Strip1Problem prob[kMaxProblems];
+};
+bool strip1_shape(int K, int *nw, int *maxs);
+int launch_strip1(const Strip1Params &p, int nw, int maxs, int n_prob, int max_strips, hipStream_t stream);
+
 // ---- native.hip (reference layouts <-> the strip-major native layout) -------------------------------------------------------
 int launch_repack_native(const qllm_weight_t &src, int zero_kind, void *qweight_out, void *scales_out, void *qzeros_out, hipStream_t stream);
 int launch_unpack_native(const qllm_weight_t &src, int dst_layout, void *qweight_out, void *scales_out, void *qzeros_out, hipStream_t stream);

@@ -1,0 +1,57 @@
+// Host side of the batch-1 native-layout decode kernel (strip1_kernel.hpp): the shape table and the instantiations.
+#include "strip1_kernel.hpp"
+
+namespace qllm {
+
+// (waves per block, k-steps per wave) for T = K / 32 k-steps, or false: not served (the general strip kernel takes the call).
+// One round per wave: NW * MAXS >= T >= MAXS.  Measured choices: profiles/r05_decode_bisect.md.
+bool strip1_shape(int K, int *nw, int *maxs) {
+  if (K % 128 != 0) return false;
+  const int T = K / 32;
+  if (T < 8) return false;
+  int w, m;
+  if (T <= 32) { w = 4; m = 8; }
+  else if (T <= 64) { w = 4; m = 16; }
+  else if (T <= 128) { w = 8; m = 16; }
+  else if (T <= 192) { w = 8; m = 24; }
+  else if (T <= 256) { if (knob("QLLM_S1_T256_NW16", 0)) { w = 16; m = 16; } else { w = 8; m = 32; } }
+  else if (T <= 384) { w = 16; m = 24; }
+  else if (T <= 512) { w = 16; m = 32; }
+  else return false;
+  *nw = w;
+  *maxs = m;
+  return true;
+}
+
+template <int NW, int MAXS, bool EXACT, bool DBG>
+static int launch_t(const Strip1Params &p, dim3 grid, hipStream_t stream) {
+  constexpr int lds_bytes = strip1_lds_bytes<NW, MAXS>();
+  static_assert(lds_bytes <= 64 * 1024, "no dynamic-LDS opt-in needed");
+  hipLaunchKernelGGL((strip1_kernel<NW, MAXS, EXACT, 2, 4, DBG>), grid, dim3(NW * 64), lds_bytes, stream, p);
+  QLLM_HIP_CHECK(hipGetLastError());
+  return QLLM_OK;
+}
+
+template <int NW, int MAXS>
+static int launch_e(const Strip1Params &p, dim3 grid, hipStream_t stream) {
+  return (NW * MAXS == p.T) ? launch_t<NW, MAXS, true, false>(p, grid, stream) : launch_t<NW, MAXS, false, false>(p, grid, stream);
+}
+
+int launch_strip1(const Strip1Params &p, int nw, int maxs, int n_prob, int max_strips, hipStream_t stream) {
+  const dim3 grid(max_strips, n_prob);
+  if (p.dbg) {  // diagnostics instantiations (timeline stamps): the two Llama-2-7B forms
+    if (nw == 8 && maxs == 16 && p.T == 128) return launch_t<8, 16, true, true>(p, grid, stream);
+    if (nw == 16 && maxs == 24 && p.T < 384) return launch_t<16, 24, false, true>(p, grid, stream);
+  }
+  if (nw == 4 && maxs == 8) return launch_e<4, 8>(p, grid, stream);
+  if (nw == 4 && maxs == 16) return launch_e<4, 16>(p, grid, stream);
+  if (nw == 8 && maxs == 16) return launch_e<8, 16>(p, grid, stream);
+  if (nw == 8 && maxs == 24) return launch_e<8, 24>(p, grid, stream);
+  if (nw == 8 && maxs == 32) return launch_e<8, 32>(p, grid, stream);
+  if (nw == 16 && maxs == 16) return launch_e<16, 16>(p, grid, stream);
+  if (nw == 16 && maxs == 24) return launch_e<16, 24>(p, grid, stream);
+  if (nw == 16 && maxs == 32) return launch_e<16, 32>(p, grid, stream);
+  return set_error(QLLM_ERR_UNSUPPORTED, "internal: no batch-1 instantiation for nw=%d round=%d", nw, maxs);
+}
+
+}  // namespace qllm

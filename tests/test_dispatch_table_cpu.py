@@ -124,10 +124,19 @@ def test_native_layout_decode_routes(lib):
     round per wave (8 waves x 16 k-steps at K = 4096, 16 waves x 24 at K = 11008)."""
     sm = " layout=strip-major"
     attn, up, down = W(4096, 4096, layout=NATIVE), W(4096, 11008, layout=NATIVE), W(11008, 4096, layout=NATIVE)
-    assert plan(lib, [attn], 1) == "strip nw=8 cpl=1 spw=16 form=lds-slab row_tiles=1" + sm
-    assert plan(lib, [attn] * 3, 1) == "strip nw=8 cpl=1 spw=16 form=lds-slab row_tiles=1" + sm
-    assert plan(lib, [up] * 2, 1) == "strip nw=8 cpl=1 spw=16 form=lds-slab row_tiles=1" + sm
-    assert plan(lib, [down], 1) == "strip nw=16 cpl=1 spw=24 form=lds-slab row_tiles=1" + sm
+    # batch 1, 4 bits, 128-wide groups: the specialised kernel (strip1_kernel.hpp, round 5): the layer of a grouped launch is blockIdx.y
+    assert plan(lib, [attn], 1) == "strip1 nw=8 round=16 exact grid=strips x 1" + sm
+    assert plan(lib, [attn] * 3, 1) == "strip1 nw=8 round=16 exact grid=strips x 3" + sm
+    assert plan(lib, [up] * 2, 1) == "strip1 nw=8 round=16 exact grid=strips x 2" + sm
+    assert plan(lib, [down], 1) == "strip1 nw=16 round=24 grid=strips x 1" + sm
+    # ... the Llama-2-70B TP = 8 shards (BASELINE configs[4]): q/k/v (ragged widths), o (K = 1024), gate/up, down (K = 3584)
+    assert plan(lib, [W(8192, 1024, layout=NATIVE), W(8192, 128, layout=NATIVE), W(8192, 128, layout=NATIVE)], 1) == "strip1 nw=8 round=32 exact grid=strips x 3" + sm
+    assert plan(lib, [W(1024, 8192, layout=NATIVE)], 1) == "strip1 nw=4 round=8 exact grid=strips x 1" + sm
+    assert plan(lib, [W(3584, 8192, layout=NATIVE)], 1) == "strip1 nw=8 round=16 grid=strips x 1" + sm
+    # ... other group sizes, 3 bits and K beyond 512 k-steps stay on the general strip kernel
+    assert plan(lib, [W(4096, 4096, 64, layout=NATIVE)], 1) == "strip nw=8 cpl=1 spw=16 form=lds-slab row_tiles=1" + sm
+    assert plan(lib, [W(4096, 4096, 128, 3, NATIVE)], 1).startswith("strip nw=16")
+    assert plan(lib, [W(28672, 8192, layout=NATIVE)], 1).startswith("strip nw=16")
     # M = 2..32: strip_dma.hpp (activations through LDS by DMA); one strip per 16-wave block while the strips fit one round of CUs
     for m in (2, 4, 5, 16):
         assert plan(lib, [attn], m) == "strip nw=16 cpl=1 spw=8 form=dma-A row_tiles=1" + sm
@@ -181,8 +190,9 @@ def test_native_layout_decode_routes(lib):
     assert plan(lib, [down], 100) == "gemm2 tile=256x128 split_k=8" + sm
     assert plan(lib, [up] * 2, 128).startswith("unsupported")              # ... groups of up to 16384 columns
     # shard shapes of Llama-2-70B (TP = 8): short K -> 4-wave blocks, K = 8192 -> 8 waves x one round of 32
-    assert plan(lib, [W(1024, 8192, layout=NATIVE)], 1).startswith("strip nw=4 cpl=1 spw=8 form=lds-slab")
-    assert plan(lib, [W(8192, 1024, layout=NATIVE)], 1).startswith("strip nw=8 cpl=1 spw=32 form=lds-slab")
+    assert plan(lib, [W(1024, 8192, layout=NATIVE)], 1).startswith("strip1 nw=4 round=8 exact")
+    assert plan(lib, [W(8192, 1024, layout=NATIVE)], 1).startswith("strip1 nw=8 round=32 exact")
+    assert plan(lib, [W(1024, 8192, 64, layout=NATIVE)], 1).startswith("strip nw=4 cpl=1 spw=8 form=lds-slab")   # (64-wide groups: the general kernel)
     assert plan(lib, [W(8192, 1024, layout=NATIVE)], 3).startswith("strip nw=16 cpl=1 spw=16 form=dma-A")
     assert plan(lib, [W(28672, 1024, layout=NATIVE)], 1).startswith("strip nw=16 cpl=1 spw=56 form=lds-slab")  # three rounds of 24
     # g64 / 3 bits / fp16 zero points: slab form for short chunks at batch 1, register-A beyond (no spilling instantiation is built)

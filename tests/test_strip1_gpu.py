@@ -1,0 +1,91 @@
+"""-m gpu: the batch-1 kernel of the native layout (csrc/strip1_kernel.hpp, round 5) against the oracle, through the C ABI: every
+(waves, round) form of its shape table -- exact and with a shifted last window -- packed / fp16 / symmetric zero points, bias, the
+AutoGPTQ offset, bf16 activations, and grouped launches whose layers differ in width (the layer is blockIdx.y; surplus blocks leave)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu as O
+from gpu_util import Ref, randx, synth, to_layer
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+# K -> the plan line's prefix (strip1.hip: strip1_shape)
+FORMS = [(256, "nw=4 round=8 grid"), (1024, "nw=4 round=8 exact"), (1152, "nw=4 round=16 grid"), (2048, "nw=4 round=16 exact"),
+         (3584, "nw=8 round=16 grid"), (4096, "nw=8 round=16 exact"), (5120, "nw=8 round=24 grid"), (6144, "nw=8 round=24 exact"),
+         (8192, "nw=8 round=32 exact"), (6656, "nw=8 round=32 grid"), (11008, "nw=16 round=24 grid"), (12288, "nw=16 round=24 exact"),
+         (14336, "nw=16 round=32 grid"), (16384, "nw=16 round=32 exact")]
+
+
+def _native(layer, d, zk, compat=0):
+    from qllm_amd import ops
+    if zk == "sym":
+        layer._descriptor(None, 0)
+        src = ops.make_weight("GPTQ", layer.qweight, layer.scales, None, None, layer.bias, d["K"], d["N"], d["groupsize"], d["bits"], compat)
+        return ops.repack_native(*src)[0:2]
+    return layer.native_descriptor(compat), None
+
+
+@pytest.mark.parametrize("K,form", FORMS)
+def test_every_form_vs_oracle(K, form):
+    from qllm_amd import ops
+    N = 1024 if K > 8192 else 2048
+    for layout, zk, bias in (("GPTQ", "asym", False), ("HQQ", "asym", True), ("GPTQ", "sym", K % 1024 == 0)):
+        d = synth(layout, 4, 128, K, N, zk, False, bias, seed=K + len(layout))
+        d["scales"] = (d["scales"].astype(np.float32) * (4096 / K) ** 0.5 * 0.5).astype(np.float16)
+        layer = to_layer(d, DEV)
+        w, keep = _native(layer, d, zk)
+        assert ops.plan_describe([w], 1).startswith("strip1 " + form), ops.plan_describe([w], 1)
+        ref = Ref(d)
+        for seed in (1, 2):
+            x = randx(1, K, seed=seed)
+            y = ops.linear_forward(w, torch.from_numpy(x).to(DEV)).cpu().numpy()
+            assert np.isfinite(y.astype(np.float32)).all()
+            assert O.rel_err(y, ref.y16(x)) <= 1e-2, (layout, zk)
+            assert O.rel_err(y.astype(np.float64), ref.y64(x)) <= 2e-3, (layout, zk)
+        xb = torch.from_numpy(randx(1, K, seed=9)).to(DEV).to(torch.bfloat16)
+        yb = ops.linear_forward(w, xb)
+        assert yb.dtype == torch.bfloat16
+        assert O.rel_err(yb.float().cpu().numpy(), ref.y64(xb.float().cpu().numpy().astype(np.float16))) <= 2e-2, (layout, zk)
+
+
+@pytest.mark.parametrize("K,widths", [(4096, (4096, 1024, 512)), (8192, (1024, 128, 128)), (11008, (512, 2048)), (4096, (11008, 11008)),
+                                      (1024, (16, 4096, 16, 48, 2048, 16, 16, 32))])
+def test_grouped_launches_of_unequal_widths(K, widths):
+    """q/k/v-like groups: one launch, the layer is blockIdx.y; add_zero_bias = 1 (COMPATIBLE_WITH_AUTOGPTQ); equal to layer-by-layer calls."""
+    from qllm_amd import ops
+    ds = [synth("GPTQ", 4, 128, K, n, seed=80 + i, bias=(i % 3 == 2)) for i, n in enumerate(widths)]
+    layers = [to_layer(d, DEV) for d in ds]
+    for compat in (0, 1):
+        ws = [l.native_descriptor(compat) for l in layers]
+        assert ops.plan_describe(ws, 1).startswith("strip1 ") and "x %d" % len(ws) in ops.plan_describe(ws, 1)
+        x = randx(1, K, seed=3 + compat)
+        xt = torch.from_numpy(x).to(DEV)
+        outs = ops.linear_forward_grouped(ws, xt)
+        for o, d, w in zip(outs, ds, ws):
+            assert O.rel_err(o.cpu().numpy(), Ref(dict(d, compat=compat)).y16(x)) <= 1e-2, compat
+            assert torch.equal(o, ops.linear_forward(w, xt))
+
+
+def test_properties_at_full_size():
+    """Size-independent properties on the Llama-2-7B shapes: x -> 2 x doubles y exactly (power-of-two scaling), zero activations
+    give the bias, a one-hot x returns one dequantised row of W (the unrounded s (q - z), within fp16 rounding of the output), and
+    replays are bit-identical."""
+    from qllm_amd import ops
+    for K, N in ((4096, 4096), (11008, 4096), (4096, 11008)):
+        d = synth("GPTQ", 4, 128, K, N, "asym", False, True, seed=K + N)
+        layer = to_layer(d, DEV)
+        w = layer.native_descriptor(0)
+        x = torch.from_numpy(randx(1, K, seed=5) * np.float16(0.25)).to(DEV)
+        y1, y2 = ops.linear_forward(w, x), ops.linear_forward(w, x * 2)
+        b = layer.bias.float()
+        assert torch.equal(y1, ops.linear_forward(w, x))
+        assert torch.allclose((y2.float() - b) / 2, y1.float() - b, rtol=0, atol=2e-3 * float(y1.abs().max()))
+        assert torch.equal(ops.linear_forward(w, torch.zeros_like(x)), layer.bias.view(1, -1))
+        k = K - 77
+        e = torch.zeros_like(x)
+        e[0, k] = 1.0
+        row = ops.linear_forward(w, e).float().cpu().numpy()[0]
+        want = Ref(d).w[k].astype(np.float32) + d["bias"].astype(np.float32)
+        assert np.abs(row - want).max() <= 2e-3 * np.abs(want).max()
