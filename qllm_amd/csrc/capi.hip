@@ -268,7 +268,7 @@ static bool strip_plan(const qllm_weight_t *w, int n, int M, StripPlan *plan) {
         plan->sm = 1;
         // batch 1, 4 bits, 128-wide groups: the specialised kernel (round 5; profiles/r05_decode_bisect.md)
         int nw1 = 0, maxs1 = 0;
-        if (M == 1 && bits == 4 && w[0].group_size == 128 && knob("QLLM_STRIP1", 1) && strip1_shape(w[0].K, &nw1, &maxs1)) {
+        if (M == 1 && bits == 4 && w[0].group_size == 128 && knob("QLLM_STRIP1", 1) && strip1_shape(w[0].K, strips, compute_units(), &nw1, &maxs1)) {
           plan->one_nw = nw1;
           plan->one_maxs = maxs1;
         }

@@ -118,7 +118,7 @@ struct Strip1Params {
   uint64_t *dbg;  // diagnostics (qllm_debug_timeline): 24 timestamps for this launch (3 blocks x 8), or NULL
   Strip1Problem prob[kMaxProblems];
 };
-bool strip1_shape(int K, int *nw, int *maxs);
+bool strip1_shape(int K, int blocks, int cus, int *nw, int *maxs);
 int launch_strip1(const Strip1Params &p, int nw, int maxs, int n_prob, int max_strips, hipStream_t stream);
 
 // ---- native.hip (reference layouts <-> the strip-major native layout) -------------------------------------------------------
@@ -188,6 +188,10 @@ bool gemm3_ok(const GemmParams &p, int layout);
 int gemm3_split_k(int M, int N, int K);
 int launch_gemm3(const GemmParams &p, int layout, hipStream_t stream);
 int launch_bf16_to_f16(const void *src, void *dst, size_t n, hipStream_t stream);  // elementwise RNE conversion (gemm3's bf16 pre-pass)
+
+// ---- gemm5.hip (256x128 tile, every wave a matrix wave, B fragments dequantised in registers; unsplit launches of gemm3's contract) --
+bool gemm5_ok(const GemmParams &p, int layout);
+int launch_gemm5(const GemmParams &p, int wm, hipStream_t stream);
 
 // ---- gemm4.hip (256x128 tile, matrix waves + all-DMA producer waves; same contract as gemm3) ----------------------------------
 int launch_gemm4(const GemmParams &p, int layout, int variant, hipStream_t stream);

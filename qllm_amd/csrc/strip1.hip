@@ -5,13 +5,17 @@ namespace qllm {
 
 // (waves per block, k-steps per wave) for T = K / 32 k-steps, or false: not served (the general strip kernel takes the call).
 // One round per wave: NW * MAXS >= T >= MAXS.  Measured choices: profiles/r05_decode_bisect.md.
-bool strip1_shape(int K, int *nw, int *maxs) {
+// `blocks`: 16-column strips of the launch (all layers); `cus`: compute units.
+bool strip1_shape(int K, int blocks, int cus, int *nw, int *maxs) {
   if (K % 128 != 0) return false;
   const int T = K / 32;
   if (T < 8) return false;
   int w, m;
   if (T <= 32) { w = 4; m = 8; }
   else if (T <= 64) { w = 4; m = 16; }
+  // one block per CU at most (o_proj): four waves x 32 k-steps, one per SIMD -- 3.54 vs 3.78 us (profiles/r05_decode_bisect.md); wider
+  // launches lose with it (gate/up 9.89 vs 9.57)
+  else if (T <= 128 && blocks <= cus && knob("QLLM_S1_NW4", 1)) { w = 4; m = 32; }
   else if (T <= 128) { w = 8; m = 16; }
   else if (T <= 192) { w = 8; m = 24; }
   else if (T <= 256) { if (knob("QLLM_S1_T256_NW16", 0)) { w = 16; m = 16; } else { w = 8; m = 32; } }
@@ -45,6 +49,7 @@ int launch_strip1(const Strip1Params &p, int nw, int maxs, int n_prob, int max_s
   }
   if (nw == 4 && maxs == 8) return launch_e<4, 8>(p, grid, stream);
   if (nw == 4 && maxs == 16) return launch_e<4, 16>(p, grid, stream);
+  if (nw == 4 && maxs == 32) return launch_e<4, 32>(p, grid, stream);
   if (nw == 8 && maxs == 16) return launch_e<8, 16>(p, grid, stream);
   if (nw == 8 && maxs == 24) return launch_e<8, 24>(p, grid, stream);
   if (nw == 8 && maxs == 32) return launch_e<8, 32>(p, grid, stream);

@@ -125,7 +125,7 @@ def test_native_layout_decode_routes(lib):
     sm = " layout=strip-major"
     attn, up, down = W(4096, 4096, layout=NATIVE), W(4096, 11008, layout=NATIVE), W(11008, 4096, layout=NATIVE)
     # batch 1, 4 bits, 128-wide groups: the specialised kernel (strip1_kernel.hpp, round 5): the layer of a grouped launch is blockIdx.y
-    assert plan(lib, [attn], 1) == "strip1 nw=8 round=16 exact grid=strips x 1" + sm
+    assert plan(lib, [attn], 1) == "strip1 nw=4 round=32 exact grid=strips x 1" + sm     # one block per CU: four waves, one per SIMD
     assert plan(lib, [attn] * 3, 1) == "strip1 nw=8 round=16 exact grid=strips x 3" + sm
     assert plan(lib, [up] * 2, 1) == "strip1 nw=8 round=16 exact grid=strips x 2" + sm
     assert plan(lib, [down], 1) == "strip1 nw=16 round=24 grid=strips x 1" + sm

@@ -30,7 +30,7 @@ def _native(layer, d, zk, compat=0):
 @pytest.mark.parametrize("K,form", FORMS)
 def test_every_form_vs_oracle(K, form):
     from qllm_amd import ops
-    N = 1024 if K > 8192 else 2048
+    N = 1024 if K > 8192 else 8192   # (more strips than CUs: the wide-launch forms; one block per CU at most is the test below)
     for layout, zk, bias in (("GPTQ", "asym", False), ("HQQ", "asym", True), ("GPTQ", "sym", K % 1024 == 0)):
         d = synth(layout, 4, 128, K, N, zk, False, bias, seed=K + len(layout))
         d["scales"] = (d["scales"].astype(np.float32) * (4096 / K) ** 0.5 * 0.5).astype(np.float16)
@@ -48,6 +48,20 @@ def test_every_form_vs_oracle(K, form):
         yb = ops.linear_forward(w, xb)
         assert yb.dtype == torch.bfloat16
         assert O.rel_err(yb.float().cpu().numpy(), ref.y64(xb.float().cpu().numpy().astype(np.float16))) <= 2e-2, (layout, zk)
+
+
+def test_one_block_per_cu_form():
+    """K <= 4096 with at most one 16-column strip per CU: four waves x 32 k-steps (o_proj)."""
+    from qllm_amd import ops
+    for K, N in ((4096, 4096), (3072, 1024), (2176, 2048)):
+        d = synth("GPTQ", 4, 128, K, N, "asym", False, True, seed=K + N)
+        layer = to_layer(d, DEV)
+        w = layer.native_descriptor(0)
+        assert ops.plan_describe([w], 1).startswith("strip1 nw=4 round=32"), ops.plan_describe([w], 1)
+        ref = Ref(d)
+        x = randx(1, K, seed=4)
+        y = ops.linear_forward(w, torch.from_numpy(x).to(DEV)).cpu().numpy()
+        assert O.rel_err(y, ref.y16(x)) <= 1e-2 and O.rel_err(y.astype(np.float64), ref.y64(x)) <= 2e-3
 
 
 @pytest.mark.parametrize("K,widths", [(4096, (4096, 1024, 512)), (8192, (1024, 128, 128)), (11008, (512, 2048)), (4096, (11008, 11008)),

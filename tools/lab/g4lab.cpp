@@ -89,11 +89,11 @@ static void free_layer(Layer &L) {
   for (void *p : L.owned) if (p) CK(hipFree(p));
 }
 
-struct Variant { const char *name; const char *g4; const char *mw; const char *pm, *pd, *pl; const char *abl; const char *dw = "4"; };
+struct Variant { const char *name; const char *g4; const char *mw; const char *pm, *pd, *pl; const char *abl; const char *dw = "4"; const char *g5 = "0"; };
 static const Variant variants[] = {
     {"gemm3 mw8", "-1", "8", "2", "0", "0", "0"},
-    {"g4 mw8+4+4", "1", "8", "2", "0", "0", "0"},
-    {"g4 mw4+4", "0", "4", "2", "0", "0", "0"},
+    {"gemm5 2x4 waves (128x32)", "-1", "8", "2", "0", "0", "0", "4", "2"},   // round 5: register-B-fragment kernel (gemm5.hip)
+    {"gemm5 1x4 waves (256x32)", "-1", "8", "2", "0", "0", "0", "4", "1"},
 };
 static const int NV = sizeof(variants) / sizeof(variants[0]);
 static void select_variant(const Variant &v) {
@@ -104,6 +104,7 @@ static void select_variant(const Variant &v) {
   setenv("QLLM_G4_PRIO_D", v.pd, 1);
   setenv("QLLM_G4_PRIO_L", v.pl, 1);
   setenv("QLLM_G4_ABLATE", v.abl, 1);
+  setenv("QLLM_GEMM5", v.g5, 1);
 }
 static bool distinct_kernel(int v) { return v >= 1; }  // (check(): priorities do not change results)
 
@@ -111,6 +112,7 @@ static int check() {
   setenv("QLLM_GEMM3_MIN_M", "65", 1);
   setenv("QLLM_GEMM3_MIN_M_3BIT", "65", 1);
   setenv("QLLM_GEMM2", "1", 1);
+  setenv("QLLM_GEMM2_SPLITK", "0", 1);  // unsplit launches: the form gemm5 serves (small shapes would otherwise split K and stay on gemm3)
   void *ws;
   const size_t ws_bytes = 256 << 20;
   CK(hipMalloc(&ws, ws_bytes)); CK(hipMemset(ws, 0, ws_bytes));
