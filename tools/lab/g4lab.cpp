@@ -89,12 +89,22 @@ static void free_layer(Layer &L) {
   for (void *p : L.owned) if (p) CK(hipFree(p));
 }
 
-struct Variant { const char *name; const char *g4; const char *mw; const char *pm, *pd, *pl; const char *abl; const char *dw = "4"; const char *g5 = "0"; };
+struct Variant { const char *name; const char *g4; const char *mw; const char *pm, *pd, *pl; const char *abl; const char *dw = "4"; const char *g5 = "0"; const char *abl5 = "0"; };
 static const Variant variants[] = {
     {"gemm3 mw8", "-1", "8", "2", "0", "0", "0"},
     {"gemm5 2x4 waves (128x32)", "-1", "8", "2", "0", "0", "0", "4", "2"},   // round 5: register-B-fragment kernel (gemm5.hip)
     {"gemm5 1x4 waves (256x32)", "-1", "8", "2", "0", "0", "0", "4", "1"},
+    // timing-only ablations of the 1x4 form (results are garbage; check() stops in front of them)
+    {"g5 1x4 - A DMA", "-1", "8", "2", "0", "0", "0", "4", "1", "1"},
+    {"g5 1x4 - dequant ALU", "-1", "8", "2", "0", "0", "0", "4", "1", "2"},
+    {"g5 1x4 - A frag reads", "-1", "8", "2", "0", "0", "0", "4", "1", "4"},
+    {"g5 1x4 - word loads", "-1", "8", "2", "0", "0", "0", "4", "1", "8"},
+    {"g5 1x4 - DMA - ALU", "-1", "8", "2", "0", "0", "0", "4", "1", "3"},
+    {"g5 1x4 - ALU - loads", "-1", "8", "2", "0", "0", "0", "4", "1", "10"},
+    {"g5 1x4 - DMA - ALU - loads", "-1", "8", "2", "0", "0", "0", "4", "1", "11"},
+    {"g5 1x4 MFMA only", "-1", "8", "2", "0", "0", "0", "4", "1", "15"},
 };
+static const int NV_CHECK = 3;
 static const int NV = sizeof(variants) / sizeof(variants[0]);
 static void select_variant(const Variant &v) {
   setenv("QLLM_GEMM4", v.g4, 1);
@@ -105,6 +115,7 @@ static void select_variant(const Variant &v) {
   setenv("QLLM_G4_PRIO_L", v.pl, 1);
   setenv("QLLM_G4_ABLATE", v.abl, 1);
   setenv("QLLM_GEMM5", v.g5, 1);
+  setenv("QLLM_G5_ABL", v.abl5, 1);
 }
 static bool distinct_kernel(int v) { return v >= 1; }  // (check(): priorities do not change results)
 
@@ -135,7 +146,7 @@ static int check() {
       CK(hipMemcpy(h0.data(), y0, ny * 2, hipMemcpyDeviceToHost));
       char plan[200];
       QK(qllm_plan_describe(&L.w, 1, c.M, 1, plan, sizeof plan));
-      for (int v = 1; v < NV; ++v) {
+      for (int v = 1; v < NV_CHECK; ++v) {
         if (!distinct_kernel(v)) continue;
         select_variant(variants[v]);
         CK(hipMemset(y1, 0xff, ny * 2));
