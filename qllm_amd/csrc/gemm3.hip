@@ -460,10 +460,10 @@ int launch_gemm3(const GemmParams &p_in, int layout, hipStream_t stream) {
   const int raster = knob("QLLM_GEMM2_RASTER", 1);
   p.raster = raster;
 #ifdef QLLM_LAB
-  if (const int g4 = knob("QLLM_GEMM4", -1); g4 >= 0) return launch_gemm4(p, layout, g4, stream);  // (lab) gemm4.hip variants
-#endif
-  // round 5: the register-B-fragment form (gemm5.hip) where it serves; QLLM_GEMM5 = waves along M (0: off)
+  if (const int g4 = knob("QLLM_GEMM4", -1); g4 >= 0) return launch_gemm4(p, layout, g4, stream);  // (lab) tools/lab/gemm4.hip variants
+  // (lab) tools/lab/gemm5.hip: every wave a matrix wave, B fragments dequantised in registers; QLLM_GEMM5 = waves along M
   if (const int g5 = knob("QLLM_GEMM5", 0); g5 > 0 && gemm5_ok(p, layout)) return launch_gemm5(p, g5, stream);
+#endif
   const int mw = knob("QLLM_GEMM3_MW", 8);  // measured (profiles/r02_prefill_summary.md): 8 matrix waves 908 / 923 / 1004 TFLOP/s, 4: 873 / 915 / 1003
   const int prio = knob("QLLM_GEMM3_PRIO", 1);
   if (layout == kGemm3Rows3Bit) return launch_gemm3_b<2, 8>(p, stream);

@@ -189,11 +189,11 @@ int gemm3_split_k(int M, int N, int K);
 int launch_gemm3(const GemmParams &p, int layout, hipStream_t stream);
 int launch_bf16_to_f16(const void *src, void *dst, size_t n, hipStream_t stream);  // elementwise RNE conversion (gemm3's bf16 pre-pass)
 
-// ---- gemm5.hip (256x128 tile, every wave a matrix wave, B fragments dequantised in registers; unsplit launches of gemm3's contract) --
+// ---- tools/lab/gemm5.hip (lab builds: 256x128 tile, every wave a matrix wave, B fragments dequantised in registers) ------------------
 bool gemm5_ok(const GemmParams &p, int layout);
 int launch_gemm5(const GemmParams &p, int wm, hipStream_t stream);
 
-// ---- gemm4.hip (256x128 tile, matrix waves + all-DMA producer waves; same contract as gemm3) ----------------------------------
+// ---- tools/lab/gemm4.hip (lab builds: 256x128 tile, matrix waves + all-DMA producer waves; same contract as gemm3) ----------------------------------
 int launch_gemm4(const GemmParams &p, int layout, int variant, hipStream_t stream);
 
 }  // namespace qllm
