@@ -224,22 +224,34 @@ static bool strip_plan(const qllm_weight_t *w, int n, int M, StripPlan *plan) {
     for (int i = 0; i < n; ++i) small_enough = small_enough && (double)w[i].K * w[i].N * bits / 8 < 2147483648.0;
     if (ra_xd && small_enough && M >= dma_from && M >= 2 && M <= 32 && w[0].K % 64 == 0) {
       const int cus = compute_units();
-      static const int cands4[] = {1, 2, 4, 6}, cands3[] = {1, 2, 4};
+      // (round 5: three strips -- q/k/v's 768 strips are 256 blocks of three, every CU busy, instead of 192 of four; six 3-bit strips where
+      //  the ring fits the registers: 64-wide groups with fp16 zero points, HQQ -- gate/up's 1376 strips in ONE round of 230 blocks
+      //  instead of 344 blocks of four in two.  profiles/r05_batch16.md)
+      static const int cands4[] = {1, 2, 3, 4, 6}, cands3[] = {1, 2, 3, 4, 6};
       const int *cands = bits == 4 ? cands4 : cands3;
-      const int n_cands = (M > 16) ? 1 : (g32 ? 2 : (bits == 4 ? 4 : 3));  // (two row tiles: one strip per block; 3 bits: four strips at most; 32-wide groups: two)
+      bool all_f16z = w[0].group_size == 64;
+      for (int i = 0; i < n; ++i) all_f16z = all_f16z && w[i].layout == QLLM_LAYOUT_NATIVE_F16Z && w[i].qzeros;
+      const int n_cands = (M > 16) ? 1 : (g32 ? 2 : (bits == 4 ? 5 : (all_f16z ? 5 : 4)));  // (two row tiles: one strip per block; 3 bits: four strips unless fp16 zeros at g64; 32-wide groups: two)
       const double x_bytes = (double)M * w[0].K * 2, strip_bytes = (double)w[0].K * bits * 2 + (double)(w[0].K / w[0].group_size) * 64;
-      int best = 1;
+      int best = 0;
       double best_cost = 0;
+      // a candidate must fit the LDS: the waves' rings + (round 5) their scale / zero-point tables, which grow with K and the width
+      auto dma_fits = [&](int c) {
+        const int nw_c = (c == 1 && M <= 16) ? 16 : 8;
+        const int spw_c = (strip_spw(w[0].K, w[0].group_size, nw_c) + 1) & ~1;
+        return strip_lds_bytes(M, spw_c, nw_c, c, w[0].group_size, 2, 1) <= 156 * 1024;
+      };
       for (int ci = 0; ci < n_cands; ++ci) {
         const int c = cands[ci];
+        if (!dma_fits(c)) continue;
         int blocks = 0;
         for (int i = 0; i < n; ++i) blocks += (w[i].N / 16 + c - 1) / c;
         // (+ 96 KB per round: the ~1.8 us a block lives before and after its stream, at the CU's ingest rate)
         const double cost = (double)((blocks + cus - 1) / cus) * (96.0 * 1024 + x_bytes + c * strip_bytes);
-        if (ci == 0 || cost < best_cost * 0.97) { best = c; best_cost = cost; }  // (wider only for a clear gain)
+        if (best == 0 || cost < best_cost * 0.97) { best = c; best_cost = cost; }  // (wider only for a clear gain)
         if (c == dma_cpl) { best = c; break; }                                    // (experiments: QLLM_DMA_CPL forces a width)
       }
-      cpl = best;
+      cpl = best ? best : 1;
       // (32-wide groups, one strip per block, short K, few rows: the register-A form's 8-k-step rounds beat the three-slot ring --
       //  4096 x 4096 at M = 4: 6.2 vs 7.7 us, M = 16: 7.8 both; tools/g32_bench.py, profiles/logs/r04r_g32_bench.log)
       const bool g32_ra = g32 && cpl == 1 && M <= 8 && w[0].K <= 4096;
@@ -697,6 +709,7 @@ int qllm_linear_forward_grouped(const qllm_weight_t *w, void *const *y, int32_t 
   clear_error();
   if (!w || !y) return set_error(QLLM_ERR_INVALID, "w / y arrays must not be NULL");
   if (n_weights < 1 || n_weights > kMaxProblems) return set_error(QLLM_ERR_INVALID, "n_weights must be 1..%d (got %d)", kMaxProblems, n_weights);
+  if (n_weights == 1) return qllm_linear_forward(&w[0], x, y[0], M, act_dtype, workspace, workspace_bytes, stream);  // (a group of one is a plain call)
   for (int i = 0; i < n_weights; ++i) {
     int rc = validate_weight(&w[i]);
     if (rc) return rc;

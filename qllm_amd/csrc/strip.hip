@@ -85,7 +85,14 @@ size_t strip_lds_bytes(int M, int spw, int nw, int cpl, int group_size, int ra, 
   const size_t red = (size_t)nw * M * 16 * cpl * sizeof(float);
   // register-A: only the cross-wave reduction buffer; ra == 2 (strip_dma.hpp): the waves' activation rings, 8 KB per 16-row tile,
   // which the reduction buffer re-uses
-  if (ra == 2) return std::max(red, (size_t)nw * (M > 16 ? 2 : 1) * 8192);
+  // (+ behind them, round 5, the waves' scale / zero-point tables: 2 x groups x strips x 32 bytes, in whole 256-byte pieces)
+  if (ra == 2) {
+    const int spg = group_size / 32, mt = M > 16 ? 2 : 1;
+    // (strip_dma.hpp, strip_dma_table_groups: rounds x groups per round, the larger of the rings the form may run)
+    const int ns1 = (cpl >= 2 || mt >= 2) ? 2 : 3, r4 = (spw + 7) / 8 * 8 / spg, r3 = (spw + 5) / 6 * 6 / spg;
+    const int ngw = spg == 1 ? (spw + 2 * ns1 - 1) / (2 * ns1) * (2 * ns1) : (spg == 2 ? std::max(r3, r4) : r4);
+    return std::max(red, (size_t)nw * (M > 16 ? 2 : 1) * 8192 + (size_t)nw * 2 * (((size_t)ngw * cpl * 32 + 255) & ~(size_t)255));
+  }
   if (ra) return red;
   const int pad = strip_spw_pad(nw, spw, cpl, 0, sm);
   const int groups = pad / (group_size / 32);  // groups per wave chunk

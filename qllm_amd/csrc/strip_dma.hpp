@@ -34,6 +34,8 @@
 // K must be a multiple of 64 and spw even (host: strip_plan).  Replaces gemv<half> (/root/reference/csrc/ort_cuda/dq_gemv.cu:41-150)
 // and, for the HQQ configuration, the dequantise-then-matmul forward of /root/reference/qllm/modeling/q_layers/quant_linear_hqq.py.
 #pragma once
+#include <algorithm>
+
 #include "kernels.hpp"
 
 namespace qllm {
@@ -73,9 +75,16 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void strip_dma_kernel(const StripP
   // vector-memory operations of one stage request, in issue order: [the scale / zero words of the group(s) that END in this slot,]
   // the DMA pieces, the weight words.  (SPG = 1: every slot holds two groups; SPG = 2: every slot ends one; SPG = 4: the odd ones.)
   constexpr bool Z2 = BITS == 3 && !ZF16;  // packed 3-bit zero points: the field may straddle into a second word
-  constexpr int LZ = CPL * (2 + (Z2 ? 1 : 0));
-  constexpr int LX = 2 * MT + 2 * CPL * WL;
-  constexpr int L_EVEN = LX + (SPG == 1 ? 2 * LZ : (SPG == 2 ? LZ : 0)), L_ODD = LX + (SPG == 1 ? 2 * LZ : LZ);  // requests of an even / odd slot
+#ifdef QLLM_DMA_ABL  // (timing-only lab variants, tools/rounds5/g07: 1 = no scale / zero loads, 2 = no packed-word loads, 3 = neither)
+  constexpr bool NO_SZ = QLLM_DMA_ABL & 1, NO_W = QLLM_DMA_ABL & 2;
+#else
+  constexpr bool NO_SZ = false, NO_W = false;
+#endif
+  // (round 5: the scale / zero tables of the wave's whole chunk travel ONCE, by LDS-DMA in 256-byte instructions in front of the ring --
+  //  a 2-byte scale load and a 4-byte zero load per strip and group were a third to a half of the loop's vector-memory instructions,
+  //  and the texture addresser charges per instruction: profiles/r05_batch16.md)
+  constexpr int LX = 2 * MT + (NO_W ? 0 : 2 * CPL * WL);
+  constexpr int L_EVEN = LX, L_ODD = LX;  // requests of an even / odd slot
   constexpr int L_ALL = (NS / 2) * (L_EVEN + L_ODD) + (NS % 2) * L_EVEN;
   extern __shared__ __attribute__((aligned(16))) float red[];
 
@@ -129,19 +138,19 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void strip_dma_kernel(const StripP
     w_strip[c] = strip * strip_bytes;
     g_strip[c] = strip * gtab;
   }
-  const int z_group = (zk == ZK_SYM) ? 0 : zmul * 4;
   const int lane_w = (g * 16 + i) * 4;
   const int lane_w3_lo = ((g == 0 ? 0 : g - 1) * 16 + i) * 4, lane_w3_hi = ((g == 3 ? 2 : g) * 16 + i) * 4;
   const uint32_t shift3 = (uint32_t)((32 - 8 * g) & 31);
-  const int lane_s = i * 2;
   // zero points: the word holding this lane's column -- packed 4-bit: nibble i%8 of word i/8; packed 3-bit: bit 3i of the 64-bit
   // pair (the field may straddle into the second word); fp16: half i%2 of word i/2
-  const int zoff = (zk == ZK_PACKED) ? (BITS == 3 ? (i * 3) >> 5 : (i >> 3)) : ((zk == ZK_F16) ? (i >> 1) : 0);
-  const int lane_z = zoff * 4;
-  const int lane_z2 = (BITS == 3 && zk == ZK_PACKED && zoff == 0) ? 4 : lane_z;
+  // (3 bits without the fp16-zero form, Z2: the lane reads the aligned 8-byte pair holding its field -- the packed row itself, or the
+  //  four halves around its fp16 zero point)
+  const int lane_z = (BITS == 3 && !ZF16) ? ((zk == ZK_F16) ? ((2 * i) & ~7) : 0)
+                                          : ((zk == ZK_PACKED) ? 4 * (i >> 3) : ((zk == ZK_F16) ? 4 * (i >> 1) : 0));
   // decode, branch-free over the zero kind: field = word >> zsh; fp16 bits = ((field + add_zero_bias) & zmask) | zor; z = float(bits) + zadd
   //   packed: the integer v through the 1024 + v pattern (0x6400 | v), zadd = -1024; fp16: the half itself; symmetric: 2^(BITS-1)
-  const uint32_t zsh = (zk == ZK_PACKED) ? (uint32_t)((BITS == 3 ? 3 * i : 4 * i) & 31) : (uint32_t)(16 * (i & 1));
+  const uint32_t zsh = (BITS == 3 && !ZF16) ? ((zk == ZK_PACKED) ? (uint32_t)(3 * i) : ((zk == ZK_F16) ? (uint32_t)(16 * (i & 3)) : 0u))
+                                            : ((zk == ZK_PACKED) ? (uint32_t)((4 * i) & 31) : (uint32_t)(16 * (i & 1)));
   const uint32_t zmask = (zk == ZK_PACKED) ? (uint32_t)((1 << BITS) - 1) : ((zk == ZK_F16) ? 0xffffu : 0u);
   const uint32_t zor = (zk == ZK_F16) ? 0u : ((zk == ZK_PACKED) ? 0x6400u : (0x6400u | (1u << (BITS - 1))));
   const uint32_t zbias = (zk == ZK_PACKED) ? (uint32_t)p.add_zero_bias : 0u;
@@ -149,6 +158,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void strip_dma_kernel(const StripP
 
   // ---- the activation ring: NS slots x MT row tiles x [16 rows][128 B] per wave (the reduction buffer re-uses the space) ----------
   uint8_t *xd = (uint8_t *)red + (size_t)wave * (NS * MT * 2048);
+  // ... behind the rings (sized for four slots): per wave the scale table [ngw groups][CPL strips][32 B] and the zero-point table
+  // ([..][32 B] fp16, [..][8 B] packed), each rounded up to whole 256-byte DMA instructions
+  const int ngw = rounds * NG;                                             // groups the wave's rounds touch (dead stages read their rows too)
+  const int G0w = t0 / SPG;                                                // the wave's first group (t0 is a multiple of SPG)
+  const int sz_zoff = (ngw * CPL * 32 + 255) & ~255;                       // zero table behind the scale table
+  uint8_t *szd = (uint8_t *)red + (size_t)NW * (4 * MT * 2048) + (size_t)wave * (2 * sz_zoff);
   const int x_bytes = (int)min((size_t)M * p.K * 2, (size_t)0x7fffffff);
   const auto rs_x = __builtin_amdgcn_make_buffer_rsrc((void *)p.x, 0, x_bytes, 0x00020000);
   // piece h of a row tile: lane l -> row 8h + l/8, physical 16-byte slot l%8 <- logical chunk (l%8) ^ swizzle(row)
@@ -185,33 +200,21 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void strip_dma_kernel(const StripP
 
   // ---- ring state: registers -----------------------------------------------------------------------------------------------
   uint32_t w[2 * NS][CPL], w_hi[BITS == 3 ? 2 * NS : 1][CPL];
-  half2_t sc2[NG][(CPL + 1) / 2];  // scales, two strips per register
-  uint32_t zr[NG][CPL], zr2[Z2 ? NG : 1][CPL];
   float4_t yacc[MT][CPL];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int c = 0; c < CPL; ++c) yacc[mt][c] = float4_t{0.f, 0.f, 0.f, 0.f};
+  // the lane's read addresses in the tables for the current round's first group (advanced by a round of groups per round)
+  int sz_rd_s = 2 * i;
+  int sz_rd_z = sz_zoff + (ZF16 ? 2 * i : lane_z);
+  const int sz_step = NG * CPL * 32;
 
   // request slot u for the round starting at k-step `base`
   auto request = [&](const int base, const int u) __attribute__((always_inline)) {
     const int kp = base + 2 * u;
     const bool live = kp < tend;      // wave-uniform
     const int kc = min(kp, T - 2);    // addresses stay inside the strip
-    if ((2 * u + 1) % SPG == SPG - 1) {
-#pragma unroll
-      for (int e = (SPG == 1 ? 0 : 1); e < 2; ++e) {  // (32-wide groups: both k-steps of the slot end a group)
-        const int j = (2 * u + e) / SPG;
-        const int G = min((int)((unsigned)(kc + (SPG == 1 ? e : 0)) / SPG), Gmax);
-#pragma unroll
-        for (int c = 0; c < CPL; ++c) {
-          const int sg = g_strip[c] + G;
-          sc2[j][c / 2][c & 1] = __builtin_bit_cast(half_t, __builtin_amdgcn_raw_buffer_load_b16(rs_s, lane_s, sg * 32, 2));
-          zr[j][c] = __builtin_amdgcn_raw_buffer_load_b32(rs_z, lane_z, sg * z_group, 2);
-          if constexpr (Z2) zr2[j][c] = __builtin_amdgcn_raw_buffer_load_b32(rs_z, lane_z2, sg * z_group, 2);
-        }
-      }
-    }
     const int so = 64 * kc;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -223,7 +226,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void strip_dma_kernel(const StripP
       }
     const int wrow = (WR * 64) * kc;
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {  // (the second k-step of the pair: + one k-step of words, an immediate offset)
+    for (int e = 0; e < (NO_W ? 0 : 2); ++e) {  // (the second k-step of the pair: + one k-step of words, an immediate offset)
 #pragma unroll
       for (int c = 0; c < CPL; ++c) {
         if constexpr (BITS == 4) {
@@ -238,46 +241,112 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void strip_dma_kernel(const StripP
 
   float4_t gacc[MT][CPL], g_sx[MT], g_nb[MT];  // group accumulators: sum x (q + bias) per strip; sum x; minus sum x bias
   // the two k-steps of slot u (+ the group's scale / zero-point step when a group ends here)
+  // B fragment of k-step s, strip c (raw biased patterns: see above)
+  auto b_frag = [&](const int s, const int c) __attribute__((always_inline)) {
+    half2_t b0, b1, b2, b3;
+    if constexpr (BITS == 4) {
+      const uint32_t wv = w[s][c], w8 = wv >> 8;
+      b0 = as_h2((wv & mask_lo) | kMagic); b1 = as_h2((wv & mask_hi) | kMagic64);
+      b2 = as_h2((w8 & mask_lo) | kMagic); b3 = as_h2((w8 & mask_hi) | kMagic64);
+    } else {
+      const uint32_t f = __builtin_amdgcn_alignbit(w_hi[s][c], w[s][c], shift3);
+      const uint32_t f1 = f << 1;
+      b0 = as_h2((f1 & m3a) | kMagic);
+      b1 = as_h2((f1 & m3b) | kMagic);
+      b2 = as_h2((f1 & m3c) | kMagic);
+      const uint32_t lo34 = ((f >> 9) & m3d) | kMagic;
+      b3 = as_h2(((f << 4) & m3e) | lo34);
+    }
+    return half8_t{b0.x, b0.y, b1.x, b1.y, b2.x, b2.y, b3.x, b3.y};
+  };
+  // A fragment of slot u, k-step parity e, row tile mt (4 bits: permuted; 3 bits: permuted and divided by the slot factors)
+  auto a_frag = [&](const int u, const int e, const int mt) __attribute__((always_inline)) {
+    const uint4_t xraw = *(const uint4_t *)(xd + (u * MT + mt) * 2048 + xd_rd[e]);
+    half8_t xv;
+    if constexpr (BF16) xv = bf16x8_to_h8(xraw); else xv = __builtin_bit_cast(half8_t, xraw);
+    if constexpr (BITS == 4) {
+      return a_perm_04152637(xv);
+    } else {
+      const half8_t pv = __builtin_shufflevector(xv, xv, 0, 5, 1, 6, 2, 7, 3, 4);
+      const half2_t q0 = half2_t{pv[0], pv[1]} * half2_t{(half_t)0.5f, (half_t)1.f};
+      const half2_t q1 = half2_t{pv[2], pv[3]} * half2_t{(half_t)0.0625f, (half_t)0.125f};
+      const half2_t q2 = half2_t{pv[4], pv[5]} * half2_t{(half_t)0.0078125f, (half_t)0.015625f};
+      return half8_t{q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, pv[6], pv[7]};
+    }
+  };
+  // scale and zero point of group j of the current round, strip c, as fp32: read from the wave's tables in LDS (cells of 32 bytes,
+  // [group][strip]: 16 halves of scales; 16 halves of fp16 zero points, or the 2 packed words of the (group, strip) row in the cell's
+  // first 8 bytes).  sz_rd_s / sz_rd_z: the lane's addresses in the round's first cell.
+  auto group_consts = [&](const int j, const int c, float &zf, float &sfc) __attribute__((always_inline)) {
+    if constexpr (NO_SZ) { zf = 3.5f; sfc = 0.01f; return; }
+    sfc = (float)*(const half_t *)(szd + sz_rd_s + (j * CPL + c) * 32);
+    if constexpr (ZF16) {
+      zf = (float)*(const half_t *)(szd + sz_rd_z + (j * CPL + c) * 32);
+    } else {
+      uint32_t field;  // branch-free over the zero kind: an aligned word (pair) holding the lane's field, shifted down
+      if constexpr (Z2) {
+        const uint2_t zz = *(const uint2_t *)(szd + sz_rd_z + (j * CPL + c) * 32);
+        field = (uint32_t)(((((uint64_t)zz.y) << 32) | zz.x) >> zsh);
+      } else {
+        field = *(const uint32_t *)(szd + sz_rd_z + (j * CPL + c) * 32) >> zsh;
+      }
+      const uint32_t zbits = ((field + zbias) & zmask) | zor;
+      zf = (float)__builtin_bit_cast(half_t, (uint16_t)zbits) + zadd;
+    }
+  };
+  // the two k-steps of slot u (+ the group's scale / zero-point step when a group ends here)
   auto compute = [&](const int u) __attribute__((always_inline)) {
+    const float4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (SPG == 2) {
+      // 64-wide groups: the slot IS a group.  Both A fragments and the bookkeeping sums first; every strip's two MFMAs then START from
+      // minus sum x bias, so the accumulator ends as sum x q and the group step is two packed fmas per accumulator pair
+      // (round 5: was an add + two fmas, profiles/r05_batch16.md)
+      half8_t av[2][MT];
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) av[e][mt] = a_frag(u, e, mt);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        g_sx[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[0][mt], b_sum, zero4, 0, 0, 0);
+        g_nb[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[0][mt], b_nbias, zero4, 0, 0, 0);
+        g_sx[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[1][mt], b_sum, g_sx[mt], 0, 0, 0);
+        g_nb[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[1][mt], b_nbias, g_nb[mt], 0, 0, 0);
+      }
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+          const half8_t bf = b_frag(2 * u + e, c);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+            gacc[mt][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[e][mt], bf, e == 0 ? g_nb[mt] : gacc[mt][c], 0, 0, 0);
+        }
+      // y += scale * (sum x q  -  z * Sx)
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        float zf, sfc;
+        group_consts(u, c, zf, sfc);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) yacc[mt][c][q] = __builtin_fmaf(sfc, __builtin_fmaf(-zf, g_sx[mt][q], gacc[mt][c][q]), yacc[mt][c][q]);
+      }
+      return;
+    }
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const int s = 2 * u + e;
-      const float4_t zero4 = {0.f, 0.f, 0.f, 0.f};
       half8_t av[MT];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        const uint4_t xraw = *(const uint4_t *)(xd + (u * MT + mt) * 2048 + xd_rd[e]);
-        half8_t xv;
-        if constexpr (BF16) xv = bf16x8_to_h8(xraw); else xv = __builtin_bit_cast(half8_t, xraw);
-        if constexpr (BITS == 4) {
-          av[mt] = a_perm_04152637(xv);
-        } else {
-          const half8_t pv = __builtin_shufflevector(xv, xv, 0, 5, 1, 6, 2, 7, 3, 4);
-          const half2_t q0 = half2_t{pv[0], pv[1]} * half2_t{(half_t)0.5f, (half_t)1.f};
-          const half2_t q1 = half2_t{pv[2], pv[3]} * half2_t{(half_t)0.0625f, (half_t)0.125f};
-          const half2_t q2 = half2_t{pv[4], pv[5]} * half2_t{(half_t)0.0078125f, (half_t)0.015625f};
-          av[mt] = half8_t{q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, pv[6], pv[7]};
-        }
+        av[mt] = a_frag(u, e, mt);
         g_sx[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[mt], b_sum, (s % SPG == 0) ? zero4 : g_sx[mt], 0, 0, 0);
         g_nb[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[mt], b_nbias, (s % SPG == 0) ? zero4 : g_nb[mt], 0, 0, 0);
       }
 #pragma unroll
       for (int c = 0; c < CPL; ++c) {
-        half2_t b0, b1, b2, b3;
-        if constexpr (BITS == 4) {
-          const uint32_t wv = w[s][c], w8 = wv >> 8;
-          b0 = as_h2((wv & mask_lo) | kMagic); b1 = as_h2((wv & mask_hi) | kMagic64);
-          b2 = as_h2((w8 & mask_lo) | kMagic); b3 = as_h2((w8 & mask_hi) | kMagic64);
-        } else {
-          const uint32_t f = __builtin_amdgcn_alignbit(w_hi[s][c], w[s][c], shift3);
-          const uint32_t f1 = f << 1;
-          b0 = as_h2((f1 & m3a) | kMagic);
-          b1 = as_h2((f1 & m3b) | kMagic);
-          b2 = as_h2((f1 & m3c) | kMagic);
-          const uint32_t lo34 = ((f >> 9) & m3d) | kMagic;
-          b3 = as_h2(((f << 4) & m3e) | lo34);
-        }
-        const half8_t bf = {b0.x, b0.y, b1.x, b1.y, b2.x, b2.y, b3.x, b3.y};
+        const half8_t bf = b_frag(s, c);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
           gacc[mt][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[mt], bf, (s % SPG == 0) ? zero4 : gacc[mt][c], 0, 0, 0);
@@ -288,17 +357,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void strip_dma_kernel(const StripP
         const int j = s / SPG;
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
-          uint32_t field;
-          if constexpr (Z2) field = (uint32_t)(((((uint64_t)zr2[j][c]) << 32) | zr[j][c]) >> zsh);
-          else field = zr[j][c] >> zsh;
-          float zf;
-          if constexpr (ZF16) {
-            zf = (float)__builtin_bit_cast(half_t, (uint16_t)field);
-          } else {
-            const uint32_t zbits = ((field + zbias) & zmask) | zor;
-            zf = (float)__builtin_bit_cast(half_t, (uint16_t)zbits) + zadd;
-          }
-          const float sfc = (float)sc2[j][c / 2][c & 1];
+          float zf, sfc;
+          group_consts(j, c, zf, sfc);
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -311,7 +371,30 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void strip_dma_kernel(const StripP
     }
   };
 
-  // ---- prologue: the whole ring; then rounds ------------------------------------------------------------------------------
+  if constexpr (NO_W) {
+#pragma unroll
+    for (int s2 = 0; s2 < 2 * NS; ++s2)
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) { w[s2][c] = 0x12345678u * (lane + 1) + s2; if constexpr (BITS == 3) w_hi[s2][c] = 0x9abcdef1u + lane; }
+  }
+  // ---- prologue: the scale / zero tables of the wave's chunk, then the whole ring; then rounds -------------------------------------
+  if constexpr (!NO_SZ) {
+    // 256 bytes per instruction: lane l carries 4 bytes of cell l / 8 = (group jj of the wave, strip c); the source row is clamped into
+    // the strip's table (rows past K are only ever multiplied by zero activations, but must be finite)
+    const int zrow = zmul * 4;  // bytes of a zero-point row in memory: 8 (packed: the cell's first two words) or 32 (fp16)
+    const int bytes = ngw * CPL * 32;
+    for (int off = 0; off < bytes; off += 256) {
+      const int cell = (off >> 5) + (lane >> 3), wb = 4 * (lane & 7);
+      const int jj = cell / CPL, c = cell - jj * CPL;
+      int gs = g_strip[0];
+#pragma unroll
+      for (int q = 1; q < CPL; ++q) gs = (c == q) ? g_strip[q] : gs;
+      const int row = gs + min(G0w + jj, Gmax);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_s, (lds_void_t *)(szd + off), 4, row * 32 + wb, 0, 0, 0);
+      if (zk != ZK_SYM) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_z, (lds_void_t *)(szd + sz_zoff + off), 4, row * zrow + min(wb, zrow - 4), 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
 #pragma unroll
   for (int u = 0; u < NS; ++u) {
     request(t0, u);
@@ -334,6 +417,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void strip_dma_kernel(const StripP
       request(t0 + 2 * NS * (r + 1), u);
       __builtin_amdgcn_sched_barrier(0);
     }
+    sz_rd_s += sz_step;
+    sz_rd_z += sz_step;
   }
   // last round: nothing is re-requested, the slots behind the one computed are the only ones still in flight
 #pragma unroll
@@ -380,17 +465,27 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void strip_dma_kernel(const StripP
 
 // dynamic LDS of a launch: the waves' activation rings (8 KB per wave and row tile); the reduction buffer (nw x M x 16 cpl floats)
 // re-uses them
-inline size_t strip_dma_lds_bytes(int M, int nw, int cpl) {
-  const int mt = M > 16 ? 2 : 1;
+// groups a wave's rounds touch, for the LDS budget: rounds x groups per round with the deepest ring the instantiation may use
+inline int strip_dma_table_groups(int spw, int spg, int cpl, int mt) {
+  if (spg == 1) {
+    const int ns = (cpl >= 2 || mt >= 2) ? 2 : 3;
+    return (spw + 2 * ns - 1) / (2 * ns) * (2 * ns);
+  }
+  const int r4 = (spw + 7) / 8 * 8 / spg, r3 = (spw + 5) / 6 * 6 / spg;  // (64-wide groups run rings of three or four slots)
+  return spg == 2 ? (r3 > r4 ? r3 : r4) : r4;
+}
+inline size_t strip_dma_lds_bytes(int M, int nw, int cpl, int spw, int group_size) {
+  const int mt = M > 16 ? 2 : 1, spg = group_size / 32, ngw = strip_dma_table_groups(spw, spg, cpl, mt);
   const size_t ring = (size_t)nw * 4 * mt * 2048  /* (sized for four slots whatever the ring) */, red = (size_t)nw * M * 16 * cpl * sizeof(float);
-  return ring > red ? ring : red;
+  const size_t tables = (size_t)nw * 2 * (((size_t)ngw * cpl * 32 + 255) & ~(size_t)255);  // (scales + zero points, fp16 zeros at most)
+  return std::max(ring + tables, red);
 }
 
 template <int NW, int CPL, int SPG, int BITS, bool BF16, int MT, bool ZF16>
 static int launch_strip_dma_z(const StripParams &p, int grid, hipStream_t stream) {
   static DeviceLatch attr_done;
   if (int rc = lds_optin(attr_done, (const void *)strip_dma_kernel<NW, CPL, SPG, BITS, BF16, MT, ZF16>)) return rc;
-  hipLaunchKernelGGL((strip_dma_kernel<NW, CPL, SPG, BITS, BF16, MT, ZF16>), dim3(grid), dim3(NW * 64), strip_dma_lds_bytes(p.M, NW, CPL), stream, p);
+  hipLaunchKernelGGL((strip_dma_kernel<NW, CPL, SPG, BITS, BF16, MT, ZF16>), dim3(grid), dim3(NW * 64), strip_dma_lds_bytes(p.M, NW, CPL, p.spw, p.group_size), stream, p);
   QLLM_HIP_CHECK(hipGetLastError());
   return QLLM_OK;
 }

@@ -6,7 +6,8 @@
 namespace qllm {
 
 // M = 5..32 with the activations staged through LDS by DMA (strip_dma.hpp; host planner: ra == 2): 16-wave blocks of one strip,
-// 8-wave blocks of 1 / 2 / 4 / 6 strips (3 bits: 1 / 2 / 4), 8-wave blocks of one strip and two row tiles
+// 8-wave blocks of 1 / 2 / 3 / 4 / 6 strips (3 bits: 1 / 2 / 3 / 4, and 6 at 64-wide groups when every layer has fp16 zero points),
+// 8-wave blocks of one strip and two row tiles
 template <int SPG, bool BF>
 static int launch_sm_dma(const StripParams &p, int grid, hipStream_t stream) {
   if (p.M > 16) {
@@ -20,12 +21,21 @@ static int launch_sm_dma(const StripParams &p, int grid, hipStream_t stream) {
     switch (p.cpl) {
       case 1: return launch_strip_dma_t<8, 1, SPG, 3, BF, 1>(p, grid, stream);
       case 2: return launch_strip_dma_t<8, 2, SPG, 3, BF, 1>(p, grid, stream);
+      case 3: return launch_strip_dma_t<8, 3, SPG, 3, BF, 1>(p, grid, stream);
       case 4: return launch_strip_dma_t<8, 4, SPG, 3, BF, 1>(p, grid, stream);
+      case 6:
+        if constexpr (SPG == 2) {  // (HQQ 3-bit gate/up at batch 2..16: one round of blocks instead of two -- the planner checks the zero kinds)
+          bool all_f16 = true;
+          for (int i = 0; i < p.n_prob; ++i) all_f16 = all_f16 && p.prob[i].zero_kind == ZK_F16;
+          if (all_f16) return launch_strip_dma_z<8, 6, SPG, 3, BF, 1, true>(p, grid, stream);
+        }
+        break;
     }
   } else {
     switch (p.cpl) {
       case 1: return launch_strip_dma_t<8, 1, SPG, 4, BF, 1>(p, grid, stream);
       case 2: return launch_strip_dma_t<8, 2, SPG, 4, BF, 1>(p, grid, stream);
+      case 3: return launch_strip_dma_t<8, 3, SPG, 4, BF, 1>(p, grid, stream);
       case 4: return launch_strip_dma_t<8, 4, SPG, 4, BF, 1>(p, grid, stream);
       case 6: return launch_strip_dma_t<8, 6, SPG, 4, BF, 1>(p, grid, stream);
     }

@@ -149,10 +149,12 @@ def test_native_layout_decode_routes(lib):
     # round of blocks: q/k/v 768 strips -> 192 blocks of four; gate/up 1376 strips -> 230 blocks of six, the last of each layer ragged
     assert plan(lib, [attn] * 3, 16) == "strip nw=8 cpl=4 spw=16 form=dma-A row_tiles=1" + sm
     assert plan(lib, [up] * 2, 8) == "strip nw=8 cpl=6 spw=16 form=dma-A row_tiles=1" + sm
-    assert plan(lib, [up], 16) == "strip nw=8 cpl=4 spw=16 form=dma-A row_tiles=1" + sm
+    assert plan(lib, [up], 16) == "strip nw=8 cpl=3 spw=16 form=dma-A row_tiles=1" + sm    # (round 5: 688 strips -> 230 blocks of three)
     assert plan(lib, [W(4096, 11008, 64, 4, NATIVE_F16Z)] * 2, 16) == "strip nw=8 cpl=6 spw=16 form=dma-A row_tiles=1" + sm
     assert plan(lib, [W(4096, 4096, 64, 3, NATIVE_F16Z)] * 3, 16) == "strip nw=8 cpl=4 spw=16 form=dma-A row_tiles=1" + sm
-    assert plan(lib, [W(4096, 11008, 64, 3, NATIVE_F16Z)] * 2, 16) == "strip nw=8 cpl=4 spw=16 form=dma-A row_tiles=1" + sm  # 3 bits: four at most
+    # 3 bits: six strips where the ring fits the registers (64-wide groups, fp16 zero points: HQQ) -- ONE round of 230 blocks (round 5); else four
+    assert plan(lib, [W(4096, 11008, 64, 3, NATIVE_F16Z)] * 2, 16) == "strip nw=8 cpl=6 spw=16 form=dma-A row_tiles=1" + sm
+    assert plan(lib, [W(4096, 11008, 128, 3, NATIVE)] * 2, 16) == "strip nw=8 cpl=3 spw=16 form=dma-A row_tiles=1" + sm   # (two rounds either way: fewer bytes per block)
     assert plan(lib, [attn], 32) == plan(lib, [attn], 17) == "panel cols=64 row_tiles=2 k_halves=2 split_k=4" + sm   # single layers from 17 rows
     assert plan(lib, [up], 24) == "panel cols=64 row_tiles=2 k_halves=2 split_k=1" + sm
     assert plan(lib, [attn] * 3, 32) == "panel cols=64 row_tiles=2 k_halves=2 split_k=1 layers=3" + sm
@@ -162,10 +164,10 @@ def test_native_layout_decode_routes(lib):
     assert plan(lib, [attn] * 3, 128) == "panel cols=64 row_tiles=8 k_halves=1 split_k=1 layers=3" + sm
     assert plan(lib, [W(4096, 1024, layout=NATIVE)] * 3, 64) == "panel cols=64 row_tiles=4 k_halves=2 split_k=4 layers=3" + sm   # 48 panels x 4
     assert plan(lib, [attn] * 3, 129).startswith("unsupported")
-    # Llama-2-70B shapes at batch 16: 512 strips -> 256 blocks of two; q/k/v (GQA) 640 strips -> 160 blocks of four; gate/up 3584
+    # Llama-2-70B shapes at batch 16: 512 strips -> 256 blocks of two; q/k/v (GQA) 640 strips -> 215 blocks of three; gate/up 3584
     # strips -> six per block; the TP = 8 shards of q/k/v (80 strips) stay one strip per 16-wave block
     assert plan(lib, [W(8192, 8192, layout=NATIVE)], 16) == "strip nw=8 cpl=2 spw=32 form=dma-A row_tiles=1" + sm
-    assert plan(lib, [W(8192, 8192, layout=NATIVE), W(8192, 1024, layout=NATIVE), W(8192, 1024, layout=NATIVE)], 16) == "strip nw=8 cpl=4 spw=32 form=dma-A row_tiles=1" + sm
+    assert plan(lib, [W(8192, 8192, layout=NATIVE), W(8192, 1024, layout=NATIVE), W(8192, 1024, layout=NATIVE)], 16) == "strip nw=8 cpl=3 spw=32 form=dma-A row_tiles=1" + sm
     assert plan(lib, [W(8192, 28672, layout=NATIVE)] * 2, 16) == "strip nw=8 cpl=6 spw=32 form=dma-A row_tiles=1" + sm
     assert plan(lib, [W(28672, 8192, layout=NATIVE)], 8) == "strip nw=8 cpl=2 spw=112 form=dma-A row_tiles=1" + sm
     assert plan(lib, [W(28672, 8192, layout=NATIVE)], 16) == "panel cols=64 row_tiles=1 k_halves=2 split_k=2" + sm   # K >= 2 N, 9+ rows

@@ -145,7 +145,7 @@ def test_native_grouped_launch_and_autogptq_offset(g):
 @pytest.mark.parametrize("widths", [(4096, 4096, 4096), (11008, 11008), (5152, 5152)])
 def test_native_multi_strip_blocks_at_batch_16(layout, bits, g, widths):
     """M = 5..16 on wide grouped launches (BASELINE configs[3]: HQQ g64, mixed 3 / 4 bits, batch 16): blocks of several adjacent
-    strips sharing one activation stream (strip_dma.hpp).  q/k/v-like: blocks of four; gate/up-like: blocks of six (4 bits) with a
+    strips sharing one activation stream (strip_dma.hpp).  q/k/v-like: blocks of four; gate/up-like: blocks of six (4 bits; HQQ 3 bits) with a
     ragged last block per layer (688 strips = 114 x 6 + 4); (5152, 5152): 322 strips each, blocks of four, the last one of two."""
     from qllm_amd import ops
     ds = [synth(layout, bits, g, 4096, n, seed=90 + i, bias=(i == 0)) for i, n in enumerate(widths)]
@@ -156,10 +156,12 @@ def test_native_multi_strip_blocks_at_batch_16(layout, bits, g, widths):
         assert "form=dma-A" in plan and "layout=strip-major" in plan, plan
         if g == 32:             # (32-wide groups: blocks of two strips at most)
             assert "cpl=2" in plan, plan
-        elif widths[0] in (4096, 5152):
-            assert "cpl=4" in plan, plan
-        elif widths[0] == 11008:  # (3 bits: four strips at most, two when the activation rows are few)
-            assert ("cpl=6" in plan) if bits == 4 else ("cpl=4" in plan or "cpl=2" in plan), plan
+        elif widths[0] == 4096:
+            assert "cpl=4" in plan, plan   # (768 strips: 192 blocks of four; three per block would be 258 blocks, blocks do not span layers)
+        elif widths[0] == 5152:
+            assert "cpl=3" in plan or "cpl=4" in plan, plan   # (644 strips: 216 blocks of three, round 5)
+        elif widths[0] == 11008:  # (3 bits: six strips only with fp16 zero points at 64-wide groups -- HQQ, round 5 -- else four at most)
+            assert ("cpl=6" in plan) if (bits == 4 or layout == "HQQ") else ("cpl=4" in plan or "cpl=3" in plan or "cpl=2" in plan), plan
         x = randx(m, 4096, seed=m)
         outs = ops.linear_forward_grouped(ws, torch.from_numpy(x).to(DEV))
         for o, d in zip(outs, ds):
