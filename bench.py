@@ -41,6 +41,7 @@ import csv
 import glob
 import json
 import os
+import re
 import shutil
 import subprocess
 import sys
@@ -277,7 +278,7 @@ def pmc_traffic(args):
             for r in csv.DictReader(open(f[0])):
                 if r["Counter_Name"] != ctr:
                     continue
-                if "qllm::strip_kernel" in r["Kernel_Name"]:
+                if re.search(r"qllm::strip\d?_kernel", r["Kernel_Name"]):  # (strip1_kernel: the batch-1 kernel, round 5)
                     tot += float(r["Counter_Value"])
                     n += 1
             per[ctr] = tot / max(n, 1)
@@ -290,6 +291,52 @@ def pmc_traffic(args):
         "this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `bench.py --pmc-child` "
         "(8 layers, same kernels); bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024, averaged over "
         "the decode-kernel dispatches")
+
+
+def pmc_prefill_mfma_busy():
+    """Matrix-pipe occupancy of the prefill kernel: one rocprofv3 PMC pass (SQ_VALU_MFMA_BUSY_CYCLES, GRBM_GUI_ACTIVE) over a child run
+    of this file that launches the 256x128 prefill kernel on the three Llama-2-7B shapes at M = 2048.  busy = MFMA-busy cycles per
+    SIMD / active cycles per XCD (SQ counters sum over the 1024 SIMDs, GRBM_GUI_ACTIVE over the 8 XCDs)."""
+    rocprof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if rocprof is None:
+        return None, "rocprofv3 not found"
+    d = tempfile.mkdtemp(prefix="qllm_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    cmd = [rocprof, "--kernel-trace", "--pmc", "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "-d", d, "-o", "p", "--output-format", "csv", "--",
+           sys.executable, os.path.abspath(__file__), "--pmc-child-prefill"]
+    try:
+        subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
+        f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+        busy, active, n = 0.0, 0.0, 0
+        rows = {}
+        for r in csv.DictReader(open(f[0])):
+            if "qllm::gemm3_kernel" not in r["Kernel_Name"]:
+                continue
+            rows.setdefault(r["Dispatch_Id"], {})[r["Counter_Name"]] = float(r["Counter_Value"])
+        for v in rows.values():
+            if "SQ_VALU_MFMA_BUSY_CYCLES" in v and "GRBM_GUI_ACTIVE" in v and v["GRBM_GUI_ACTIVE"] > 0:
+                busy += v["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0
+                active += v["GRBM_GUI_ACTIVE"] / 8.0
+                n += 1
+        shutil.rmtree(d, ignore_errors=True)
+        if not n:
+            return None, "no gemm3 dispatch in the counter pass"
+        return round(busy / active, 4), ("this run: rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE over `bench.py "
+                                         "--pmc-child-prefill` (%d dispatches of qllm::gemm3_kernel at M = 2048); busy cycles per SIMD / active cycles per XCD" % n)
+    except Exception as e:  # noqa: BLE001
+        shutil.rmtree(d, ignore_errors=True)
+        return None, f"rocprofv3 MFMA-busy pass failed: {type(e).__name__}"
+
+
+def pmc_child_prefill():
+    """Target of pmc_prefill_mfma_busy: two prefill passes of one decoder layer's linears at M = 2048 (AWQ w4 g128 through the modules)."""
+    dev = torch.device("cuda", 0)
+    from qllm_amd.modeling.q_layers import WQLinear_GEMM
+    ps = Stack(WQLinear_GEMM, 1, dev, seed=99)
+    xp = torch.randn(2048, HIDDEN, device=dev, dtype=torch.float16)
+    for _ in range(2):
+        ps(xp)
+    torch.cuda.synchronize()
 
 
 def self_launch(n: int) -> int:
@@ -352,10 +399,13 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the per-shape / prefill / CPU legs")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 PMC passes behind roofline.traffic")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--min-timed-s", type=float, default=1.5,
+    ap.add_argument("--pmc-child-prefill", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--min-timed-s", type=float, default=8.0,
                     help="after the K timed steps keep replaying until the GPU has been busy this long (reported as `sustained`; "
                          "the headline numbers are those of exactly K steps)")
     args = ap.parse_args()
+    if args.pmc_child_prefill:
+        return pmc_child_prefill()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus))
@@ -452,9 +502,10 @@ def main():
                    "layers": LAYERS, "linears_per_layer": 7, "batch": 1, "launches_per_step": launches,
                    "driven_through": "q_layer modules (sibling groups installed by the loader)", "grouped_qkv_gateup": fused,
                    "weight_layout": "native strip-major copy built on device at first use (qllm_repack_native)" if os.environ.get("QLLM_NATIVE_LAYOUT", "1") != "0" else "reference buffers in place",
-                   "graph": True, "parallelism": f"replicas x{world}",
+                   "graph": True, "parallelism": f"replicas x{world}", "ranks_seen": world,
+                   "backend": (dist.get_backend() if world > 1 else None),
                    "device": info["arch"], "compute_units": info["compute_units"]},
-        "roofline": {"bound": "hbm", "kernel": "qllm::strip_kernel (decode matvec; serves every launch of the step)",
+        "roofline": {"bound": "hbm", "kernel": "qllm::strip1_kernel (batch-1 decode matvec, csrc/strip1_kernel.hpp; serves every launch of the step)",
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "achievable": HBM_COPY_GBPS,
                      "frac_of_achievable": round(achieved / HBM_COPY_GBPS, 4), "traffic": traffic, "traffic_source": traffic_source,
@@ -529,6 +580,17 @@ def main():
             extra[f"prefill_m2048_{tag}"] = {"ms_per_4_layers": round(ms, 3), "TFLOPs": round(tf, 1),
                                              "frac_of_mfma_peak": round(tf / MFMA_PEAK_TFLOPS, 4)}
             del ps
+        # the other half of BASELINE's metric at top level: the prefill kernel against the dense MFMA peak (fp16 AWQ leg through the
+        # modules = 7 launches of qllm::gemm3_kernel per layer), with the matrix pipe's occupancy from a live counter pass
+        busy, busy_src = (None, "skipped (--no-pmc)") if args.no_pmc else pmc_prefill_mfma_busy()
+        pf = extra["prefill_m2048_awq"]
+        result["roofline_prefill"] = {
+            "bound": "mfma", "kernel": "qllm::gemm3_kernel (256x128x64 tiles, 8 matrix + 4 dequant waves; csrc/gemm3.hip)",
+            "workload": "llama2-7b-awq-w4-g128-prefill-m2048 (7 linears x 4 layers through the q_layer modules, hipGraph replay)",
+            "achieved": pf["TFLOPs"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": pf["frac_of_mfma_peak"],
+            "gptq_actorder_frac": extra["prefill_m2048_gptq_actorder"]["frac_of_mfma_peak"],
+            "awq_bf16_frac": extra["prefill_m2048_awq_bf16"]["frac_of_mfma_peak"],
+            "mfma_busy_frac": busy, "mfma_busy_source": busy_src, "traffic": None}
         extra.update(hqq_leg(dev))
         try:  # BASELINE configs[4] on one GPU: the per-rank shard shapes of Llama-2-70B at TP = 8
             from tools import tp_bench

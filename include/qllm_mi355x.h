@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define QLLM_ABI_VERSION 4
+#define QLLM_ABI_VERSION 5
 
 typedef enum qllm_status {
   QLLM_OK = 0,
@@ -112,6 +112,10 @@ typedef struct qllm_device_info {
 
 /* ---- library ------------------------------------------------------------------------------------------- */
 int qllm_abi_version(void);
+/* 1 for a lab build of the library (-DQLLM_LAB: the dispatchers' tuning knobs QLLM_* are re-read from the environment at every call),
+ * 0 for the release build (knobs are compile-time constants; only QLLM_NUM_CU is read).  Tools that A/B through the environment
+ * assert on it instead of timing the same kernel twice (ABI 5). */
+int qllm_is_lab_build(void);
 /* Thread-local, never NULL; "" when the calling thread's last call succeeded. */
 const char *qllm_last_error(void);
 /* Fills `out` for HIP device `device`; QLLM_ERR_DEVICE if there is none or it is not gfx950. */
@@ -239,7 +243,7 @@ int qllm_pack_qweight(const int32_t *q_kn, int32_t layout, int32_t bits, int32_t
  * not range-checked).  x, perm, out 16-byte aligned, out must not alias x; K % 8 == 0 and K <= 28672, else QLLM_ERR_UNSUPPORTED. */
 int qllm_gather_columns(const void *x, const int32_t *perm, void *out, int32_t M, int32_t K, int32_t act_dtype, void *stream);
 
-/* ---- tensor-parallel decode: one-shot all-reduce over peer-mapped staging buffers (ABI 4) -------------------------------------- */
+/* ---- tensor-parallel decode: one-shot all-reduce over peer-mapped staging buffers (ABI 4; fused form ABI 5) -------------------------------------- */
 /* For decode-sized tensors ([1, 8192] fp16 = 16 KB per row-parallel layer) a ring / tree all-reduce is pure latency.  On the xGMI
  * full mesh every rank instead writes its vector into every peer's staging buffer (one hop), waits for the world's flags and sums
  * locally in rank order (bit-identical on every rank).  One process per GPU: each rank allocates ONE staging buffer
@@ -257,6 +261,16 @@ int qllm_comm_import(const void *handle64, void **ptr);
 int qllm_comm_close(void *ptr);
 int qllm_allreduce_oneshot(void *const *peers_dev, int32_t rank, int32_t world, void *x_inout, int32_t n, int32_t act_dtype,
                            size_t slot_bytes, int32_t *status_dev, void *stream);
+/* (ABI 5) A row-parallel layer at batch 1 fused with that all-reduce: y[1, N] = sum over ranks of (x_rank . dequant(W_rank)) in ONE
+ * launch per rank.  Every block of the batch-1 kernel pushes its 16 partial outputs -- rounded to the activation type exactly as
+ * the unfused path's y -- into every peer's staging slot; the rank's last block publishes the flags, waits for the world's and
+ * writes the rank-ordered fp32 sum: bit-identical to qllm_linear_forward + qllm_allreduce_oneshot, one kernel boundary less per
+ * row-parallel layer (o_proj, down_proj: 160 per Llama-2-70B token).  Same staging buffers, epoch and calling discipline as
+ * qllm_allreduce_oneshot (the two may be mixed on one stream).  Serves M == 1 on native 4-bit layers with 128-wide groups whose
+ * K per rank the batch-1 kernel takes (<= 16384), N * 2 <= slot_bytes, y 16-byte aligned; anything else: QLLM_ERR_UNSUPPORTED
+ * and the caller runs the two calls separately.  No counterpart in the reference (no distributed code). */
+int qllm_linear_forward_allreduce(const qllm_weight_t *w, const void *x, void *y, int32_t M, int32_t act_dtype, void *const *peers_dev,
+                                  int32_t rank, int32_t world, size_t slot_bytes, int32_t *status_dev, void *stream);
 
 #ifdef __cplusplus
 }

@@ -16,15 +16,15 @@ LIB_PATH = os.environ.get("QLLM_MI355X_LIB") or os.path.join(_HERE, LIB_NAME)  #
 QLLM_OK, QLLM_ERR_INVALID, QLLM_ERR_UNSUPPORTED, QLLM_ERR_WORKSPACE, QLLM_ERR_LAUNCH, QLLM_ERR_DEVICE = range(6)
 LAYOUT_GPTQ, LAYOUT_AWQ_GEMM, LAYOUT_HQQ, LAYOUT_NATIVE, LAYOUT_NATIVE_F16Z = 0, 1, 2, 3, 4
 DT_F16, DT_BF16, DT_F16_IN_BF16_OUT = 0, 1, 2
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 EXPORTS = (
-    "qllm_abi_version", "qllm_last_error", "qllm_device_info", "qllm_workspace_bytes", "qllm_workspace_bytes_act", "qllm_workspace_init",
+    "qllm_abi_version", "qllm_is_lab_build", "qllm_last_error", "qllm_device_info", "qllm_workspace_bytes", "qllm_workspace_bytes_act", "qllm_workspace_init",
     "qllm_linear_forward", "qllm_linear_forward_grouped", "qllm_dequant", "qllm_ort_gemv", "qllm_ort_dequant",
     "qllm_awq_gemm_forward", "qllm_unpack_qweight", "qllm_pack_qweight", "qllm_gather_columns", "qllm_ort_dequantize4bits",
     "qllm_plan_describe", "qllm_debug_timeline", "qllm_native_sizes", "qllm_repack_native", "qllm_unpack_native",
     "qllm_comm_buffer_bytes", "qllm_comm_alloc", "qllm_comm_free", "qllm_comm_export", "qllm_comm_import", "qllm_comm_close",
-    "qllm_allreduce_oneshot", "qllm_convert_bf16_to_f16",
+    "qllm_allreduce_oneshot", "qllm_linear_forward_allreduce", "qllm_convert_bf16_to_f16",
 )
 
 
@@ -64,6 +64,8 @@ def _declare(lib):
     wp = C.POINTER(QllmWeight)
     lib.qllm_abi_version.restype = C.c_int
     lib.qllm_abi_version.argtypes = []
+    lib.qllm_is_lab_build.restype = C.c_int
+    lib.qllm_is_lab_build.argtypes = []
     lib.qllm_last_error.restype = C.c_char_p
     lib.qllm_last_error.argtypes = []
     lib.qllm_device_info.restype = C.c_int
@@ -86,6 +88,8 @@ def _declare(lib):
     lib.qllm_comm_close.argtypes = [vp]
     lib.qllm_allreduce_oneshot.restype = C.c_int
     lib.qllm_allreduce_oneshot.argtypes = [vp, i32, i32, vp, i32, i32, sz, vp, vp]
+    lib.qllm_linear_forward_allreduce.restype = C.c_int
+    lib.qllm_linear_forward_allreduce.argtypes = [C.POINTER(QllmWeight), vp, vp, i32, i32, vp, i32, i32, sz, vp, vp]
     lib.qllm_convert_bf16_to_f16.restype = C.c_int
     lib.qllm_convert_bf16_to_f16.argtypes = [vp, vp, sz, vp]
     lib.qllm_workspace_init.restype = C.c_int

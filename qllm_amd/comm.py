@@ -56,8 +56,11 @@ class OneShotAllReduce:
         dist.barrier(group=group)   # every rank has mapped every buffer before the first push
 
     def supports(self, t: torch.Tensor) -> bool:
-        return (t.is_cuda and t.device == self.device and t.is_contiguous() and t.dtype in (torch.float16, torch.bfloat16)
-                and t.numel() % 8 == 0 and 0 < t.numel() * 2 <= self.slot_bytes and t.data_ptr() % 16 == 0)
+        """Whether `t` travels through the one-shot kernel.  Decided ONLY from properties every rank of a collective call shares
+        (dtype, element count against the slot size): a rank-local property -- alignment, contiguity -- must never pick the path,
+        or one rank would spin in the kernel while its peer sits in dist.all_reduce."""
+        return (t.is_cuda and t.device == self.device and t.dtype in (torch.float16, torch.bfloat16)
+                and t.numel() % 8 == 0 and 0 < t.numel() * 2 <= self.slot_bytes)
 
     def all_reduce(self, t: torch.Tensor) -> torch.Tensor:
         """Sum `t` over the group, in place.  Small fp16 / bf16 tensors: the one-shot kernel; everything else: dist.all_reduce."""
@@ -66,12 +69,36 @@ class OneShotAllReduce:
         if not self.supports(t):
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
             return t
+        # a misaligned or non-contiguous tensor is staged through an aligned scratch buffer instead of changing the path
+        direct = t.is_contiguous() and t.data_ptr() % 16 == 0
+        buf = t if direct else t.contiguous().clone(memory_format=torch.contiguous_format)
         with torch.cuda.device(self.device):
-            rc = self._lib.qllm_allreduce_oneshot(self._table.data_ptr(), self.rank, self.world, t.data_ptr(), t.numel(),
+            rc = self._lib.qllm_allreduce_oneshot(self._table.data_ptr(), self.rank, self.world, buf.data_ptr(), buf.numel(),
                                                   _lib.DT_F16 if t.dtype == torch.float16 else _lib.DT_BF16, self.slot_bytes,
                                                   self._status.data_ptr(), torch.cuda.current_stream().cuda_stream)
         _lib.check(rc)
+        if not direct:
+            t.copy_(buf)
         return t
+
+    def linear_all_reduce(self, w, x2d: torch.Tensor, out: torch.Tensor) -> bool:
+        """out[1, N] = sum over ranks of x2d_rank . dequant(w_rank): the row-parallel layer and its all-reduce as ONE launch
+        (qllm_linear_forward_allreduce: the batch-1 kernel's blocks push their partial outputs into every peer's slot, the rank's
+        last block sums).  Bit-identical to `ops.linear_forward` + `all_reduce`.  False = not served (the decision depends only on
+        shapes, dtypes and the layer's layout, which every rank of a tensor-parallel layer shares): run the two steps instead."""
+        if self.world == 1 or x2d.shape[0] != 1 or x2d.dtype not in (torch.float16, torch.bfloat16) or out.dtype != x2d.dtype:
+            return False
+        if w.N * 2 > self.slot_bytes or w.N % 16 or out.data_ptr() % 16 or x2d.data_ptr() % 16:
+            return False
+        with torch.cuda.device(self.device):
+            rc = self._lib.qllm_linear_forward_allreduce(C.byref(w), x2d.data_ptr(), out.data_ptr(), 1,
+                                                         _lib.DT_F16 if x2d.dtype == torch.float16 else _lib.DT_BF16,
+                                                         self._table.data_ptr(), self.rank, self.world, self.slot_bytes,
+                                                         self._status.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        if rc == _lib.QLLM_ERR_UNSUPPORTED:
+            return False
+        _lib.check(rc)
+        return True
 
     def check(self):
         """Raise if a call timed out waiting for a peer (host sync; for tests and shutdown paths)."""
@@ -80,6 +107,7 @@ class OneShotAllReduce:
 
     def close(self):
         torch.cuda.synchronize(self.device)
+        timed_out = bool(self._own) and int(self._status.item()) != 0   # (a timed-out call continued with a partial sum: say so)
         if dist.is_initialized():
             dist.barrier(group=self.group)   # nobody unmaps while a peer may still push
         for p in self._peers:
@@ -88,6 +116,9 @@ class OneShotAllReduce:
         if self._own:
             self._lib.qllm_comm_free(self._own)
             self._own = C.c_void_p()
+        if timed_out:
+            raise RuntimeError("one-shot all-reduce: a call timed out waiting for a peer (its result was a partial sum); every rank "
+                               "must make the same sequence of calls -- call check() after a step to catch this early")
 
 
 __all__ = ["OneShotAllReduce"]

@@ -555,6 +555,9 @@ static bool panel_layers_ok(const qllm_weight_t *w, int n, int M) {
   for (int i = 0; i < n; ++i) {
     if ((w[i].bits != 4 && w[i].bits != 3) || w[i].bits != w[0].bits || !is_native(w[i]) || w[i].g_idx || w[i].K != w[0].K || w[i].group_size != w[0].group_size) return false;
     if (!panel_shape_ok(M, w[i].K, w[i].N, w[i].group_size, w[i].bits)) return false;
+    // (one launch decodes every layer's zero points the same way: fp16 zero points and packed / symmetric ones do not mix -- such a
+    //  group goes to the strips, which decide per layer, or runs layer by layer)
+    if ((zero_kind_of(w[i]) == ZK_F16) != (zero_kind_of(w[0]) == ZK_F16)) return false;
     if ((uintptr_t)w[i].qweight % 16 || (uintptr_t)w[i].scales % 16 || (w[i].qzeros && (uintptr_t)w[i].qzeros % 8)) return false;
   }
   return true;
@@ -649,6 +652,14 @@ using namespace qllm;
 extern "C" {
 
 int qllm_abi_version(void) { return QLLM_ABI_VERSION; }
+
+int qllm_is_lab_build(void) {
+#ifdef QLLM_LAB
+  return 1;
+#else
+  return 0;
+#endif
+}
 
 const char *qllm_last_error(void) { return g_err; }
 
@@ -764,12 +775,16 @@ int qllm_linear_forward(const qllm_weight_t *w, const void *x, void *y, int32_t 
     // x already converted by the caller: only the 256x128 prefill kernel writes bf16 from fp16 inputs (out_bf16)
     rc = check_io(x, y, M, QLLM_F16);
     if (rc) return rc;
-    if (w->bits != 4 || w->g_idx || M <= 64 || (uintptr_t)w->qweight % 16 != 0 || (uintptr_t)w->scales % 16 != 0)
+    if (w->bits != 4 || w->g_idx || M <= 64 || (uintptr_t)w->qweight % 16 != 0 || (uintptr_t)w->scales % 16 != 0 ||
+        (w->qzeros && (uintptr_t)w->qzeros % 8 != 0))
       return set_error(QLLM_ERR_UNSUPPORTED, "QLLM_F16_IN_BF16_OUT: 4-bit prefill calls of the 256x128 kernel only");
     GemmParams p;
     fill_gemm_params(p, w, x, y, M, QLLM_F16);
     const int lay = w->layout == QLLM_LAYOUT_AWQ_GEMM ? QLLM_LAYOUT_AWQ_GEMM : QLLM_LAYOUT_GPTQ;
-    if (!gemm3_ok(p, lay) || !(gemm2_split_k(p.M, p.N, p.K) == 1 || gemm3_use_split(p, workspace, workspace_bytes)))
+    // the predicates of the regular path in front of this kernel: native layers through native_prefill_ok, reference layouts through
+    // gemm_ok + gemm2_ok (this branch used to launch on gemm3_ok alone)
+    const bool served = is_native(*w) ? (native_prefill_ok(w, p) && !panel_serves(w, p)) : (gemm_ok(*w) && gemm2_ok(p, w->layout));
+    if (!served || !gemm3_ok(p, lay) || !(gemm2_split_k(p.M, p.N, p.K) == 1 || gemm3_use_split(p, workspace, workspace_bytes)))
       return set_error(QLLM_ERR_UNSUPPORTED, "QLLM_F16_IN_BF16_OUT: M=%d K=%d N=%d is not served by the 256x128 prefill kernel", M, w->K, w->N);
     p.out_bf16 = 1;
     return launch_gemm3(p, lay, (hipStream_t)stream);
@@ -810,6 +825,37 @@ int qllm_linear_forward(const qllm_weight_t *w, const void *x, void *y, int32_t 
   }
   return set_error(QLLM_ERR_UNSUPPORTED, "no fused kernel for bits=%d K=%d N=%d g=%d layout=%d act_order=%d; use qllm_dequant + GEMM",
                    w->bits, w->K, w->N, w->group_size, w->layout, w->g_idx != nullptr);
+}
+
+int qllm_linear_forward_allreduce(const qllm_weight_t *w, const void *x, void *y, int32_t M, int32_t act_dtype, void *const *peers_dev,
+                                  int32_t rank, int32_t world, size_t slot_bytes, int32_t *status_dev, void *stream) {
+  clear_error();
+  int rc = validate_weight(w);
+  if (rc) return rc;
+  rc = check_io(x, y, M, act_dtype);
+  if (rc) return rc;
+  if (!peers_dev) return set_error(QLLM_ERR_INVALID, "qllm_linear_forward_allreduce: peers_dev is NULL");
+  if (world < 1 || world > kCommMaxWorld || rank < 0 || rank >= world) return set_error(QLLM_ERR_INVALID, "world must be 1..%d and 0 <= rank < world (rank=%d world=%d)", kCommMaxWorld, rank, world);
+  StripPlan pl;
+  // the batch-1 kernel's shapes only (callers run the layer and qllm_allreduce_oneshot / RCCL separately for everything else)
+  if (M != 1 || !is_native(*w) || !strip_plan(w, 1, 1, &pl) || !pl.one_nw)
+    return set_error(QLLM_ERR_UNSUPPORTED, "fused all-reduce: batch-1 calls on native 4-bit layers with 128-wide groups (M=%d bits=%d g=%d layout=%d)", M, w->bits, w->group_size, w->layout);
+  if ((size_t)w->N * 2 > slot_bytes || slot_bytes % 16 != 0 || (uintptr_t)y % 16 != 0)
+    return set_error(QLLM_ERR_UNSUPPORTED, "fused all-reduce: N * 2 <= slot_bytes, slot_bytes %% 16 == 0, y 16-byte aligned (N=%d slot=%zu)", w->N, slot_bytes);
+  Strip1Params p;
+  memset(&p, 0, sizeof(p));
+  p.x = x;
+  p.T = w->K / 32;
+  p.n_groups = w->K / 128;
+  p.add_zero_bias = w->add_zero_bias;
+  p.act_bf16 = (act_dtype == QLLM_BF16);
+  p.prob[0] = Strip1Problem{(const uint32_t *)w->qweight, (const half_t *)w->scales, w->qzeros, (const half_t *)w->bias, y, w->N / 16, zero_kind_of(*w)};
+  p.ar_peers = peers_dev;
+  p.ar_status = status_dev;
+  p.ar_rank = rank;
+  p.ar_world = world;
+  p.ar_slot_bytes = (uint32_t)slot_bytes;
+  return launch_strip1_allreduce(p, pl.one_nw, pl.one_maxs, w->N / 16, (hipStream_t)stream);
 }
 
 int qllm_dequant(const qllm_weight_t *w, void *out, int32_t out_dtype, int32_t out_transposed, void *stream) {

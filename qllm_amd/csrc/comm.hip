@@ -25,23 +25,6 @@ namespace qllm {
 namespace {
 
 constexpr int kCommThreads = 1024;
-constexpr int kCommMaxWorld = 16;
-
-// staging buffer of one rank: [2 parities][world][slot_bytes] payload | control block
-struct CommCtl {
-  uint32_t flag[2][kCommMaxWorld];  // flag[parity][src rank] = epoch of the last push
-  uint32_t epoch;                   // calls completed by the owner (read and bumped by its own kernel only)
-};
-
-__device__ __forceinline__ void store16_sys(void *p, uint4_t v) {
-  __hip_atomic_store((uint64_t *)p, ((uint64_t)v.y << 32) | v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  __hip_atomic_store((uint64_t *)p + 1, ((uint64_t)v.w << 32) | v.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-__device__ __forceinline__ uint4_t load16_sys(const void *p) {
-  const uint64_t a = __hip_atomic_load((const uint64_t *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  const uint64_t b = __hip_atomic_load((const uint64_t *)p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  return uint4_t{(uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32)};
-}
 
 template <bool BF16>
 __global__ __launch_bounds__(kCommThreads) void allreduce_oneshot_kernel(void *const *__restrict__ peers, int rank, int world, void *x_inout,

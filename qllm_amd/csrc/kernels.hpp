@@ -117,9 +117,34 @@ struct Strip1Params {
   int act_bf16;
   uint64_t *dbg;  // diagnostics (qllm_debug_timeline): 24 timestamps for this launch (3 blocks x 8), or NULL
   Strip1Problem prob[kMaxProblems];
+  // row-parallel layer fused with its one-shot all-reduce (comm.hip; the AR instantiations, one layer per launch): every block pushes
+  // its 16 partial outputs into every peer's staging slot; the rank's last block publishes the flags, waits for the world and sums
+  void *const *ar_peers;   // device array of the world's staging buffers (this rank's at index ar_rank)
+  int *ar_status;          // set to 1 if a peer never arrived (nullable)
+  int ar_rank, ar_world;
+  uint32_t ar_slot_bytes;
 };
+
+// ---- comm.hip: staging buffer of one rank = [2 parities][world][slot_bytes] payload | this control block ----------------------------
+constexpr int kCommMaxWorld = 16;
+struct CommCtl {
+  uint32_t flag[2][kCommMaxWorld];  // flag[parity][src rank] = epoch of the last push
+  uint32_t epoch;                   // calls completed by the owner (read and bumped by its own kernels only)
+  uint32_t ticket;                  // fused GEMV + all-reduce: blocks of the running launch that have pushed (re-armed by the last one)
+};
+// 16-byte system-scope (write-through) store / load: what crosses xGMI
+__device__ __forceinline__ void store16_sys(void *p, uint4_t v) {
+  __hip_atomic_store((uint64_t *)p, ((uint64_t)v.y << 32) | v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store((uint64_t *)p + 1, ((uint64_t)v.w << 32) | v.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ uint4_t load16_sys(const void *p) {
+  const uint64_t a = __hip_atomic_load((const uint64_t *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  const uint64_t b = __hip_atomic_load((const uint64_t *)p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  return uint4_t{(uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32)};
+}
 bool strip1_shape(int K, int blocks, int cus, int *nw, int *maxs);
 int launch_strip1(const Strip1Params &p, int nw, int maxs, int n_prob, int max_strips, hipStream_t stream);
+int launch_strip1_allreduce(const Strip1Params &p, int nw, int maxs, int n_strips, hipStream_t stream);  // (p.ar_* set; one layer)
 
 // ---- native.hip (reference layouts <-> the strip-major native layout) -------------------------------------------------------
 int launch_repack_native(const qllm_weight_t &src, int zero_kind, void *qweight_out, void *scales_out, void *qzeros_out, hipStream_t stream);

@@ -41,6 +41,27 @@ static int launch_e(const Strip1Params &p, dim3 grid, hipStream_t stream) {
   return (NW * MAXS == p.T) ? launch_t<NW, MAXS, true, false>(p, grid, stream) : launch_t<NW, MAXS, false, false>(p, grid, stream);
 }
 
+template <int NW, int MAXS>
+static int launch_ar(const Strip1Params &p, int n_strips, hipStream_t stream) {
+  constexpr int lds_bytes = strip1_lds_bytes<NW, MAXS>();
+  if (NW * MAXS == p.T) hipLaunchKernelGGL((strip1_kernel<NW, MAXS, true, 2, 4, false, true>), dim3(n_strips, 1), dim3(NW * 64), lds_bytes, stream, p);
+  else hipLaunchKernelGGL((strip1_kernel<NW, MAXS, false, 2, 4, false, true>), dim3(n_strips, 1), dim3(NW * 64), lds_bytes, stream, p);
+  QLLM_HIP_CHECK(hipGetLastError());
+  return QLLM_OK;
+}
+
+// the row-parallel layer fused with its one-shot all-reduce: the forms of the Llama-class row-parallel shards (K / world per rank)
+int launch_strip1_allreduce(const Strip1Params &p, int nw, int maxs, int n_strips, hipStream_t stream) {
+  if (nw == 4 && maxs == 8) return launch_ar<4, 8>(p, n_strips, stream);
+  if (nw == 4 && maxs == 16) return launch_ar<4, 16>(p, n_strips, stream);
+  if (nw == 4 && maxs == 32) return launch_ar<4, 32>(p, n_strips, stream);
+  if (nw == 8 && maxs == 16) return launch_ar<8, 16>(p, n_strips, stream);
+  if (nw == 8 && maxs == 24) return launch_ar<8, 24>(p, n_strips, stream);
+  if (nw == 8 && maxs == 32) return launch_ar<8, 32>(p, n_strips, stream);
+  if (nw == 16 && maxs == 24) return launch_ar<16, 24>(p, n_strips, stream);
+  return set_error(QLLM_ERR_UNSUPPORTED, "fused all-reduce: no batch-1 instantiation for nw=%d round=%d", nw, maxs);
+}
+
 int launch_strip1(const Strip1Params &p, int nw, int maxs, int n_prob, int max_strips, hipStream_t stream) {
   const dim3 grid(max_strips, n_prob);
   if (p.dbg) {  // diagnostics instantiations (timeline stamps): the two Llama-2-7B forms

@@ -51,7 +51,11 @@ constexpr int strip1_lds_bytes() {
 }
 
 // NW waves x MAXS k-steps cover T (host: NW * MAXS >= T >= MAXS; EXACT: NW * MAXS == T, no masking of a shifted window)
-template <int NW, int MAXS, bool EXACT, int NCH = 2, int LVL = 4, bool DBG = false>
+// AR: the row-parallel form (one layer per launch, p.ar_* set): instead of storing y the block pushes its 16 partial outputs, rounded to
+//     the activation type like the unfused path's y, into slot [parity][rank] of EVERY peer's staging buffer (comm.hip's layout and
+//     protocol) and takes a ticket; the rank's last block publishes the world's flags, waits for the peers' and writes the sum of the
+//     slots in rank order -- the o_proj / down_proj launch and its all-reduce are ONE launch (160 kernel boundaries per Llama-2-70B token).
+template <int NW, int MAXS, bool EXACT, int NCH = 2, int LVL = 4, bool DBG = false, bool AR = false>
 // (second launch bound = minimum waves per SIMD: 64 registers up to rounds of 24 k-steps -- a CU full of waves -- 128 above)
 __global__ __launch_bounds__(NW * 64, (MAXS <= 24) ? 8 : 4) void strip1_kernel(const Strip1Params p) {
   static_assert(MAXS % 4 == 0 && MAXS >= 8 && MAXS <= 32, "rounds are whole 128-wide groups, at most 8 of them");
@@ -241,6 +245,7 @@ __global__ __launch_bounds__(NW * 64, (MAXS <= 24) ? 8 : 4) void strip1_kernel(c
   if constexpr (DBG) {
     if (dbg_slot && lane == 0) dbg_slot[4] = __builtin_amdgcn_s_memrealtime();
   }
+  float vfin = 0.f;  // (lanes 0..15 of wave 0: the block's 16 outputs)
   if (threadIdx.x < 16) {
     const float4_t *row = (const float4_t *)(lds + threadIdx.x * RS);
     float4_t t[NW];
@@ -261,8 +266,88 @@ __global__ __launch_bounds__(NW * 64, (MAXS <= 24) ? 8 : 4) void strip1_kernel(c
     }
     const int n = b * 16 + threadIdx.x;
     if (pr.bias) v += (float)pr.bias[n];
-    if (p.act_bf16) ((uint16_t *)pr.y)[n] = f32_to_bf16(v);
-    else ((half_t *)pr.y)[n] = (half_t)v;
+    vfin = v;
+    if constexpr (!AR) {
+      if (p.act_bf16) ((uint16_t *)pr.y)[n] = f32_to_bf16(v);
+      else ((half_t *)pr.y)[n] = (half_t)v;
+    }
+  }
+  if constexpr (AR) {
+    // ---- push: the 16 partial outputs as two 16-byte system-scope stores per peer (lanes 0 and 1 of wave 0, through LDS) ------------
+    const int world = p.ar_world, rank = p.ar_rank;
+    const size_t slot = p.ar_slot_bytes, payload = 2 * (size_t)world * slot;
+    CommCtl *own = (CommCtl *)((char *)p.ar_peers[rank] + payload);
+    // (every block reads the epoch before it takes its ticket; the last block bumps it after the last ticket)
+    const uint32_t epoch = __hip_atomic_load(&own->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    const int parity = (int)(epoch & 1u);
+    uint16_t *stage = (uint16_t *)(lds + 16 * RS);  // (the first wave's staging area: its activations are long consumed)
+    int *s_last = (int *)(lds + 16 * RS) + 16;
+    if (wave == 0) {
+      if (lane < 16) stage[lane] = p.act_bf16 ? f32_to_bf16(vfin) : __builtin_bit_cast(uint16_t, (half_t)vfin);
+      if (lane < 2) {
+        const uint4_t chunk = *(const uint4_t *)(stage + 8 * lane);
+        for (int q = 0; q < world; ++q) {
+          char *dst = (char *)p.ar_peers[q] + ((size_t)parity * world + rank) * slot + ((size_t)b * 16 + 8 * lane) * 2;
+          store16_sys(dst, chunk);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-through stores have left ...
+      if (lane == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // ... (system scope) before the ticket says so
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t ticket = __hip_atomic_fetch_add(&own->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *s_last = (ticket == gridDim.x - 1) ? 1 : 0;
+      }
+    }
+    __syncthreads();
+    if (*s_last == 0) return;
+    // ---- the rank's last block: every block's slice is in every peer's slot.  Publish, wait for the world, sum in rank order ----------
+    if (threadIdx.x == 0) __hip_atomic_store(&own->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm (graph replay)
+    if ((int)threadIdx.x < world) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the other blocks' tickets (and the stores in front of them)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      CommCtl *peer = (CommCtl *)((char *)p.ar_peers[threadIdx.x] + payload);
+      __hip_atomic_store(&peer->flag[parity][rank], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      unsigned spins = 0;
+      while (__hip_atomic_load(&own->flag[parity][threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != epoch) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > (1u << 26)) {  // a peer never arrived (seconds): report instead of hanging the GPU
+          if (p.ar_status) *p.ar_status = 1;
+          break;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    }
+    __syncthreads();
+    const char *mine = (const char *)p.ar_peers[rank] + (size_t)parity * world * slot;
+    const int n16 = (int)gridDim.x * 2;  // 16-byte chunks of the output row (16 columns per block)
+    for (int c = threadIdx.x; c < n16; c += NW * 64) {
+      float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      for (int r = 0; r < world; ++r) {
+        const uint4_t v = load16_sys(mine + (size_t)r * slot + (size_t)c * 16);
+        const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (p.act_bf16) {
+            a8[2 * j] += __builtin_bit_cast(float, wds[j] << 16);
+            a8[2 * j + 1] += __builtin_bit_cast(float, wds[j] & 0xffff0000u);
+          } else {
+            const half2_t h = as_h2(wds[j]);
+            a8[2 * j] += (float)h.x;
+            a8[2 * j + 1] += (float)h.y;
+          }
+        }
+      }
+      uint32_t o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (p.act_bf16) o[j] = (uint32_t)f32_to_bf16(a8[2 * j]) | ((uint32_t)f32_to_bf16(a8[2 * j + 1]) << 16);
+        else o[j] = as_u32(half2_t{(half_t)a8[2 * j], (half_t)a8[2 * j + 1]});
+      }
+      *((uint4_t *)pr.y + c) = uint4_t{o[0], o[1], o[2], o[3]};
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(&own->epoch, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if constexpr (DBG) {
     if (dbg_slot && lane == 0) dbg_slot[5] = __builtin_amdgcn_s_memrealtime();

@@ -197,6 +197,21 @@ class HipForwardMixin:
             out.copy_(self(x).reshape(out.shape))
         return out
 
+    def forward_allreduce_into(self, x: torch.Tensor, out: torch.Tensor, reducer) -> bool:
+        """Row-parallel shard at batch 1: y = sum over ranks of forward(x_rank), in ONE launch per rank (the batch-1 kernel pushes its
+        partial outputs straight into the peers' staging buffers of `reducer`, a qllm_amd.comm.OneShotAllReduce; csrc/strip1_kernel.hpp,
+        AR).  False when the call is not served (rows, layout, shape, act-order): the caller then runs forward_into + the collective."""
+        x2d = x.reshape(-1, x.shape[-1])
+        resolve = getattr(self, "_resolve_act_order", None)
+        if resolve is not None:
+            resolve()
+        if (x2d.shape[0] != 1 or getattr(self, "act_order", None) or not x2d.is_contiguous() or not out.is_contiguous()
+                or not hasattr(reducer, "linear_all_reduce")):
+            return False
+        azb = autogptq_compat() if self._layout_name() == "GPTQ" else 0
+        w = self.native_descriptor(azb)
+        return w is not None and reducer.linear_all_reduce(w, x2d, out.view(1, self.outfeatures))
+
     def _hip_linear(self, x: torch.Tensor, act_order_g_idx=None, add_zero_bias: int = 0) -> torch.Tensor:
         if not x.is_cuda or not self.qweight.is_cuda:
             raise RuntimeError(
@@ -213,7 +228,7 @@ class HipForwardMixin:
         try:
             try:
                 # (bf16 prefill: x is converted to fp16 ONCE per distinct tensor -- siblings share it -- instead of once per call)
-                y = ops.linear_forward_shared(w, x2d) if act_order_g_idx is None else ops.linear_forward(w, x2d)
+                y = ops.linear_forward_shared(w, x2d, key=x) if act_order_g_idx is None else ops.linear_forward(w, x2d)
             except ops.QllmUnsupported:
                 if w.layout not in (ops.LAYOUTS["NATIVE"], ops.LAYOUTS["NATIVE_F16Z"]):
                     raise

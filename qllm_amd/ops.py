@@ -134,33 +134,53 @@ def linear_forward(w: QllmWeight, x2d: torch.Tensor, out: Optional[torch.Tensor]
 _LAST_CONVERT: dict = {}
 
 
-def bf16_as_f16(x2d: torch.Tensor) -> torch.Tensor:
+def _tensor_version(t) -> int:
+    return 0 if t.is_inference() else t._version
+
+
+def bf16_as_f16(x2d: torch.Tensor, key: Optional[torch.Tensor] = None) -> torch.Tensor:
     """fp16 copy of a contiguous bf16 activation matrix (round to nearest even, what `.to(float16)` does), made by the library's
-    kernel and REMEMBERED per device for the very tensor it was made from (identity + version, held weakly): q/k/v -- and gate/up --
-    are called with the same tensor one after the other, so three prefill calls convert once."""
+    kernel and REMEMBERED per device for the tensor OBJECT it was made from: q/k/v -- and gate/up -- are called with the same
+    tensor one after the other, so three prefill calls convert once.  `key` is that object (module code passes the `x` its forward
+    received: `x.reshape(-1, K)` is a fresh object per call and would never hit); it is held weakly and its death drops the copy,
+    so the cache never keeps a prefill-sized buffer beyond its input's life.  Inference tensors (no version counter: an in-place
+    update could not be seen) are converted every time."""
     import weakref
-    ver = 0 if x2d.is_inference() else x2d._version
-    hit = _LAST_CONVERT.get(x2d.device)
-    if hit is not None and hit[0]() is x2d and hit[1] == ver:
-        return hit[2]
+    k = x2d if key is None else key
+    cacheable = not k.is_inference() and k.device == x2d.device
+    dev = x2d.device
+    if cacheable:
+        hit = _LAST_CONVERT.get(dev)
+        if hit is not None and hit[0]() is k and hit[1] == k._version and hit[2].shape == x2d.shape:
+            return hit[2]
     _check_input(x2d, "x")
-    out = torch.empty(x2d.shape, dtype=torch.float16, device=x2d.device)
-    with torch.cuda.device(x2d.device):
+    out = torch.empty(x2d.shape, dtype=torch.float16, device=dev)
+    with torch.cuda.device(dev):
         _lib.check(_lib.load().qllm_convert_bf16_to_f16(x2d.data_ptr(), out.data_ptr(), x2d.numel(), _stream_ptr()))
-    _LAST_CONVERT[x2d.device] = (weakref.ref(x2d), ver, out)
+    if cacheable:
+        def _drop(ref, dev=dev):
+            cur = _LAST_CONVERT.get(dev)
+            if cur is not None and cur[0] is ref:
+                _LAST_CONVERT.pop(dev, None)
+        _LAST_CONVERT[dev] = (weakref.ref(k, _drop), k._version, out)
+    else:
+        _LAST_CONVERT.pop(dev, None)
     return out
 
 
-def linear_forward_bf16_via_f16(w: QllmWeight, x2d: torch.Tensor) -> torch.Tensor:
+def linear_forward_bf16_via_f16(w: QllmWeight, x2d: torch.Tensor, key: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Prefill-sized bf16 call with the conversion of x hoisted and shared (QLLM_F16_IN_BF16_OUT): bit-identical to
     `linear_forward(w, x2d)` on the 256x128 prefill kernel, which converts x into the workspace on every call.  Raises
-    QllmUnsupported where that kernel does not serve the call (callers then use linear_forward)."""
+    QllmUnsupported where that kernel does not serve the call (callers then use linear_forward) -- decided from the plan BEFORE x is
+    converted, so that a call the panel kernel / gemm2 / the fallbacks take does not pay for a copy it cannot use."""
     _check_x(x2d, (w,))
     if x2d.dtype != torch.bfloat16 or x2d.shape[0] <= 64 or x2d.numel() % 8 != 0:
-        raise QllmUnsupported("bf16 prefill calls only")
+        raise QllmUnsupported(_lib.QLLM_ERR_UNSUPPORTED, "bf16 prefill calls only")
+    if w.bits != 4 or not plan_describe([w], x2d.shape[0]).startswith("gemm3"):
+        raise QllmUnsupported(_lib.QLLM_ERR_UNSUPPORTED, "not a call of the 256x128 prefill kernel")
     lib = _lib.load()
     m = x2d.shape[0]
-    xh = bf16_as_f16(x2d)
+    xh = bf16_as_f16(x2d, key)
     out = torch.empty((m, w.N), dtype=torch.bfloat16, device=x2d.device)
     with torch.cuda.device(x2d.device):
         nbytes = lib.qllm_workspace_bytes_act(C.byref(w), m, DT_F16)
@@ -171,11 +191,12 @@ def linear_forward_bf16_via_f16(w: QllmWeight, x2d: torch.Tensor) -> torch.Tenso
     return out
 
 
-def linear_forward_shared(w: QllmWeight, x2d: torch.Tensor) -> torch.Tensor:
-    """linear_forward for module code: bf16 prefill calls go through the shared fp16 copy of x where the kernel allows it."""
+def linear_forward_shared(w: QllmWeight, x2d: torch.Tensor, key: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """linear_forward for module code: bf16 prefill calls go through the shared fp16 copy of x where the kernel allows it.  `key`:
+    the tensor object whose identity marks "the same input" across sibling calls (default: x2d itself)."""
     if x2d.dtype == torch.bfloat16 and x2d.shape[0] > 64:
         try:
-            return linear_forward_bf16_via_f16(w, x2d)
+            return linear_forward_bf16_via_f16(w, x2d, key)
         except QllmUnsupported:
             pass
     return linear_forward(w, x2d)

@@ -228,19 +228,22 @@ class RowParallelQuantLinear(nn.Module):
     """`reducer`: an object with `all_reduce(tensor)` (qllm_amd.comm.OneShotAllReduce: decode-sized sums through the one-shot
     peer-write kernel, larger ones through RCCL); None = `dist.all_reduce`."""
 
-    def __init__(self, shard: nn.Module, group=None, input_is_parallel: bool = True, static_output: bool = False, reducer=None):
+    def __init__(self, shard: nn.Module, group=None, input_is_parallel: bool = True, static_output: bool = False, reducer=None,
+                 fuse_reduce: bool = True):
         super().__init__()
         self.shard = shard
         self.group = group
         self.input_is_parallel = input_is_parallel
         self.static_output = static_output
         self.reducer = reducer
+        self.fuse_reduce = fuse_reduce   # batch 1 + one-shot reducer: GEMV and all-reduce in one launch (False: two launches)
         self._bufs: dict = {}
 
     @classmethod
-    def from_full(cls, layer: nn.Module, group=None, input_is_parallel: bool = True, static_output: bool = False, reducer=None):
+    def from_full(cls, layer: nn.Module, group=None, input_is_parallel: bool = True, static_output: bool = False, reducer=None,
+                  fuse_reduce: bool = True):
         rank, world = _world(group)
-        return cls(shard_rows(layer, rank, world), group, input_is_parallel, static_output, reducer)
+        return cls(shard_rows(layer, rank, world), group, input_is_parallel, static_output, reducer, fuse_reduce)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         rank, world = _world(self.group)
@@ -253,12 +256,21 @@ class RowParallelQuantLinear(nn.Module):
                 x = x[..., rank * kl:(rank + 1) * kl]
         # (input_is_parallel with an act-order shard: the producer was sharded with columns=shard.input_index)
         x = x.contiguous()
-        if self.static_output:
+        fuse = (world > 1 and self.fuse_reduce and self.reducer is not None and x.is_cuda and x.numel() == x.shape[-1]
+                and hasattr(self.shard, "forward_allreduce_into"))
+        if self.static_output or fuse:
             lead = tuple(x.shape[:-1])
-            key = (lead, x.dtype, x.device)
-            y = self._bufs.get(key)
-            if y is None:
-                y = self._bufs[key] = torch.empty(lead + (self.shard.outfeatures,), dtype=x.dtype, device=x.device)
+            if self.static_output:
+                key = (lead, x.dtype, x.device)
+                y = self._bufs.get(key)
+                if y is None:
+                    y = self._bufs[key] = torch.empty(lead + (self.shard.outfeatures,), dtype=x.dtype, device=x.device)
+            else:
+                y = torch.empty(lead + (self.shard.outfeatures,), dtype=x.dtype, device=x.device)
+            # batch 1 with a one-shot reducer: the shard's launch pushes its partial outputs to the peers itself and its last block
+            # sums -- ONE launch instead of GEMV + all-reduce (csrc/strip1_kernel.hpp, AR); bit-identical to the two-step path
+            if fuse and self.shard.forward_allreduce_into(x, y.view(-1, self.shard.outfeatures), self.reducer):
+                return y
             self.shard.forward_into(x, y.view(-1, self.shard.outfeatures))
         else:
             y = self.shard(x)

@@ -201,6 +201,59 @@ def _body(rank, world):
     x1 = torch.from_numpy(randx(1, K, seed=77)).to(dev)
     if _rel(rp1(x1), full["GEMM"](x1)) > 1e-3:
         msgs.append("row-parallel layer behind the one-shot reducer differs from the unsharded layer")
+    # ---- fused (round 5, csrc/strip1_kernel.hpp AR): at batch 1 the row-parallel shard's launch pushes its partial outputs to the
+    #      peers itself and its last block sums: no separate all-reduce launch, BIT-IDENTICAL to GEMV + one-shot all-reduce, equal on
+    #      every rank, over many calls (epochs, parities, the ticket re-arming), fp16 and bf16 activations, with a bias, the
+    #      shifted-window form (K / 2 = 5504), mixed with plain one-shot calls on the same buffers, and as a hipGraph
+    dbias = synth("GPTQ", 4, 128, 11008, 4096, bias=True, seed=23)
+    dbias["scales"] = (dbias["scales"].astype(np.float32) * 0.2).astype(np.float16)
+    cases = [("GEMM 4096x4096", full["GEMM"], K), ("GPTQ 4096x4096", full["GPTQ"], K), ("GPTQ 11008x4096 bias", to_layer(dbias, dev), 11008)]
+    real_one = ar.all_reduce
+    n_one = [0]
+    ar.all_reduce = lambda t_: (n_one.__setitem__(0, n_one[0] + 1), real_one(t_))[1]
+    for name, layer, kk in cases:
+        rf = P.RowParallelQuantLinear.from_full(layer, input_is_parallel=False, static_output=True, reducer=ar, fuse_reduce=True)
+        ru = P.RowParallelQuantLinear.from_full(layer, input_is_parallel=False, static_output=True, reducer=ar, fuse_reduce=False)
+        for dtype in (torch.float16, torch.bfloat16):
+            for it in range(5):
+                xx = torch.from_numpy(randx(1, kk, seed=500 + it)).to(dev).to(dtype)
+                n0 = n_one[0]
+                yf = rf(xx).clone()
+                if n_one[0] != n0:
+                    msgs.append(f"fused row-parallel {name} {dtype}: the separate all-reduce ran (fused launch not taken)")
+                yu = ru(xx).clone()
+                torch.cuda.synchronize()
+                if not torch.equal(yf, yu):
+                    msgs.append(f"fused row-parallel {name} {dtype} call {it}: differs from GEMV + one-shot all-reduce ({_rel(yf, yu):.2e})")
+                both = [torch.empty_like(yf) for _ in range(world)]
+                dist.all_gather(both, yf)
+                if not torch.equal(both[0], both[1]):
+                    msgs.append(f"fused row-parallel {name} {dtype}: ranks disagree")
+        if _rel(rf(torch.from_numpy(randx(1, kk, seed=9)).to(dev)), layer(torch.from_numpy(randx(1, kk, seed=9)).to(dev))) > 2e-3:
+            msgs.append(f"fused row-parallel {name}: differs from the unsharded layer")
+    ar.all_reduce = real_one
+    ar.check()
+    rf = P.RowParallelQuantLinear.from_full(full["GEMM"], input_is_parallel=False, static_output=True, reducer=ar)
+    xg = torch.from_numpy(randx(1, K, seed=91)).to(dev)
+    exp_f = rf(xg).clone()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        rf(xg)
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    gf = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gf):
+        yg = rf(xg)
+    dist.barrier()
+    for _ in range(3):
+        yg.zero_()
+        gf.replay()
+        torch.cuda.synchronize()
+        if not torch.equal(yg, exp_f):
+            msgs.append("graph replay of the fused row-parallel launch differs")
+        dist.barrier()
+    ar.check()
     t = torch.randn(8192, device=dev, dtype=torch.float16, generator=gen)
     tin = t.clone()
     exp = tin.clone()
@@ -248,5 +301,6 @@ def test_hip_shards_behind_a_real_collective_two_ranks_one_gpu(capfd):
     assert "[tp_bench] world_size=2 backend=gloo tp_degree=2 layers=2" in out
     assert "[tp_bench] sharded == unsharded on 2 rank(s)" in out
     assert "[tp_bench] row-parallel sums: one-shot peer-write kernel" in out and '"oneshot_all_reduce_us_16KB"' in out
-    assert "[tp_bench] step runs as: eager (backend gloo" in out
+    assert "[tp_bench] step runs as: hipGraph replay" in out   # (every sum of the step is one of the library's kernels: it captures under gloo too)
+    assert "[tp_bench] row-parallel GEMV + all-reduce: fused (one launch)" in out and '"row_parallel_all_reduce_fused_into_gemv": true' in out
     assert '"ranks": 2' in out and '"all_reduces_per_layer": 2' in out

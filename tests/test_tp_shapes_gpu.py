@@ -121,7 +121,7 @@ def test_tp_block_through_modules_uses_grouped_shard_launches():
     from tools import tp_bench
     blocks = tp_bench.build_stack(8, 2, torch.device(DEV), seed=3)
     b0 = blocks[0]
-    assert b0.q_proj._siblings.describe(1).startswith("strip") and b0.gate_proj._siblings.describe(1).startswith("strip nw=8 cpl=1 spw=32 form=lds-slab row_tiles=1 layout=strip-major")
+    assert b0.q_proj._siblings.describe(1).startswith("strip") and b0.gate_proj._siblings.describe(1) == "strip1 nw=8 round=32 exact grid=strips x 2 layout=strip-major"
     h = torch.randn(1, tp_bench.H70, device=DEV, dtype=torch.float16)
     y = h
     for b in blocks:

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Decode (M small) latency of narrow-N / tensor-parallel shard shapes under the current dispatch knobs:
-   QLLM_STRIP_MIN=192 python tools/narrow_ab.py     vs     QLLM_STRIP_MIN=48 python tools/narrow_ab.py
-Prints plan + us per launch (graph replay over distinct weight sets, HIP events)."""
+   QLLM_MI355X_LIB=tools/lab/libqllm_lab.so QLLM_STRIP_MIN=192 python tools/narrow_ab.py   vs   ... QLLM_STRIP_MIN=48 ...
+Prints plan + us per launch (graph replay over distinct weight sets, HIP events).  The release library compiles its knobs in:
+with a QLLM_* knob in the environment this tool insists on the LAB build (tools/lab/build_lab.sh; qllm_is_lab_build)."""
 import os
 import sys
 
@@ -11,6 +12,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from qllm_amd import ops  # noqa: E402
 from qllm_amd.modeling.q_layers import QuantLinearGPTQ  # noqa: E402
 
+if "QLLM_STRIP_MIN" in os.environ and not ops._lib.load().qllm_is_lab_build():
+    raise SystemExit("QLLM_STRIP_MIN is set but the loaded library is the release build (knobs are compile-time constants there): "
+                     "run with QLLM_MI355X_LIB=tools/lab/libqllm_lab.so")
 dev = torch.device("cuda:0")
 SHAPES = [(8192, [1024, 128, 128]), (8192, [1024]), (8192, [3584, 3584]), (1024, [8192]), (3584, [8192]), (4096, [1024]),
           (4096, [2048]), (4096, [512, 512, 512]), (8192, [8192]), (8192, [28672])]

@@ -224,7 +224,9 @@ def run(args, world, rank, dev, info):
 
     # Graph path: one rank (no collective) or RCCL ("nccl": its collectives are stream operations and capture with the kernels).
     # Any other backend (gloo: host-side collectives) runs eagerly BY DESIGN; a failed RCCL capture is reported, not hidden.
-    want_graph = world == 1 or (backend == "nccl" and os.environ.get("QLLM_TP_GRAPH", "1") != "0")
+    # (round 5: with the one-shot reducer every sum of the step is one of the library's own kernels -- fused into the row-parallel
+    #  launch at batch 1 -- so the step captures whatever the backend)
+    want_graph = world == 1 or ((backend == "nccl" or reducer is not None) and os.environ.get("QLLM_TP_GRAPH", "1") != "0")
     graph_mode = "eager (backend %s: collectives are not stream operations)" % backend if not want_graph else None
     run_step = step
     out = None
@@ -261,6 +263,34 @@ def run(args, world, rank, dev, info):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t[0])
     ms_per_step = wall * 1e3 / args.steps
+    # the same step with the row-parallel launches and their all-reduces as TWO launches each (fuse_reduce off): what the fusion buys
+    ms_unfused = None
+    fused = bool(reducer is not None and world > 1 and getattr(blocks[0].o_proj, "fuse_reduce", False))
+    if fused:
+        for b in blocks:
+            b.o_proj.fuse_reduce = b.down_proj.fuse_reduce = False
+        run2 = step
+        if want_graph and graph_mode == "hipGraph replay":
+            try:
+                graph2, _ = _capture(step)
+                run2 = graph2.replay
+            except Exception:  # noqa: BLE001
+                torch.cuda.synchronize()
+        for _ in range(args.warmup):
+            run2()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            run2()
+        barrier()
+        w2 = time.perf_counter() - t0
+        t = torch.tensor([w2], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ms_unfused = float(t[0]) * 1e3 / args.steps
+        for b in blocks:
+            b.o_proj.fuse_reduce = b.down_proj.fuse_reduce = True
+        if rank == 0:
+            print(f"[tp_bench] row-parallel GEMV + all-reduce: fused (one launch) {ms_per_step:.4f} ms per step, unfused (two launches) {ms_unfused:.4f}", flush=True)
     ar_us = ar1_us = None
     if world > 1:  # the decode-sized all-reduce on its own ([1, 8192] fp16 = 16 KB: latency-bound over xGMI)
         buf = torch.zeros(M, H70, device=dev, dtype=torch.float16)
@@ -282,6 +312,7 @@ def run(args, world, rank, dev, info):
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": "llama2-70b-awq-w4-g128-decode-b1-tp", "tp_degree": P, "ranks": world, "backend": backend,
                        "layers": n_layers, "launches_per_layer": 4, "all_reduces_per_layer": 2 if world > 1 else 0,
+                       "row_parallel_all_reduce_fused_into_gemv": fused, "ranks_seen": dist.get_world_size() if world > 1 else 1,
                        "graph": graph_mode, "parallelism": f"tp{P}" + ("" if world > 1 else " (1 rank, no collective)"),
                        "device": info["arch"]},
             "roofline": {"bound": "hbm", "kernel": "qllm::strip_kernel", "achieved": round(nbytes / ms_per_step / 1e6, 1),
@@ -289,6 +320,7 @@ def run(args, world, rank, dev, info):
                          "traffic": None},
             "all_reduce_us_16KB": None if ar_us is None else round(ar_us, 2),
             "oneshot_all_reduce_us_16KB": None if ar1_us is None else round(ar1_us, 2), "row_parallel_sums": reducer_mode,
+            "ms_per_step_unfused_all_reduce": None if ms_unfused is None else round(ms_unfused, 4),
             "cpu_baseline": None}), flush=True)
     if reducer is not None:
         reducer.close()
