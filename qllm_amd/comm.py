@@ -54,12 +54,49 @@ class OneShotAllReduce:
             self._status = torch.zeros(1, dtype=torch.int32, device=self.device)
         torch.cuda.synchronize(self.device)
         dist.barrier(group=group)   # every rank has mapped every buffer before the first push
+        self.disabled_reason = None
+        self._self_test()
+
+    def _self_test(self):
+        """First-lease hardening: before the one-shot path is trusted, every rank pushes a known vector through it once and all
+        ranks compare notes.  Peer access that maps but does not deliver (no xGMI / PCIe peer-to-peer between two devices, a
+        container without IPC rights that slipped through the import) shows up here as a timeout or a wrong sum; the verdict is
+        taken COLLECTIVELY (all_gather_object), so either every rank uses the kernel or every rank uses `dist.all_reduce`, and the
+        reason is printed once."""
+        if self.world == 1:
+            return
+        ok, why = True, ""
+        try:
+            # (peers live in other processes, so hipDeviceCanAccessPeer ordinals are not comparable here: the ping IS the test)
+            probe = torch.full((64,), float(self.rank + 1), device=self.device, dtype=torch.float16)
+            with torch.cuda.device(self.device):
+                rc = self._lib.qllm_allreduce_oneshot(self._table.data_ptr(), self.rank, self.world, probe.data_ptr(), probe.numel(),
+                                                      _lib.DT_F16, self.slot_bytes, self._status.data_ptr(),
+                                                      torch.cuda.current_stream().cuda_stream)
+            _lib.check(rc)
+            torch.cuda.synchronize(self.device)
+            want = self.world * (self.world + 1) / 2
+            if int(self._status.item()) != 0:
+                ok, why = False, "a peer's flag never arrived (timeout)"
+                self._status.zero_()
+            elif not bool((probe == want).all()):
+                ok, why = False, f"ping summed to {float(probe[0])} instead of {want}"
+        except Exception as e:  # noqa: BLE001
+            ok, why = False, f"{type(e).__name__}: {e}"
+        verdicts = [None] * self.world
+        dist.all_gather_object(verdicts, (ok, why), group=self.group)
+        bad = [(r, w) for r, (o, w) in enumerate(verdicts) if not o]
+        if bad:
+            self.disabled_reason = "; ".join(f"rank {r}: {w}" for r, w in bad)
+            if self.rank == 0:
+                print(f"[qllm_amd.comm] one-shot all-reduce disabled, sums go through dist.all_reduce ({dist.get_backend(self.group)}): "
+                      f"{self.disabled_reason}", flush=True)
 
     def supports(self, t: torch.Tensor) -> bool:
         """Whether `t` travels through the one-shot kernel.  Decided ONLY from properties every rank of a collective call shares
         (dtype, element count against the slot size): a rank-local property -- alignment, contiguity -- must never pick the path,
         or one rank would spin in the kernel while its peer sits in dist.all_reduce."""
-        return (t.is_cuda and t.device == self.device and t.dtype in (torch.float16, torch.bfloat16)
+        return (self.disabled_reason is None and t.is_cuda and t.device == self.device and t.dtype in (torch.float16, torch.bfloat16)
                 and t.numel() % 8 == 0 and 0 < t.numel() * 2 <= self.slot_bytes)
 
     def all_reduce(self, t: torch.Tensor) -> torch.Tensor:
@@ -86,7 +123,8 @@ class OneShotAllReduce:
         (qllm_linear_forward_allreduce: the batch-1 kernel's blocks push their partial outputs into every peer's slot, the rank's
         last block sums).  Bit-identical to `ops.linear_forward` + `all_reduce`.  False = not served (the decision depends only on
         shapes, dtypes and the layer's layout, which every rank of a tensor-parallel layer shares): run the two steps instead."""
-        if self.world == 1 or x2d.shape[0] != 1 or x2d.dtype not in (torch.float16, torch.bfloat16) or out.dtype != x2d.dtype:
+        if (self.world == 1 or self.disabled_reason is not None or x2d.shape[0] != 1 or x2d.dtype not in (torch.float16, torch.bfloat16)
+                or out.dtype != x2d.dtype):
             return False
         if w.N * 2 > self.slot_bytes or w.N % 16 or out.data_ptr() % 16 or x2d.data_ptr() % 16:
             return False

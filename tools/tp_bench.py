@@ -206,6 +206,8 @@ def run(args, world, rank, dev, info):
             from qllm_amd.comm import OneShotAllReduce
             reducer = OneShotAllReduce(max_bytes=M_MAX_ONESHOT * H70 * 2)
             reducer_mode = "one-shot peer-write kernel (HIP IPC staging buffers)"
+            if reducer.disabled_reason is not None:   # (its collective self-test failed: every rank falls back together)
+                reducer_mode = f"dist.all_reduce (one-shot self-test failed: {reducer.disabled_reason})"
         except Exception as e:  # noqa: BLE001  (e.g. IPC not permitted in this container): RCCL serves the sums
             reducer_mode = f"dist.all_reduce (one-shot unavailable: {type(e).__name__}: {e})"
     if rank == 0:
