@@ -52,11 +52,13 @@ __global__ __launch_bounds__(WM * 256) void gemm5_kernel(const GemmParams p) {
   constexpr int NP = 32 / NWV;         // activation DMA pieces per wave and k-tile: 8 or 4
   constexpr int PPS = NP / 4;          // ... per sub-step: 2 or 1
   constexpr bool NO_DMA = ABL & 1, NO_DQ = ABL & 2, NO_READ = ABL & 4, NO_LOAD = ABL & 8;
-  constexpr int VM_TILE = (NO_DMA ? 0 : NP) + (NO_LOAD ? 0 : 6);      // vector-memory operations a wave issues per k-tile
+  // per k-tile a wave issues NP activation pieces, ONE 1 KB piece of packed words (its 32 columns x 8 word rows: v3 -- four 4-byte
+  // loads per lane cost the wave more than a DMA piece, r05_prefill_lab.md) and the scale / zero words
+  constexpr int VM_TILE = (NO_DMA ? 0 : NP) + (NO_LOAD ? 0 : 3);      // vector-memory operations a wave issues per k-tile
   // at barrier #t the operations of tile t + 1 (requested during tile t - 2: THREE tiles ahead -- two left the last requests of a
   // batch 3 sub-steps of flight, less than an HBM round trip: 68.6 -> 52 us with the word loads ablated, profiles/r05_prefill_lab.md)
   // are older than tile t - 1's whole batch and the requests of this tile's sub-steps 0..2
-  constexpr int VM_WAIT = 2 * VM_TILE - ((NO_DMA ? 0 : PPS) + (NO_LOAD ? 0 : 2));
+  constexpr int VM_WAIT = 2 * VM_TILE - ((NO_DMA ? 0 : PPS) + (NO_LOAD ? 0 : 1));
   extern __shared__ __attribute__((aligned(16))) half_t smem[];
   half_t *As = smem;  // [4][256][64]  (LDS-DMA ring: FOUR slots, so that the slot of every fragment read is a compile-time constant
                       //  in a loop unrolled four k-tiles deep -- two register sets x ... -- and folds into the ds_read's offset field)
@@ -93,11 +95,15 @@ __global__ __launch_bounds__(WM * 256) void gemm5_kernel(const GemmParams p) {
   const auto rs_w = __builtin_amdgcn_make_buffer_rsrc((void *)p.qweight, 0, (int)((size_t)p.K * p.N / 2), 0x00020000);
   const auto rs_s = __builtin_amdgcn_make_buffer_rsrc((void *)p.scales, 0, Gn * p.N * 2, 0x00020000);
   const auto rs_z = __builtin_amdgcn_make_buffer_rsrc((void *)zbase, 0, (sm ? (p.N >> 4) * Gn * zmul : Gn * zmul_all) * 4, 0x00020000);
-  const int wrow_bytes = sm ? 64 : p.N * 4;  // bytes per packed word row (strip-major: the strip's 16 words)
-  const int ktile_bytes = 8 * wrow_bytes;    // 8 word rows per k-tile
-  int voff_w[4];                             // word row 8 kt + 2 ks + fs of column nB
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) voff_w[ks] = (2 * ks + fs) * wrow_bytes + (sm ? (nB >> 4) * (p.K >> 3) * 64 + ncs * 4 : nB * 4);
+  // packed words of a k-tile for this wave: 8 word rows x its 32 columns = 1 KB, ONE LDS-DMA piece into the image [row][32 columns]
+  // (lane l carries row l / 8, columns 4 (l % 8) .. + 3: 16 contiguous bytes in the row-stream layouts and -- inside a 16-column
+  // strip -- in the strip-major one), four slots per wave behind the activation ring; the lane's word of sub-step ks is
+  // image[2 ks + fs][fr]: read with ds_read_b32 at the k-tile barrier
+  const int nW0 = n0 + wn * 32 + 4 * (lane & 7);                      // first of the lane's four columns
+  const int voff_wd = sm ? (nW0 >> 4) * (p.K >> 3) * 64 + (lane >> 3) * 64 + (nW0 & 15) * 4 : (lane >> 3) * p.N * 4 + nW0 * 4;
+  const int ktile_bytes = sm ? 512 : 8 * p.N * 4;                     // advance of a k-tile (strip-major: 8 rows x 64 B of the strip)
+  uint32_t *Wl = (uint32_t *)(smem + 4 * kATile) + wave * 1024;       // this wave's four 1 KB slots
+  const int w_rd = fs * 32 + fr;                                      // word of sub-step 0 in a slot (sub-step ks: + 64 ks)
   const int srow_bytes = sm ? 32 : p.N * 2;
   const int voff_s = sm ? (nB >> 4) * Gn * 32 + ncs * 2 : nB * 2, voff_z = zoff * 4;
   const uint32_t mask_lo = nib_mask_vgpr(), mask_hi = mask_lo << 4;
@@ -106,8 +112,15 @@ __global__ __launch_bounds__(WM * 256) void gemm5_kernel(const GemmParams p) {
     uint32_t sraw, z;
   };
   BSet bset[4];
-  auto load_word = [&](int kt, BSet &bs, int ks) {
-    if constexpr (!NO_LOAD) bs.w[ks] = __builtin_amdgcn_raw_buffer_load_b32(rs_w, voff_w[ks], kt * ktile_bytes, 0);
+  auto dma_words = [&](int kt, int slot) {
+    lds_void_t *dst = (lds_void_t *)(Wl + slot * 256);
+    if constexpr (!NO_LOAD) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, dst, 16, voff_wd, kt * ktile_bytes, 0, 0);
+  };
+  auto read_words = [&](int slot, BSet &bs) {
+    if constexpr (!NO_LOAD) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) bs.w[ks] = Wl[slot * 256 + w_rd + 64 * ks];
+    }
   };
   auto load_scale = [&](int kt, BSet &bs) {
     if constexpr (!NO_LOAD) bs.sraw = __builtin_amdgcn_raw_buffer_load_b16(rs_s, voff_s, ((kt * BK) >> p.gs_shift) * srow_bytes, 0);
@@ -191,27 +204,25 @@ __global__ __launch_bounds__(WM * 256) void gemm5_kernel(const GemmParams p) {
   __builtin_amdgcn_s_setprio(1);
 #pragma unroll
   for (int q = 0; q < NP; ++q) dma_piece(0, 0, q);
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) load_word(0, bset[0], ks);
+  dma_words(0, 0);
   load_scale(0, bset[0]);
   load_zero(0, bset[0]);
   G5_SB();  // (the batches stay in this order: hipcc's own vmcnt for a register is the minimum over the paths into the loop)
 #pragma unroll
   for (int q = 0; q < NP; ++q) dma_piece(1, 1, q);
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) load_word(1, bset[1], ks);
+  dma_words(1, 1);
   load_scale(1, bset[1]);
   load_zero(1, bset[1]);
   G5_SB();
 #pragma unroll
   for (int q = 0; q < NP; ++q) dma_piece(2, 2, q);
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) load_word(2, bset[2], ks);
+  dma_words(2, 2);
   load_scale(2, bset[2]);
   load_zero(2, bset[2]);
   G5_SB();
   g5_wait_vm<2 * VM_TILE>();  // tile 0's operations have completed (tiles 1, 2 in flight)
   __builtin_amdgcn_s_barrier();
+  read_words(0, bset[0]);
   if constexpr (NO_LOAD) {
     bset[0] = BSet{{0x12345678u, 0x9abcdef0u, 0x0fedcba9u, 0x87654321u}, 0x2000u, 0x77777777u};
     bset[1] = bset[0]; bset[2] = bset[0]; bset[3] = bset[0];
@@ -240,7 +251,7 @@ __global__ __launch_bounds__(WM * 256) void gemm5_kernel(const GemmParams p) {
       else { dq_step(2 * a, wn_, ccn_, fb_n); dq_step(2 * a + 1, wn_, ccn_, fb_n); }                                                    \
       if (a == AM / 8) dma_piece((kt_) + 3, SLOT_REQ, PPS * (KS_));                                                                     \
       if (PPS == 2 && a == 5) dma_piece((kt_) + 3, SLOT_REQ, PPS * (KS_) + 1);                                                          \
-      if (a == AM / 2 - 1) load_word((kt_) + 3, set_, KS_);                                                                             \
+      if (a == AM / 2 - 1 && (KS_) == 0) dma_words((kt_) + 3, SLOT_REQ);                                                                \
       if (a == AM - 1 && (KS_) == 2) load_scale((kt_) + 3, set_);                                                                       \
       if (a == AM - 1 && (KS_) == 3) load_zero((kt_) + 3, set_);                                                                        \
       G5_SB();                                                                                                                          \
@@ -258,6 +269,7 @@ __global__ __launch_bounds__(WM * 256) void gemm5_kernel(const GemmParams p) {
     g5_wait_vm_lgkm<VM_WAIT>();                                                                                                         \
     __builtin_amdgcn_s_barrier();                                                                                                       \
     G5_SB();                                                                                                                            \
+    read_words(SA1, NXT);                                                                                                               \
     ccn = col_const(NXT);                                                                                                               \
     G5_SB();                                                                                                                            \
     G5_SUBSTEP(fa1, fb1, fa0, fb0, SA1, 0, NXT.w[0], ccn, kt_, REQ, 3, SA3)                                                             \
@@ -317,7 +329,7 @@ static int launch_gemm5_t(const GemmParams &p, hipStream_t stream) {
   static DeviceLatch attr_done;
   if (int rc = lds_optin(attr_done, (const void *)gemm5_kernel<WM, ABL>)) return rc;
   const int tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
-  const size_t lds = (size_t)(4 * kATile) * sizeof(half_t);  // 128 KB
+  const size_t lds = (size_t)(4 * kATile) * sizeof(half_t) + (size_t)WM * 4 * 4096;  // 128 KB + the waves' packed-word slots
   hipLaunchKernelGGL((gemm5_kernel<WM, ABL>), dim3(tiles), dim3(WM * 256), lds, stream, p);
   QLLM_HIP_CHECK(hipGetLastError());
   return QLLM_OK;
