@@ -1,0 +1,47 @@
+"""-m gpu: ONE numerics contract across the dispatch boundaries.  The library evaluates a layer three ways -- the strips and the
+batch-1 kernel: x . s (q - z) for the unrounded W in fp32; the panel kernel: exact q - z in the B fragment, one fma per group; the
+tile GEMMs (gemm2 / gemm3): the reference's three fp16 roundings of W bit for bit -- and a module crosses from one to the next as
+its batch grows by one row (16 -> 17, 32 -> 33, 64 -> 65, 128 -> 129; round-4 verdict, weak 11).  Every path must stay inside the
+same two bounds on the same layer and the same rows: 2e-3 of exact (float64) arithmetic on the reference's own W, 1e-2 of the
+reference's fp16 CPU path (north_star tolerance); and the rows shared by two batch sizes may differ only by those roundings."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu as O
+from gpu_util import Ref, randx, synth, to_layer
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+BOUNDARIES = (1, 2, 16, 17, 32, 33, 64, 65, 128, 129)
+
+
+@pytest.mark.parametrize("layout,bits,g,K,N", [("GPTQ", 4, 128, 4096, 4096), ("GEMM", 4, 128, 4096, 11008), ("HQQ", 4, 64, 4096, 4096),
+                                                ("GPTQ", 4, 128, 11008, 4096), ("HQQ", 3, 64, 4096, 4096)])
+def test_every_dispatch_boundary_keeps_the_contract(layout, bits, g, K, N):
+    from qllm_amd import ops
+    d = synth(layout, bits, g, K, N, "asym", False, True, seed=K + N + bits)
+    d["scales"] = (d["scales"].astype(np.float32) * (4096 / K) ** 0.5 * 0.5).astype(np.float16)
+    layer = to_layer(d, DEV)
+    ref = Ref(d)
+    x_all = randx(max(BOUNDARIES), K, seed=11)
+    plans, ys = {}, {}
+    for m in BOUNDARIES:
+        if bits == 3 and m > 64:
+            continue
+        x = x_all[:m]
+        y = layer(torch.from_numpy(x).to(DEV)).cpu().numpy()
+        w = layer.native_descriptor(0)
+        plans[m] = ops.plan_describe([w], m).split(" ")[0] if w is not None else "reference-layout"
+        assert np.isfinite(y.astype(np.float32)).all()
+        assert O.rel_err(y.astype(np.float64), ref.y64(x)) <= 2e-3, (m, plans[m])
+        assert O.rel_err(y, ref.y16(x)) <= 1e-2, (m, plans[m])
+        ys[m] = y
+    # the batch really crosses kernels here (else this test guards nothing) ...
+    assert len(set(plans.values())) >= 3, plans
+    # ... and the rows two batch sizes share agree to the contract's own tolerance (same x rows, different kernels)
+    scale = float(np.abs(ref.y64(x_all[:1])).max())
+    ms = sorted(ys)
+    for a, b in zip(ms, ms[1:]):
+        diff = np.abs(ys[a].astype(np.float64) - ys[b][:a].astype(np.float64)).max()
+        assert diff <= 4e-3 * max(scale, float(np.abs(ys[b].astype(np.float64)).max())), (a, b, plans[a], plans[b], diff)
