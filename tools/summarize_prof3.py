@@ -8,7 +8,10 @@ import csv
 import glob
 import json
 import os
+import re
 import sys
+
+DECODE_RE = re.compile(r"qllm::strip\d?_kernel")  # strip_kernel and the M = 1 strip1_kernel
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src = sys.argv[2] if len(sys.argv) > 2 else f"gpurun_out/prof_{tag}"
@@ -38,7 +41,7 @@ with open(f"{out}/{tag}_bench_kernel_stats.csv", "w", newline="") as f:
             w.writerow(r)
 
 # dispatches of the decode kernel in issue order: every step is 32 x (q/k/v, o, gate/up, down)
-tr = [r for r in csv.DictReader(open(glob.glob(f"{src}/trace/*kernel_trace.csv")[0])) if "qllm::strip_kernel" in r["Kernel_Name"]]
+tr = [r for r in csv.DictReader(open(glob.glob(f"{src}/trace/*kernel_trace.csv")[0])) if DECODE_RE.search(r["Kernel_Name"])]
 tr.sort(key=lambda r: int(r["Start_Timestamp"]))
 per_role = collections.defaultdict(list)
 inst = {}
@@ -51,7 +54,7 @@ for kind in ("fetch", "write"):
     fs = glob.glob(f"{src}/pmc_{kind}/*counter_collection.csv")
     if not fs:
         continue
-    rs = [r for r in csv.DictReader(open(fs[0])) if "qllm::strip_kernel" in r["Kernel_Name"]]
+    rs = [r for r in csv.DictReader(open(fs[0])) if DECODE_RE.search(r["Kernel_Name"])]
     rs.sort(key=lambda r: int(r["Dispatch_Id"]))
     agg = collections.defaultdict(lambda: [0, 0.0])
     for i, r in enumerate(rs):
@@ -101,8 +104,10 @@ for role in range(4):
         per_launch[name.split(" ")[0]] = int(traffic)
 L += ["", f"Sum of the four medians: {tot_med:.2f} us per decoder layer = {32 * tot_med / 1e3:.3f} ms per token if nothing overlapped; "
       f"algorithmic bytes per layer {tot_alg / 1e6:.1f} MB.",
-      "Template arguments of `strip_kernel`: <waves per block, strips (columns) per lane, k-steps per round, k-steps per group, staged x "
-      "chunks per lane, bits, register-A, bf16, row tiles, strip-major layout, timeline diagnostics, one-round fold>.",
+      "Template arguments of `strip1_kernel` (csrc/strip1_kernel.hpp, the M = 1 4-bit g128 decode kernel): <waves per block, k-steps "
+      "per wave, exact-fit K (no tail predicate), staged x chunks per lane, ablation level (4 = full), timeline diagnostics, fused "
+      "all-reduce epilogue>; of `strip_kernel`: <waves per block, strips (columns) per lane, k-steps per round, k-steps per group, "
+      "staged x chunks per lane, bits, register-A, bf16, row tiles, strip-major layout, timeline diagnostics, one-round fold>.",
       "FETCH_SIZE on gfx950 counts 64 B per 128-B request for wide coalesced reads (MI355X_MICROARCH.md, HBM section): doubled; unit KB."]
 notes = f"{out}/{tag}_bench_notes.md"
 if os.path.exists(notes):  # hand-written remarks kept next to the generated table
@@ -117,8 +122,6 @@ if tot_traffic:
 # ---- BASELINE configs[3]: HQQ g64, batch 16 ---------------------------------------------------------------------------------
 ht = glob.glob(f"{src}/hqq_trace/*kernel_trace.csv")
 if ht:
-    import re
-
     def hqq_alg(K, N, bits, M=16, g=64):  # packed words + fp16 scales + fp16 zero points + x + y
         return K * N * bits // 8 + 2 * (K // g) * N * 2 + 2 * M * K + 2 * M * N
     def bits_of(name):  # strip_kernel<NW, CPL, MAXS, SPG, XL, BITS, ...> / strip_dma_kernel<NW, CPL, SPG, BITS, BF16, MT>
@@ -127,10 +130,12 @@ if ht:
             return int(m.group(1).split(",")[3])
         if "panel_kernel<" in name:  # csrc/panel.hip: 4 bits only
             return 4
+        if "strip1_kernel<" in name:  # csrc/strip1_kernel.hpp: 4 bits only
+            return 4
         m = re.search(r"strip_kernel<([^>]*)>", name)
         return int(m.group(1).split(",")[5]) if m else 0
     def ours(name):
-        return "qllm::strip_kernel" in name or "qllm::strip_dma_kernel" in name or "panel_kernel<" in name
+        return bool(DECODE_RE.search(name)) or "qllm::strip_dma_kernel" in name or "panel_kernel<" in name
     names = ["q/k/v (one grouped launch)", "o_proj", "gate/up (one grouped launch)", "down_proj"]
     shapes = [(H, 3 * H), (H, H), (H, 2 * I), (I, H)]
     tr = [r for r in csv.DictReader(open(ht[0])) if ours(r["Kernel_Name"])]

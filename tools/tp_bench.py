@@ -317,7 +317,7 @@ def run(args, world, rank, dev, info):
                        "row_parallel_all_reduce_fused_into_gemv": fused, "ranks_seen": dist.get_world_size() if world > 1 else 1,
                        "graph": graph_mode, "parallelism": f"tp{P}" + ("" if world > 1 else " (1 rank, no collective)"),
                        "device": info["arch"]},
-            "roofline": {"bound": "hbm", "kernel": "qllm::strip_kernel", "achieved": round(nbytes / ms_per_step / 1e6, 1),
+            "roofline": {"bound": "hbm", "kernel": "qllm::strip1_kernel", "achieved": round(nbytes / ms_per_step / 1e6, 1),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s (per rank)", "frac": round(nbytes / ms_per_step / 1e6 / HBM_PEAK_GBPS, 4),
                          "traffic": None},
             "all_reduce_us_16KB": None if ar_us is None else round(ar_us, 2),

@@ -5,12 +5,13 @@ Usage: python tools/trace_overlap.py <dir-with-*kernel_trace.csv> [n_last_dispat
 import collections
 import csv
 import glob
+import re
 import sys
 
 src = sys.argv[1]
 last = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 f = glob.glob(f"{src}/**/*kernel_trace.csv", recursive=True)[0]
-rows = [r for r in csv.DictReader(open(f)) if "qllm::strip_kernel" in r["Kernel_Name"]]
+rows = [r for r in csv.DictReader(open(f)) if re.search(r"qllm::strip\d?_kernel", r["Kernel_Name"])]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 rows = rows[-last:]
 t0 = int(rows[0]["Start_Timestamp"])
@@ -19,7 +20,7 @@ ov_tot = span = 0
 print("  start_us    dur_us  overlap_with_prev_us  gap_us  queue/stream  grid  kernel")
 for i, r in enumerate(rows):
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
-    name = r["Kernel_Name"].split("strip_kernel")[1].split("(")[0][:44]
+    name = re.split(r"strip\d?_kernel", r["Kernel_Name"])[1].split("(")[0][:44]
     ov = gap = 0.0
     if prev is not None:
         ov = max(0, min(prev[1], e) - s) / 1e3
@@ -32,7 +33,7 @@ for i, r in enumerate(rows):
 span = (max(int(r["End_Timestamp"]) for r in rows) - t0) / 1e3
 dur = collections.defaultdict(list)
 for r in rows:
-    dur[(r["Kernel_Name"].split("strip_kernel")[1].split("(")[0][:44], r.get("Grid_Size_X", r.get("Grid_Size", "?")))].append(
+    dur[(re.split(r"strip\d?_kernel", r["Kernel_Name"])[1].split("(")[0][:44], r.get("Grid_Size_X", r.get("Grid_Size", "?")))].append(
         (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 print(f"\n{len(rows)} dispatches over {span:.1f} us: sum of durations {sum(sum(v) for v in dur.values()):.1f} us, "
       f"pairwise overlap {ov_tot:.1f} us")
