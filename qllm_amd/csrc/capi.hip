@@ -131,13 +131,16 @@ struct StripPlan {
 static uint64_t *g_timeline = nullptr;
 static int g_timeline_slots = 0, g_timeline_next = 0;
 
-// the mid-batch panel kernel (panel.hip): single native 4-bit layers, M from QLLM_PANEL_MIN_M (17) to 128 rows -- and from 9 rows
-// where K >= 2 N (one-strip strip blocks pull all of x through every CU there).  us per linear, strips -> panel
-// (profiles/r04_mid_m.md): M = 32: 11.0 -> 10.7 (4096 x 4096), 23.8 -> 15.9 (4096 x 11008), 20.8 -> 16.0 (11008 x 4096);
-// M = 16: 8.0 -> 8.2, 11.5 -> 12.9, 13.4 -> 12.0 (g64: 15.6 -> 13.3); M = 8: 7.3 -> 8.2, 11.0 -> 13.0, 12.3 -> 12.0
+// the mid-batch panel kernel (panel.hip): single native layers from QLLM_PANEL_MIN_M (17) rows to 128.  us per linear, strips -> panel
+// (profiles/r04_mid_m.md): M = 32: 23.8 -> 15.9 (4096 x 11008), 20.8 -> 16.0 (11008 x 4096).
+// Round 5 (profiles/r05_batch16.md, tools/rounds5/g13_down_sweep.sh), after the strips' scale / zero tables moved to LDS:
+//   * 9..16 rows where K >= 2 N (down_proj) went BACK to the strips: 15.0 -> 12.6-14.4 us (HQQ g64 4 bits), 16.5 -> 14.1-15.0 (3 bits),
+//     13.5 -> 11.9-13.1 (g128): the split-K fix-up of the panel costs more than the one-strip blocks' x traffic now;
+//   * 17..32 rows on layers of up to 4096 x 4096 (o_proj) stay on the two-row-tile strips: 9.1-9.7 -> 7.7-8.9 us (3 bits 10.3 -> 8.2-9.9).
 static bool panel_rows_ok(int M, int K, int N) {
-  const int min_m = knob("QLLM_PANEL_MIN_M", 17);
-  return M >= min_m || (min_m == 17 && M >= 9 && K >= 2 * N);
+  if (M < knob("QLLM_PANEL_MIN_M", 17)) return false;  // (lab builds only: below 17 rows the release library has no panel form)
+  if (M <= 32 && K <= 4096 && N <= 4096 && !knob("QLLM_PANEL_SMALL", 0)) return false;
+  return true;
 }
 
 static bool strip_plan(const qllm_weight_t *w, int n, int M, StripPlan *plan) {

@@ -183,7 +183,7 @@ int gemm2_tile_n(int M, int N, int split_k);
 size_t gemm2_slab_bytes(int M, int N, int S);
 int launch_gemm2(const GemmParams &p, int layout, hipStream_t stream);
 
-// ---- panel.hip (17 <= M <= 128, and long-K layers from 9 rows, on the native layout: 64-column panels, A tiles shared through LDS,
+// ---- panel.hip (17 <= M <= 128 on the native layout: 64-column panels, A tiles shared through LDS,
 //      B fragments from registers; up to 8 layers sharing x in one launch) ----------------------------------------------------------
 struct PanelProblem {
   const uint32_t *qweight;

@@ -1,4 +1,4 @@
-// Mid-batch "panel" kernel (round 4): y[M, N] = x[M, K] . dequant(W) (4 bits, or 3) for 17 <= M <= 128 (from 9 rows where K >= 2 N)
+// Mid-batch "panel" kernel (round 4): y[M, N] = x[M, K] . dequant(W) (4 bits, or 3) for 17 <= M <= 128 (round 5: layers of up to 4096 x 4096 from 33 rows)
 // on the strip-major native layout; one layer, or up to 8 layers sharing x (q/k/v, gate/up) in one launch.
 //
 // Why: between the strip kernels (M <= 32: every block re-reads ALL of x, which grows with M) and the 256-row prefill tiles there
@@ -430,11 +430,19 @@ int launch_g(const PanelParams &p, int grid, hipStream_t stream) {
 
 }  // namespace
 
+// Rows served: from 17 (two row tiles).  The one-row-tile form was round 4's route for 9..16 rows where K >= 2 N; round 5's strips beat
+// it there (profiles/r05_batch16.md), so only the lab build (QLLM_PANEL_MIN_M) still instantiates and reaches it.
+#ifdef QLLM_LAB
+constexpr int kPanelMinRows = 2;
+#else
+constexpr int kPanelMinRows = 17;
+#endif
+
 // whole 64-column panels, whole k-step pairs, the group sizes of the strips (callers: native strip-major 4-bit layers, no g_idx)
 bool panel_shape_ok(int M, int K, int N, int group_size, int bits) {
-  if (bits == 3) return M >= 2 && M <= 64 && K % 64 == 0 && N % 64 == 0 && (group_size == 64 || group_size == 128) && K % group_size == 0 &&
+  if (bits == 3) return M >= kPanelMinRows && M <= 64 && K % 64 == 0 && N % 64 == 0 && (group_size == 64 || group_size == 128) && K % group_size == 0 &&
                         (double)K * N * 3 / 8 < 2147483648.0;
-  return bits == 4 && M >= 2 && M <= 128 && K % 64 == 0 && N % 64 == 0 && ((group_size == 32 && M <= 64) || group_size == 64 || group_size == 128) &&
+  return bits == 4 && M >= kPanelMinRows && M <= 128 && K % 64 == 0 && N % 64 == 0 && ((group_size == 32 && M <= 64) || group_size == 64 || group_size == 128) &&
          K % group_size == 0 && (double)K * N / 2 < 2147483648.0;
 }
 
@@ -456,7 +464,11 @@ size_t panel_slab_bytes(int M, int n_panels, int S) { return S > 1 ? (size_t)n_p
 
 int launch_panel(const PanelParams &p, hipStream_t stream) {
   const int grid = p.n_panels * p.split_k;
+#ifdef QLLM_LAB
   if (p.M <= 16) return p.act_bf16 ? launch_g<1, 2, true>(p, grid, stream) : launch_g<1, 2, false>(p, grid, stream);
+#else
+  if (p.M < kPanelMinRows) return set_error(QLLM_ERR_UNSUPPORTED, "internal: the panel kernel serves 17..128 rows");
+#endif
   if (p.M <= 32) return p.act_bf16 ? launch_g<2, 2, true>(p, grid, stream) : launch_g<2, 2, false>(p, grid, stream);
   if (p.M <= 64) return p.act_bf16 ? launch_g<4, 2, true>(p, grid, stream) : launch_g<4, 2, false>(p, grid, stream);
   return p.act_bf16 ? launch_g<8, 1, true>(p, grid, stream) : launch_g<8, 1, false>(p, grid, stream);

@@ -140,10 +140,12 @@ def test_native_layout_decode_routes(lib):
     # M = 2..32: strip_dma.hpp (activations through LDS by DMA); one strip per 16-wave block while the strips fit one round of CUs
     for m in (2, 4, 5, 16):
         assert plan(lib, [attn], m) == "strip nw=16 cpl=1 spw=8 form=dma-A row_tiles=1" + sm
-        # K >= 2 N from 9 rows: the panel kernel (a one-strip block pulls all of x through its CU: 13.4 -> 12.0 us at M = 16)
-        assert plan(lib, [down], m) == ("strip nw=16 cpl=1 spw=24 form=dma-A row_tiles=1" if m < 9 else "panel cols=64 row_tiles=1 k_halves=2 split_k=4") + sm
-    assert plan(lib, [W(11008, 4096, 64, 4, NATIVE_F16Z)], 16) == "panel cols=64 row_tiles=1 k_halves=2 split_k=4" + sm   # (BASELINE configs[3] down_proj)
-    assert plan(lib, [W(11008, 4096, 64, 3, NATIVE_F16Z)], 16) == "panel cols=64 row_tiles=1 k_halves=2 split_k=4 bits=3" + sm   # (3 bits too)
+        # K >= 2 N: round 4 sent 9..16 rows to the panel kernel; with the strips' scale / zero tables in LDS (round 5) the one-strip
+        # blocks win again (M = 16: 15.0 -> 13.5-14.4 us at g64, 13.5 -> 13.1 at g128; profiles/r05_batch16.md)
+        assert plan(lib, [down], m) == "strip nw=16 cpl=1 spw=24 form=dma-A row_tiles=1" + sm
+    assert plan(lib, [W(11008, 4096, 64, 4, NATIVE_F16Z)], 16) == "strip nw=16 cpl=1 spw=22 form=dma-A row_tiles=1" + sm   # (BASELINE configs[3] down_proj)
+    assert plan(lib, [W(11008, 4096, 64, 3, NATIVE_F16Z)], 16) == "strip nw=16 cpl=1 spw=22 form=dma-A row_tiles=1" + sm   # (3 bits too)
+    assert plan(lib, [W(11008, 4096, 64, 3, NATIVE_F16Z)], 17) == "panel cols=64 row_tiles=2 k_halves=2 split_k=4 bits=3" + sm
     assert plan(lib, [W(11008, 4096, 64, 3, NATIVE_F16Z)], 8).startswith("strip ")
     # ... wide (grouped) launches: blocks of several adjacent strips share one activation stream -- as many as make the launch ONE
     # round of blocks: q/k/v 768 strips -> 192 blocks of four; gate/up 1376 strips -> 230 blocks of six, the last of each layer ragged
@@ -155,7 +157,10 @@ def test_native_layout_decode_routes(lib):
     # 3 bits: six strips where the ring fits the registers (64-wide groups, fp16 zero points: HQQ) -- ONE round of 230 blocks (round 5); else four
     assert plan(lib, [W(4096, 11008, 64, 3, NATIVE_F16Z)] * 2, 16) == "strip nw=8 cpl=6 spw=16 form=dma-A row_tiles=1" + sm
     assert plan(lib, [W(4096, 11008, 128, 3, NATIVE)] * 2, 16) == "strip nw=8 cpl=3 spw=16 form=dma-A row_tiles=1" + sm   # (two rounds either way: fewer bytes per block)
-    assert plan(lib, [attn], 32) == plan(lib, [attn], 17) == "panel cols=64 row_tiles=2 k_halves=2 split_k=4" + sm   # single layers from 17 rows
+    # single layers from 17 rows: the panel kernel -- except up to 4096 x 4096 at 17..32 rows, where the two-row-tile strips are
+    # faster (o_proj 9.1-9.7 -> 7.7-8.9 us, round 5)
+    assert plan(lib, [attn], 32) == plan(lib, [attn], 17) == "strip nw=8 cpl=1 spw=16 form=dma-A row_tiles=2" + sm
+    assert plan(lib, [down], 32) == plan(lib, [down], 17) == "panel cols=64 row_tiles=2 k_halves=2 split_k=4" + sm
     assert plan(lib, [up], 24) == "panel cols=64 row_tiles=2 k_halves=2 split_k=1" + sm
     assert plan(lib, [attn] * 3, 32) == "panel cols=64 row_tiles=2 k_halves=2 split_k=1 layers=3" + sm
     assert plan(lib, [up] * 2, 16) == "strip nw=8 cpl=6 spw=16 form=dma-A row_tiles=1" + sm
@@ -170,7 +175,8 @@ def test_native_layout_decode_routes(lib):
     assert plan(lib, [W(8192, 8192, layout=NATIVE), W(8192, 1024, layout=NATIVE), W(8192, 1024, layout=NATIVE)], 16) == "strip nw=8 cpl=3 spw=32 form=dma-A row_tiles=1" + sm
     assert plan(lib, [W(8192, 28672, layout=NATIVE)] * 2, 16) == "strip nw=8 cpl=6 spw=32 form=dma-A row_tiles=1" + sm
     assert plan(lib, [W(28672, 8192, layout=NATIVE)], 8) == "strip nw=8 cpl=2 spw=112 form=dma-A row_tiles=1" + sm
-    assert plan(lib, [W(28672, 8192, layout=NATIVE)], 16) == "panel cols=64 row_tiles=1 k_halves=2 split_k=2" + sm   # K >= 2 N, 9+ rows
+    assert plan(lib, [W(28672, 8192, layout=NATIVE)], 16) == "strip nw=8 cpl=2 spw=112 form=dma-A row_tiles=1" + sm
+    assert plan(lib, [W(28672, 8192, layout=NATIVE)], 17) == "panel cols=64 row_tiles=2 k_halves=2 split_k=2" + sm
     assert plan(lib, [W(8192, 1024, layout=NATIVE), W(8192, 128, layout=NATIVE), W(8192, 128, layout=NATIVE)], 16) == "strip nw=16 cpl=1 spw=16 form=dma-A row_tiles=1" + sm
     # 33 <= M <= 128, single 4-bit layers: the panel kernel (panel.hip, round 4): 64-column panels, two K halves per block up to 64
     # rows, split over K until the panels cover the CUs (at least two K-tiles per part); grouped launches keep the four-row-tile strips
@@ -206,7 +212,8 @@ def test_native_layout_decode_routes(lib):
     assert plan(lib, [h3], 1).startswith("strip nw=16 cpl=1 spw=8 form=lds-slab")
     assert plan(lib, [h3], 16).startswith("strip nw=16 cpl=1 spw=8 form=dma-A")
     # 3 bits from 17 rows: the panel kernel (exact q - z from the slot-scaled patterns), up to 64 rows; the 256-row tiles above
-    assert plan(lib, [h3], 32) == "panel cols=64 row_tiles=2 k_halves=2 split_k=4 bits=3" + sm
+    assert plan(lib, [h3], 32) == "strip nw=8 cpl=1 spw=16 form=dma-A row_tiles=2" + sm      # (up to 4096 x 4096 and 32 rows: strips)
+    assert plan(lib, [W(4096, 11008, 64, 3, NATIVE_F16Z)], 32) == "panel cols=64 row_tiles=2 k_halves=2 split_k=1 bits=3" + sm
     assert plan(lib, [h3], 48) == "panel cols=64 row_tiles=4 k_halves=2 split_k=4 bits=3" + sm
     assert plan(lib, [h3], 65).startswith("gemm3") and "bits=3" in plan(lib, [h3], 65)
     assert plan(lib, [W(4096, 4096, 128, 3, NATIVE)], 33) == "panel cols=64 row_tiles=4 k_halves=2 split_k=4 bits=3" + sm   # packed 3-bit zero points
@@ -222,10 +229,11 @@ def test_native_layout_decode_routes(lib):
         # (one strip per block, K <= 4096, M <= 8: register-A measured faster than the three-slot ring)
         assert plan(lib, [g32(4096, 4096)], m) == "strip nw=16 cpl=1 spw=8 form=%s row_tiles=1" % ("register-A" if m <= 8 else "dma-A") + sm
         assert plan(lib, [g32(4096, 11008)] * 2, m) == "strip nw=8 cpl=2 spw=16 form=dma-A row_tiles=1" + sm
-        assert plan(lib, [g32(11008, 4096)], m) == ("strip nw=16 cpl=1 spw=22 form=dma-A row_tiles=1" if m < 9 else "panel cols=64 row_tiles=1 k_halves=2 split_k=4") + sm
+        assert plan(lib, [g32(11008, 4096)], m) == "strip nw=16 cpl=1 spw=22 form=dma-A row_tiles=1" + sm
     assert plan(lib, [g32(2112, 4096)], 16) == "strip nw=16 cpl=1 spw=6 form=dma-A row_tiles=1" + sm    # 66 k-steps over 16 waves: 5 -> 6
     assert plan(lib, [g32(2112, 4096)], 4) == "strip nw=16 cpl=1 spw=5 form=register-A row_tiles=1" + sm
-    assert plan(lib, [g32(4096, 4096)], 32) == "panel cols=64 row_tiles=2 k_halves=2 split_k=4" + sm
+    assert plan(lib, [g32(4096, 4096)], 32) == "strip nw=8 cpl=1 spw=16 form=dma-A row_tiles=2" + sm    # (up to 4096 x 4096 and 32 rows: strips; measured on g32 too)
+    assert plan(lib, [g32(4096, 4096)], 33) == "panel cols=64 row_tiles=4 k_halves=2 split_k=4" + sm
     assert plan(lib, [g32(4096, 1024)] * 2, 32) == "panel cols=64 row_tiles=2 k_halves=2 split_k=4 layers=2" + sm
     assert plan(lib, [g32(4096, 1024)] * 2, 16) == "strip nw=16 cpl=1 spw=8 form=dma-A row_tiles=1" + sm
     assert plan(lib, [g32(4096, 4096)], 64) == "panel cols=64 row_tiles=4 k_halves=2 split_k=4" + sm

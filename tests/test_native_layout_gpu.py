@@ -178,16 +178,20 @@ PANEL_CASES = [  # layout, g, K, N, zero kind, bias
     ("GPTQ", 128, 4096, 4096, "asym", False), ("GPTQ", 128, 11008, 4096, "asym", True), ("GEMM", 128, 4096, 11008, "asym", False),
     ("HQQ", 64, 4096, 4096, "asym", True), ("GPTQ", 32, 2048, 1152, "asym", False), ("GPTQ", 128, 4096, 1024, "sym", True),
     ("GPTQ", 64, 2112, 4096, "asym", False), ("GEMM", 64, 1024, 512, "asym", True), ("HQQ", 64, 11008, 4096, "asym", False),
+    # (round 5: up to 4096 x 4096 the strips keep 17..32 rows -- wider layers for the two-row-tile panels of every group size / zero kind)
+    ("GPTQ", 32, 1024, 4224, "asym", True), ("GPTQ", 128, 1024, 4224, "sym", False),
 ]
 PANEL_CASES_3BIT = [  # the 3-bit stream (up to 64 rows): fp16 (HQQ), packed and symmetric zero points, both group sizes, a ragged K
     ("HQQ", 64, 4096, 4096, "asym", True), ("GPTQ", 128, 4096, 1024, "asym", False), ("HQQ", 64, 11008, 4096, "asym", False),
     ("GPTQ", 64, 2112, 4096, "sym", True), ("GPTQ", 64, 1024, 512, "asym", False),
+    ("GPTQ", 128, 1024, 4224, "asym", True), ("GPTQ", 64, 1024, 4224, "sym", False),
 ]
 
 
 @pytest.mark.parametrize("bits,layout,g,K,N,zk,bias", [(4,) + c for c in PANEL_CASES] + [(3,) + c for c in PANEL_CASES_3BIT])
 def test_panel_kernel_vs_oracle(bits, layout, g, K, N, zk, bias):
-    """17 <= M <= 128 (from 9 rows where K >= 2 N) on native 4-bit layers: the panel kernel (csrc/panel.hip: 64-column panels, A tiles shared through LDS, B
+    """17 <= M <= 128 on native layers (from 33 rows where the layer is no larger than 4096 x 4096: the strips keep 17..32 rows there, and
+    everything below 17 -- round 5, profiles/r05_batch16.md): the panel kernel (csrc/panel.hip: 64-column panels, A tiles shared through LDS, B
     fragments q - z from registers, split-K partial panels through the workspace).  Every zero-point kind, g32 / g64 / g128, a K whose
     k-steps do not fill the last K-tile or split (2112 = 66 k-steps), bias, fp16 and bf16 activations, against the oracle."""
     from qllm_amd import ops
@@ -202,13 +206,11 @@ def test_panel_kernel_vs_oracle(bits, layout, g, K, N, zk, bias):
         w = layer.native_descriptor(0)
     ref = Ref(d)
     for m in (9, 16, 17, 24, 32, 33, 48, 64, 65, 100, 128):
-        if m < 17 and K < 2 * N:  # (few rows: only where K >= 2 N)
-            assert ops.plan_describe([w], m).startswith("strip "), (m, ops.plan_describe([w], m))
-            continue
+        strips = m < 17 or (m <= 32 and K <= 4096 and N <= 4096)   # (checked against the oracle like the panels)
         if m > 64 and (g == 32 or bits == 3 or K * N > 2 ** 25):   # (eight row tiles: 4 bits, 64- / 128-wide groups, layers of up to 2^25 weights; else
             assert ops.plan_describe([w], m).startswith("gemm"), (m, ops.plan_describe([w], m))   # the 256-row tiles take over at 65 rows)
             continue
-        assert ops.plan_describe([w], m).startswith("panel "), (m, ops.plan_describe([w], m))
+        assert ops.plan_describe([w], m).startswith("strip " if strips else "panel "), (m, ops.plan_describe([w], m))
         x = randx(m, K, seed=m)
         y = ops.linear_forward(w, torch.from_numpy(x).to(DEV)).cpu().numpy()
         assert np.isfinite(y.astype(np.float32)).all()

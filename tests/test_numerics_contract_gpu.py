@@ -38,7 +38,7 @@ def test_every_dispatch_boundary_keeps_the_contract(layout, bits, g, K, N):
         assert O.rel_err(y, ref.y16(x)) <= 1e-2, (m, plans[m])
         ys[m] = y
     # the batch really crosses kernels here (else this test guards nothing) ...
-    assert len(set(plans.values())) >= 3, plans
+    assert len(set(plans.values())) >= (3 if bits == 4 else 2), plans  # (3 bits: the native kernels end at 64 rows)
     # ... and the rows two batch sizes share agree to the contract's own tolerance (same x rows, different kernels)
     scale = float(np.abs(ref.y64(x_all[:1])).max())
     ms = sorted(ys)

@@ -8,5 +8,8 @@ $HIPCC --offload-arch=gfx950 -O3 -I $R/include -o $R/tools/lab/g4lab $R/tools/la
 # decode: the step through the C ABI (release library / lab library) and the round-5 bisect
 $HIPCC --offload-arch=gfx950 -O3 -I $R/include -o $R/tools/lab/cbench $R/tools/lab/cbench.cpp -L $R/qllm_amd -lqllm_mi355x -Wl,-rpath,'$ORIGIN/../../qllm_amd'
 $HIPCC --offload-arch=gfx950 -O3 -I $R/include -o $R/tools/lab/cbench_lab $R/tools/lab/cbench.cpp -L $R/tools/lab -lqllm_lab -Wl,-rpath,'$ORIGIN'
+# batch 2..32 per launch kind (BASELINE configs[3] with --cfg3): release library / lab library
+$HIPCC --offload-arch=gfx950 -O3 -I $R/include -o $R/tools/lab/gbench $R/tools/lab/gbench.cpp -L $R/qllm_amd -lqllm_mi355x -Wl,-rpath,'$ORIGIN/../../qllm_amd'
+$HIPCC --offload-arch=gfx950 -O3 -I $R/include -o $R/tools/lab/gbench_lab $R/tools/lab/gbench.cpp -L $R/tools/lab -lqllm_lab -Wl,-rpath,'$ORIGIN'
 $HIPCC --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I $R/include -I $R/qllm_amd/csrc -o $R/tools/lab/dbisect $R/tools/lab/dbisect.hip -L $R/tools/lab -lqllm_lab -Wl,-rpath,'$ORIGIN'
 ls -la $R/tools/lab/g4lab $R/tools/lab/cbench $R/tools/lab/cbench_lab $R/tools/lab/dbisect $R/tools/lab/libqllm_lab.so

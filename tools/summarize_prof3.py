@@ -185,7 +185,7 @@ if ht:
         Q += ["", f"Sum of the four medians: {tm:.2f} us per decoder layer; algorithmic bytes per layer {ta / 1e6:.1f} MB = "
               f"{ta / tm / 1e6:.2f} TB/s = {ta / tm / 1e6 / 8.0:.3f} of 8 TB/s.",
               "Template arguments of `strip_dma_kernel`: <waves per block, strips per block, k-steps per group, bits, bf16 activations, row tiles, fp16-zero-point form>; "
-              "of `panel_kernel` (csrc/panel.hip; round 4: down_proj, K >= 2 N): <row tiles, strips per wave, K halves per block, k-steps per group, bf16 activations, fp16-zero-point form>.", ""]
+              "of `panel_kernel` (csrc/panel.hip; from 17 rows): <row tiles, strips per wave, K halves per block, k-steps per group, bf16 activations, fp16-zero-point form>.", ""]
     notes = f"{out}/{tag}_hqq_notes.md"
     if os.path.exists(notes):
         Q += [l.rstrip("\n") for l in open(notes)]
