@@ -70,7 +70,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void strip_dma_kernel(const StripP
   constexpr int NG = 2 * NS / SPG;         // groups per round of the ring
   constexpr int TN = 16 * CPL;             // columns per block
   constexpr int WR = (BITS == 4) ? 4 : 3;  // word-rows per k-step
-  constexpr int WL = (BITS == 4) ? 1 : 2;  // loads per weight fragment
+  constexpr int WL = 1;                    // loads per weight fragment (3 bits: the neighbour word comes from the lane 16 below, see b_frag)
   typedef __attribute__((address_space(3))) void lds_void_t;
   // vector-memory operations of one stage request, in issue order: [the scale / zero words of the group(s) that END in this slot,]
   // the DMA pieces, the weight words.  (SPG = 1: every slot holds two groups; SPG = 2: every slot ends one; SPG = 4: the odd ones.)
@@ -139,7 +139,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void strip_dma_kernel(const StripP
     g_strip[c] = strip * gtab;
   }
   const int lane_w = (g * 16 + i) * 4;
-  const int lane_w3_lo = ((g == 0 ? 0 : g - 1) * 16 + i) * 4, lane_w3_hi = ((g == 3 ? 2 : g) * 16 + i) * 4;
+  // 3 bits: a column's k-step is 96 bits = words 0..2 of the strip row; lane (g, i) owns the 24 bits from bit 24 g: word 0 | words 0, 1 from
+  // bit 24 | words 1, 2 from bit 16 | word 2 from bit 8.  Each lane LOADS one word -- (0, 1, 2, 2) by g -- and takes the lower word of
+  // its pair from lane - 16 (g = 1, 2) through ds_bpermute (no memory access: the LDS crossbar): one vector-memory instruction per
+  // fragment instead of two.  The loop is bound by its vector-memory instructions (profiles/r05_batch16.md).
+  const int lane_w3 = ((g == 3 ? 2 : g) * 16 + i) * 4;
+  const int bperm3 = ((g == 1 || g == 2) ? lane - 16 : lane) * 4;
   const uint32_t shift3 = (uint32_t)((32 - 8 * g) & 31);
   // zero points: the word holding this lane's column -- packed 4-bit: nibble i%8 of word i/8; packed 3-bit: bit 3i of the 64-bit
   // pair (the field may straddle into the second word); fp16: half i%2 of word i/2
@@ -199,7 +204,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void strip_dma_kernel(const StripP
                                     : half8_t{(half_t)2.f, (half_t)1.f, (half_t)16.f, (half_t)8.f, (half_t)128.f, (half_t)64.f, (half_t)1.f, (half_t)1.f};
 
   // ---- ring state: registers -----------------------------------------------------------------------------------------------
-  uint32_t w[2 * NS][CPL], w_hi[BITS == 3 ? 2 * NS : 1][CPL];
+  uint32_t w[2 * NS][CPL];
   float4_t yacc[MT][CPL];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
@@ -232,8 +237,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void strip_dma_kernel(const StripP
         if constexpr (BITS == 4) {
           w[2 * u + e][c] = __builtin_amdgcn_raw_buffer_load_b32(rs_w, lane_w + e * (WR * 64), w_strip[c] + wrow, 2);
         } else {
-          w[2 * u + e][c] = __builtin_amdgcn_raw_buffer_load_b32(rs_w, lane_w3_lo + e * (WR * 64), w_strip[c] + wrow, 2);
-          w_hi[2 * u + e][c] = __builtin_amdgcn_raw_buffer_load_b32(rs_w, lane_w3_hi + e * (WR * 64), w_strip[c] + wrow, 2);
+          w[2 * u + e][c] = __builtin_amdgcn_raw_buffer_load_b32(rs_w, lane_w3 + e * (WR * 64), w_strip[c] + wrow, 2);
         }
       }
     }
@@ -249,7 +253,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void strip_dma_kernel(const StripP
       b0 = as_h2((wv & mask_lo) | kMagic); b1 = as_h2((wv & mask_hi) | kMagic64);
       b2 = as_h2((w8 & mask_lo) | kMagic); b3 = as_h2((w8 & mask_hi) | kMagic64);
     } else {
-      const uint32_t f = __builtin_amdgcn_alignbit(w_hi[s][c], w[s][c], shift3);
+      const uint32_t own = w[s][c];
+      const uint32_t below = (uint32_t)__builtin_amdgcn_ds_bpermute(bperm3, (int)own);  // (g = 0, 3: the lane itself)
+      const uint32_t f = __builtin_amdgcn_alignbit(own, below, shift3);
       const uint32_t f1 = f << 1;
       b0 = as_h2((f1 & m3a) | kMagic);
       b1 = as_h2((f1 & m3b) | kMagic);
@@ -375,7 +381,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void strip_dma_kernel(const StripP
 #pragma unroll
     for (int s2 = 0; s2 < 2 * NS; ++s2)
 #pragma unroll
-      for (int c = 0; c < CPL; ++c) { w[s2][c] = 0x12345678u * (lane + 1) + s2; if constexpr (BITS == 3) w_hi[s2][c] = 0x9abcdef1u + lane; }
+      for (int c = 0; c < CPL; ++c) w[s2][c] = 0x12345678u * (lane + 1) + s2;
   }
   // ---- prologue: the scale / zero tables of the wave's chunk, then the whole ring; then rounds -------------------------------------
   if constexpr (!NO_SZ) {
