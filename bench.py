@@ -234,28 +234,31 @@ def cpu_baseline_leg(dev):
                 gpu_vs_cpu_rel_err_11008x4096=round(rel, 6))
 
 
-def hqq_leg(dev):
+def hqq_leg(dev, n_layers=LAYERS):
     """BASELINE configs[3]: HQQ g64 fp16 zeros, batch 16, 4-bit and 3-bit decoder layers (the reference mixes them per layer).
-    Four layers of each width (> the 256 MB Infinity Cache together with their neighbours), through the modules with the
-    loader's sibling groups, like the headline leg; the 7-launch form beside it."""
+    A stack of the model's depth for each width (32 layers: one hipGraph per batch step, like the headline leg -- a four-layer
+    graph, rounds 3-4, charged the replay boundary of a step to four layers instead of 32: ~1.5 us per layer), through the modules
+    with the loader's sibling groups; the 7-launch form beside it."""
     extra = {}
     from qllm_amd.modeling.q_layers import QuantLinearHQQ
     x16 = torch.randn(16, HIDDEN, device=dev, dtype=torch.float16)
     for bits_sel, tag in ((4, "hqq_w4_g64_m16"), (3, "hqq_w3_g64_m16")):
-        hs = Stack(QuantLinearHQQ, 4, dev, seed=7 + bits_sel, bits=bits_sel, group=64)
+        hs = Stack(QuantLinearHQQ, n_layers, dev, seed=7 + bits_sel, bits=bits_sel, group=64)
         # (only the packed words scale with the bit width: scales, fp16 zero points, x and y do not)
-        nbytes = 4 * sum(alg_bytes(K, N, 16, 64, "f16") - K * N // 2 + K * N * bits_sel // 8
-                         for (K, N) in [(HIDDEN, HIDDEN)] * 4 + [(HIDDEN, INTER)] * 2 + [(INTER, HIDDEN)])
+        nbytes = sum(alg_bytes(K, N, 16, 64, "f16") - K * N // 2 + K * N * bits_sel // 8
+                     for (K, N) in [(HIDDEN, HIDDEN)] * 4 + [(HIDDEN, INTER)] * 2 + [(INTER, HIDDEN)])   # per layer
         res = {}
         for fz in (True, False):
             hs.set_fused(fz)
             gh, _ = capture(lambda: hs(x16))
-            ms = time_events(gh.replay, 20) / 4
+            ms = time_events(gh.replay, 20) / n_layers
             del gh
             res["grouped" if fz else "ungrouped"] = ms
-        extra[tag] = {"ms_per_layer": round(res["grouped"], 4), "GBps": round(nbytes / 4 / res["grouped"] / 1e6, 1),
+        extra[tag] = {"ms_per_layer": round(res["grouped"], 4), "GBps": round(nbytes / res["grouped"] / 1e6, 1),
+                      "frac_of_hbm_peak": round(nbytes / res["grouped"] / 1e6 / HBM_PEAK_GBPS, 4), "layers": n_layers,
                       "ms_per_layer_7_launches": round(res["ungrouped"], 4)}
         del hs
+        torch.cuda.empty_cache()
     return extra
 
 

@@ -87,7 +87,10 @@ int main(int argc, char **argv) {
     CK(hipMalloc(&ws, ws_bytes)); CK(hipMemset(ws, 0, ws_bytes));
     hipStream_t st;
     CK(hipStreamCreate(&st));
-    struct L { const char *name; int K, N, n; } launches[] = {{"q/k/v", 4096, 4096, 3}, {"o_proj", 4096, 4096, 1}, {"gate/up", 4096, 11008, 2}, {"down", 11008, 4096, 1}};
+    struct L { const char *name; int K, N, n; };
+    std::vector<L> launches = {{"q/k/v", 4096, 4096, 3}, {"o_proj", 4096, 4096, 1}, {"gate/up", 4096, 11008, 2}, {"down", 11008, 4096, 1}};
+    // GBENCH_FUSED=1: what a sibling group would cost as ONE layer of the summed width (the strips of adjacent native copies are one array)
+    if (getenv("GBENCH_FUSED")) launches = {{"qkv-as-1", 4096, 12288, 1}, {"gu-as-1", 4096, 22016, 1}};
     const int NSET = 20;  // (20 x 10..52 MB per launch kind: far beyond the 256 MB Infinity Cache)
     for (int M : ms) {
       double total = 0, bytes_total = 0;

@@ -15,8 +15,8 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $P/trace -o 
 timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $P/pmc_fetch -o f -- python $R/bench.py --steps 5 --warmup 2 --no-extra --min-timed-s 0 > /dev/null 2> $P/rocprof_fetch.err
 timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $P/pmc_write -o w -- python $R/bench.py --steps 5 --warmup 2 --no-extra --min-timed-s 0 > /dev/null 2> $P/rocprof_write.err
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $P/hqq_trace -o h -- python $R/tools/hqq_leg.py 10 > $P/hqq_leg.log 2> $P/rocprof_hqq.err
-timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $P/hqq_fetch -o f -- python $R/tools/hqq_leg.py 3 > /dev/null 2> $P/rocprof_hqq_fetch.err
-timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $P/hqq_write -o w -- python $R/tools/hqq_leg.py 3 > /dev/null 2> $P/rocprof_hqq_write.err
+timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $P/hqq_fetch -o f -- python $R/tools/hqq_leg.py 3 8 > /dev/null 2> $P/rocprof_hqq_fetch.err
+timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $P/hqq_write -o w -- python $R/tools/hqq_leg.py 3 8 > /dev/null 2> $P/rocprof_hqq_write.err
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $P/prefill -o p -- python $R/tools/kbench.py --m 2048 --iters 40 --layouts GPTQ GEMM > $P/prefill_kbench.log 2> $P/rocprof_prefill.err
 cd $R
 bash tools/pmc_pass.sh ${tag}_sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -- python tools/one_shape.py > /dev/null

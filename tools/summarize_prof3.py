@@ -141,8 +141,8 @@ if ht:
     tr = [r for r in csv.DictReader(open(ht[0])) if ours(r["Kernel_Name"])]
     tr.sort(key=lambda r: int(r["Start_Timestamp"]))
     Q = [f"# {tag}: BASELINE configs[3] -- HQQ g64 fp16 zero points, batch 16, per launch", "",
-         "`rocprofv3 --kernel-trace --stats -- python tools/hqq_leg.py 10` (four decoder layers of each width through the modules: sibling",
-         "groups, native layout; graph replay), HBM counters from `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of `tools/hqq_leg.py 3`.",
+         "`rocprofv3 --kernel-trace --stats -- python tools/hqq_leg.py 10` (a 32-layer stack of each width through the modules: sibling",
+         "groups, native layout; graph replay), HBM counters from `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of `tools/hqq_leg.py 3 8` (8 layers).",
          "Un-profiled lines of the same script:", "", "```"]
     Q += [l.rstrip() for l in open(f"{src}/hqq_leg.log") if l.startswith("hqq")]
     Q += ["```", ""]

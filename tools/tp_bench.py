@@ -107,8 +107,10 @@ def build_stack(P, n_layers, dev, seed, group=None, reducer=None):
     return blocks
 
 
-def shard_shapes_leg(dev, n_layers=16):
-    """1 GPU: what one rank of an 8-way tensor-parallel Llama-2-70B executes (no collective), decode M=1 and prefill M=2048."""
+def shard_shapes_leg(dev, n_layers=80):
+    """1 GPU: what one rank of an 8-way tensor-parallel Llama-2-70B executes (no collective), decode M=1 and prefill M=2048.
+    80 layers = the model's depth: one hipGraph per token, as a serving loop would replay it (rounds 3-4 timed a 16-layer graph and
+    charged the per-replay boundary, ~8 us, to 16 layers instead of 80)."""
     from qllm_amd import ops
     P = 8
     blocks = build_stack(P, n_layers, dev, seed=77)
