@@ -42,6 +42,26 @@ __global__ void fill_x(_Float16 *p, size_t n, uint32_t seed) {
   }
 }
 
+// --prefetch experiment (round 5): a side stream reads the packed words of the launch `dist` ahead while the current launch runs, so
+// that HBM keeps streaming through the launch boundaries and the next launch finds its words in the Infinity Cache.  Plain
+// loads, nothing stored (the never-true store keeps the loads alive).
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__global__ void prefetch_kernel(const u32x4 *p, size_t n16, uint32_t *sink) {
+  uint32_t acc = 0;
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = tid; i < n16; i += nth * 8) {  // eight independent 16-byte loads per thread in flight
+    u32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const size_t idx = i + u * nth;
+      v[u] = idx < n16 ? __builtin_nontemporal_load(p + idx) : u32x4{0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc ^= v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+  }
+  if (acc == 0x9e3779b9u && sink) *sink = acc;
+}
+
 struct Layer {
   qllm_weight_t g{}, n{};  // GPTQ row-stream descriptor, native descriptor
 };
@@ -73,6 +93,7 @@ static Layer make_layer(int K, int N, int group, uint32_t seed, bool keep_gptq, 
 
 int main(int argc, char **argv) {
   int layers = 32, iters = 50, M = 1;
+  int pf_dist = 0, pf_blocks = 256, pf_threads = 256;  // --prefetch <launches ahead> [--pf-blocks n] [--pf-threads n]
   std::string layout = "native";
   bool timeline = false;
   for (int i = 1; i < argc; ++i) {
@@ -81,10 +102,14 @@ int main(int argc, char **argv) {
     else if (!strcmp(argv[i], "--layout")) layout = argv[++i];
     else if (!strcmp(argv[i], "--m")) M = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--timeline")) timeline = true;
+    else if (!strcmp(argv[i], "--prefetch")) pf_dist = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--pf-blocks")) pf_blocks = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--pf-threads")) pf_threads = atoi(argv[++i]);
   }
   qllm_device_info_t info;
   QK(qllm_device_info(0, &info));
-  printf("device %s, %d CUs; layers=%d M=%d layout=%s\n", info.arch, info.compute_units, layers, M, layout.c_str());
+  printf("device %s, %d CUs; layers=%d M=%d layout=%s prefetch=%d launches ahead (%d x %d threads)\n", info.arch, info.compute_units, layers, M, layout.c_str(),
+         pf_dist, pf_blocks, pf_threads);
   const int H = 4096, I = 11008, GS = 128;
   const bool both = layout == "both", want_native = both || layout == "native", want_gptq = both || layout == "gptq";
   struct Block { Layer q, k, v, o, gate, up, down; };
@@ -112,19 +137,60 @@ int main(int argc, char **argv) {
   CK(hipDeviceSynchronize());
 
   auto pick = [&](const Layer &L, bool native) -> const qllm_weight_t & { return native ? L.n : L.g; };
+  // launch j of the step (4 per layer): the layers whose words it streams
+  auto launch_layers = [&](int j) {
+    Block &b = blocks[(j / 4) % layers];
+    std::vector<const Layer *> v;
+    switch (j % 4) {
+      case 0: v = {&b.q, &b.k, &b.v}; break;
+      case 1: v = {&b.o}; break;
+      case 2: v = {&b.gate, &b.up}; break;
+      default: v = {&b.down};
+    }
+    return v;
+  };
+  hipStream_t st2 = nullptr;
+  uint32_t *sink = nullptr;
+  std::vector<hipEvent_t> evs;
+  if (pf_dist > 0) {
+    CK(hipStreamCreate(&st2));
+    CK(hipMalloc(&sink, 4));
+    evs.resize(4 * layers + 1);
+    for (auto &e : evs) CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
   auto step = [&](bool native, hipStream_t st) {
     const _Float16 *x = h0;
+    int j = 0;
+    auto before = [&]() {  // in front of launch j: the side stream may start on launch j + dist once launch j - 1 is done
+      if (pf_dist > 0 && native) {
+        CK(hipEventRecord(evs[j], st));
+        CK(hipStreamWaitEvent(st2, evs[j], 0));
+        for (const Layer *L : launch_layers((j + pf_dist) % (4 * layers))) {
+          const size_t n16 = (size_t)L->n.K * L->n.N / 2 / 16;
+          prefetch_kernel<<<pf_blocks, pf_threads, 0, st2>>>((const u32x4 *)L->n.qweight, n16, sink);
+        }
+      }
+      ++j;
+    };
     for (int l = 0; l < layers; ++l) {
       Block &b = blocks[l];
       qllm_weight_t w3[3] = {pick(b.q, native), pick(b.k, native), pick(b.v, native)};
       void *y3[3] = {q, k, v};
+      before();
       QK(qllm_linear_forward_grouped(w3, y3, 3, x, M, QLLM_F16, ws, ws_bytes, st));
+      before();
       QK(qllm_linear_forward(&pick(b.o, native), q, o, M, QLLM_F16, ws, ws_bytes, st));
       qllm_weight_t w2[2] = {pick(b.gate, native), pick(b.up, native)};
       void *y2[2] = {gate, up};
+      before();
       QK(qllm_linear_forward_grouped(w2, y2, 2, o, M, QLLM_F16, ws, ws_bytes, st));
+      before();
       QK(qllm_linear_forward(&pick(b.down, native), gate, h1, M, QLLM_F16, ws, ws_bytes, st));
       x = h1;
+    }
+    if (pf_dist > 0 && native) {  // join the side stream (a capture must end with one)
+      CK(hipEventRecord(evs[4 * layers], st2));
+      CK(hipStreamWaitEvent(st, evs[4 * layers], 0));
     }
   };
 
