@@ -27,6 +27,17 @@
 //     layout: the per-group VALU work of a strip is 6 packed operations + the decode of one scale and one zero point.
 //   * k-steps past the wave's chunk or past K: the DMA source offset is pushed out of the buffer's range, the image holds zeros and
 //     the stage contributes nothing (the weight / scale addresses are clamped into the strip and cost an L2 hit).
+//   Round 5 (profiles/r05_batch16.md; the loop is bound by its vector-memory INSTRUCTIONS, timing-only ablations there):
+//   * SCALE / ZERO TABLES IN FRONT OF THE RING.  The scale and zero words of the wave's whole chunk travel once, by LDS-DMA in 256-byte
+//     instructions, into per-wave tables behind the rings ([group][strip] cells of 32 bytes) and are read back per group with
+//     ds_read_u16 -- they were 96 of a wave's 208 vector-memory instructions and carry almost no bytes (q/k/v 11.6 -> 10.9 us).
+//   * 64-WIDE GROUPS FINISH FROM minus-sum-x-bias ACCUMULATORS: both A fragments and the bookkeeping MFMAs of a slot first, the strips'
+//     MFMAs then start from -sum x bias, so a group step is two fmas per accumulator.
+//   * 3 BITS: ONE WORD LOAD PER FRAGMENT.  The lane's 24-bit field straddles two words for g = 1, 2; each lane loads word (0,1,2,2)[g]
+//     and takes the lower word of its pair from lane - 16 with ds_bpermute (configs[3] 3-bit layer 54.6 -> 51.2 us).
+//   * blocks of 1, 2, 3, 4 or 6 strips (3 bits: 6 only with fp16 zero points at 64-wide groups, where the ring fits the registers).
+//   Lost: the 16-bytes-per-lane layout (tools/lab/attic/native_layout_v2.patch): 8-byte loads per ring slot touch eight lines per
+//   instruction, -13..-25 % on the wide launches.
 //   Measured dead ends (same file, profiles/r03_batch16.md): K split over adjacent blocks with fp32 partial slabs + arrival ticket
 //   (fewer activation bytes per CU, but the fix-up costs 3-4 us: 4096 -> 4096 at M = 16 5.8 -> 10.6 us); two or four small blocks
 //   per CU (no change: the CU's ingest rate is the bound, not the blocks' start-up).

@@ -19,7 +19,7 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 def _resources(src):
     if not os.path.exists(HIPCC):
         pytest.skip("hipcc not available")
-    stamp = max(int(os.path.getmtime(os.path.join(CSRC, f))) for f in (src, "strip_kernel.hpp", "strip_dma.hpp", "strip_dma_launch.hpp", "kernels.hpp", "common.hpp"))
+    stamp = max(int(os.path.getmtime(os.path.join(CSRC, f))) for f in (src, "strip_kernel.hpp", "strip1_kernel.hpp", "strip_dma.hpp", "strip_dma_launch.hpp", "kernels.hpp", "common.hpp"))
     out = os.path.join("/tmp", f"qllm_res_{src}_{stamp}.s")
     if not os.path.exists(out):
         subprocess.run([HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-S",
@@ -85,6 +85,17 @@ def test_native_layout_decode_kernels_keep_their_occupancy():
                       (_strip(8, 1, 16, 2, 2, sm=True, oner=True), 64), (_strip(8, 1, 16, 4, 2, sm=True), 80)):
         assert name in res, name
         assert res[name][1] == 0 and res[name][0] <= cap, (name, res[name])
+
+
+def test_batch1_kernel_keeps_a_cu_full_of_waves():
+    """csrc/strip1_kernel.hpp (round 5, the headline kernel): rounds of up to 24 k-steps at <= 64 registers (8 waves per SIMD: its
+    launch bound), rounds of 32 at <= 128; the fused all-reduce forms within the same budgets; no instantiation spills."""
+    res = {n: v for n, v in _resources("strip1.hip").items() if "strip1_kernel" in n}
+    assert len(res) >= 16
+    for n, (vgpr, spill) in res.items():
+        m = re.search(r"strip1_kernelILi(\d+)ELi(\d+)E", n)
+        nw, maxs = int(m.group(1)), int(m.group(2))
+        assert spill == 0 and vgpr <= (64 if maxs <= 24 else 128), (n, nw, maxs, vgpr, spill)
 
 
 def test_wave_specialised_prefill_kernel_budget():
