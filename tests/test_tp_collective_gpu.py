@@ -16,6 +16,7 @@ import torch.multiprocessing as mp
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
 
 
 def _free_port():
@@ -280,7 +281,7 @@ def _body(rank, world):
     # ---- tools/tp_bench.run, as `bench.py --tp 2` would drive it (two layers, eager because the backend is gloo)
     from qllm_amd import _lib
     from tools import tp_bench
-    args = types.SimpleNamespace(tp=world, steps=3, warmup=1, tp_layers=2, keep_process_group=True)
+    args = types.SimpleNamespace(tp=world, steps=10, warmup=2, tp_layers=8, keep_process_group=True)
     tp_bench.run(args, world, rank, torch.device(dev), _lib.device_info(0))
     return msgs
 
@@ -298,7 +299,13 @@ def test_hip_shards_behind_a_real_collective_two_ranks_one_gpu(capfd):
     for rank, msgs in sorted(results):
         assert not msgs, (rank, msgs)
     out = capfd.readouterr().out
-    assert "[tp_bench] world_size=2 backend=gloo tp_degree=2 layers=2" in out
+    try:   # (evidence: the fused / unfused timings of this run, copied to profiles/ by the round's evidence script)
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "tp_bench_two_ranks_one_gpu.log"), "w") as f:
+            f.write("\n".join(l for l in out.splitlines() if "tp_bench" in l or l.startswith("{")) + "\n")
+    except OSError:
+        pass
+    assert "[tp_bench] world_size=2 backend=gloo tp_degree=2 layers=8" in out
     assert "[tp_bench] sharded == unsharded on 2 rank(s)" in out
     assert "[tp_bench] row-parallel sums: one-shot peer-write kernel" in out and '"oneshot_all_reduce_us_16KB"' in out
     assert "[tp_bench] step runs as: hipGraph replay" in out   # (every sum of the step is one of the library's kernels: it captures under gloo too)
