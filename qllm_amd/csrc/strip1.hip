@@ -22,6 +22,11 @@ bool strip1_shape(int K, int blocks, int cus, int *nw, int *maxs) {
   else if (T <= 384) { w = 16; m = 24; }
   else if (T <= 512) { w = 16; m = 32; }
   else return false;
+  // No dead waves where an odd wave count is built: K = 11008 is 344 k-steps = 14 1/3 rounds of 24 -- the sixteenth wave of a 16 x 24
+  // block owns nothing (it re-reads its neighbour's words and multiplies zeros); K = 3584 (a Llama-2-70B TP = 8 down_proj shard) is
+  // exactly 7 x 16.  The cross-wave sum is a pairwise tree over NW values: the dead wave contributed an exact zero, same bits.
+  const int need = (T + m - 1) / m;
+  if (need < w && knob("QLLM_S1_ODD", 1) && ((need == 7 && m == 16) || (need == 15 && m == 24))) w = need;
   *nw = w;
   *maxs = m;
   return true;
@@ -56,9 +61,11 @@ int launch_strip1_allreduce(const Strip1Params &p, int nw, int maxs, int n_strip
   if (nw == 4 && maxs == 16) return launch_ar<4, 16>(p, n_strips, stream);
   if (nw == 4 && maxs == 32) return launch_ar<4, 32>(p, n_strips, stream);
   if (nw == 8 && maxs == 16) return launch_ar<8, 16>(p, n_strips, stream);
+  if (nw == 7 && maxs == 16) return launch_ar<7, 16>(p, n_strips, stream);
   if (nw == 8 && maxs == 24) return launch_ar<8, 24>(p, n_strips, stream);
   if (nw == 8 && maxs == 32) return launch_ar<8, 32>(p, n_strips, stream);
   if (nw == 16 && maxs == 24) return launch_ar<16, 24>(p, n_strips, stream);
+  if (nw == 15 && maxs == 24) return launch_ar<15, 24>(p, n_strips, stream);
   return set_error(QLLM_ERR_UNSUPPORTED, "fused all-reduce: no batch-1 instantiation for nw=%d round=%d", nw, maxs);
 }
 
@@ -66,16 +73,18 @@ int launch_strip1(const Strip1Params &p, int nw, int maxs, int n_prob, int max_s
   const dim3 grid(max_strips, n_prob);
   if (p.dbg) {  // diagnostics instantiations (timeline stamps): the two Llama-2-7B forms
     if (nw == 8 && maxs == 16 && p.T == 128) return launch_t<8, 16, true, true>(p, grid, stream);
-    if (nw == 16 && maxs == 24 && p.T < 384) return launch_t<16, 24, false, true>(p, grid, stream);
+    if (nw == 15 && maxs == 24 && p.T < 360) return launch_t<15, 24, false, true>(p, grid, stream);
   }
   if (nw == 4 && maxs == 8) return launch_e<4, 8>(p, grid, stream);
   if (nw == 4 && maxs == 16) return launch_e<4, 16>(p, grid, stream);
   if (nw == 4 && maxs == 32) return launch_e<4, 32>(p, grid, stream);
   if (nw == 8 && maxs == 16) return launch_e<8, 16>(p, grid, stream);
+  if (nw == 7 && maxs == 16) return launch_e<7, 16>(p, grid, stream);
   if (nw == 8 && maxs == 24) return launch_e<8, 24>(p, grid, stream);
   if (nw == 8 && maxs == 32) return launch_e<8, 32>(p, grid, stream);
   if (nw == 16 && maxs == 16) return launch_e<16, 16>(p, grid, stream);
   if (nw == 16 && maxs == 24) return launch_e<16, 24>(p, grid, stream);
+  if (nw == 15 && maxs == 24) return launch_e<15, 24>(p, grid, stream);
   if (nw == 16 && maxs == 32) return launch_e<16, 32>(p, grid, stream);
   return set_error(QLLM_ERR_UNSUPPORTED, "internal: no batch-1 instantiation for nw=%d round=%d", nw, maxs);
 }

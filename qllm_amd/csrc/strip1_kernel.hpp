@@ -43,11 +43,15 @@ __device__ __forceinline__ float dpp_add1(float v) {
 }
 
 // bytes of LDS per block: red[16 columns][36 floats >= NW * 4] | per wave: staged x (XL KB) + 256 zero bytes
+// floats per column of the reduction buffer: NW x 4 values, rows 16-byte aligned and never a multiple of 32 floats apart (7 and 15
+// waves would otherwise put all 16 columns on the same banks)
+constexpr int strip1_rs(int nw) { return nw * 4 + 4 + (((nw * 4 + 4) % 32 == 0) ? 4 : 0); }
+
 template <int NW, int MAXS>
 constexpr int strip1_lds_bytes() {
   constexpr int XL = (MAXS * 4 + 63) / 64;
   static_assert(NW * 4 <= 64, "at most 16 waves");
-  return 16 * (NW * 4 + 4) * 4 + NW * (XL * 1024 + 256);
+  return 16 * strip1_rs(NW) * 4 + NW * (XL * 1024 + 256);
 }
 
 // NW waves x MAXS k-steps cover T (host: NW * MAXS >= T >= MAXS; EXACT: NW * MAXS == T, no masking of a shifted window)
@@ -62,7 +66,7 @@ __global__ __launch_bounds__(NW * 64, (MAXS <= 24) ? 8 : 4) void strip1_kernel(c
   constexpr int NG = MAXS / 4;            // groups per wave
   constexpr int NPASS = (NG + 3) / 4;     // accumulator sets: groups 0-3, groups 4-7
   constexpr int XL = (MAXS * 4 + 63) / 64;  // 16-byte activation chunks per lane
-  constexpr int RS = NW * 4 + 4;          // floats per column of the reduction buffer (16-byte aligned rows, 2-way banks at most)
+  constexpr int RS = strip1_rs(NW);       // floats per column of the reduction buffer (16-byte aligned rows, 2-way banks at most)
   extern __shared__ __attribute__((aligned(16))) float lds[];
 
   const int lane = threadIdx.x & 63;

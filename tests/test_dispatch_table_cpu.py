@@ -128,11 +128,11 @@ def test_native_layout_decode_routes(lib):
     assert plan(lib, [attn], 1) == "strip1 nw=4 round=32 exact grid=strips x 1" + sm     # one block per CU: four waves, one per SIMD
     assert plan(lib, [attn] * 3, 1) == "strip1 nw=8 round=16 exact grid=strips x 3" + sm
     assert plan(lib, [up] * 2, 1) == "strip1 nw=8 round=16 exact grid=strips x 2" + sm
-    assert plan(lib, [down], 1) == "strip1 nw=16 round=24 grid=strips x 1" + sm
+    assert plan(lib, [down], 1) == "strip1 nw=15 round=24 grid=strips x 1" + sm      # (344 k-steps: no sixteenth, dead wave)
     # ... the Llama-2-70B TP = 8 shards (BASELINE configs[4]): q/k/v (ragged widths), o (K = 1024), gate/up, down (K = 3584)
     assert plan(lib, [W(8192, 1024, layout=NATIVE), W(8192, 128, layout=NATIVE), W(8192, 128, layout=NATIVE)], 1) == "strip1 nw=8 round=32 exact grid=strips x 3" + sm
     assert plan(lib, [W(1024, 8192, layout=NATIVE)], 1) == "strip1 nw=4 round=8 exact grid=strips x 1" + sm
-    assert plan(lib, [W(3584, 8192, layout=NATIVE)], 1) == "strip1 nw=8 round=16 grid=strips x 1" + sm
+    assert plan(lib, [W(3584, 8192, layout=NATIVE)], 1) == "strip1 nw=7 round=16 exact grid=strips x 1" + sm
     # ... other group sizes, 3 bits and K beyond 512 k-steps stay on the general strip kernel
     assert plan(lib, [W(4096, 4096, 64, layout=NATIVE)], 1) == "strip nw=8 cpl=1 spw=16 form=lds-slab row_tiles=1" + sm
     assert plan(lib, [W(4096, 4096, 128, 3, NATIVE)], 1).startswith("strip nw=16")

@@ -13,8 +13,9 @@ DEV = "cuda:0"
 
 # K -> the plan line's prefix (strip1.hip: strip1_shape)
 FORMS = [(256, "nw=4 round=8 grid"), (1024, "nw=4 round=8 exact"), (1152, "nw=4 round=16 grid"), (2048, "nw=4 round=16 exact"),
-         (3584, "nw=8 round=16 grid"), (4096, "nw=8 round=16 exact"), (5120, "nw=8 round=24 grid"), (6144, "nw=8 round=24 exact"),
-         (8192, "nw=8 round=32 exact"), (6656, "nw=8 round=32 grid"), (11008, "nw=16 round=24 grid"), (12288, "nw=16 round=24 exact"),
+         (3584, "nw=7 round=16 exact"), (3840, "nw=8 round=16 grid"), (4096, "nw=8 round=16 exact"), (5120, "nw=8 round=24 grid"), (6144, "nw=8 round=24 exact"),
+         (8192, "nw=8 round=32 exact"), (6656, "nw=8 round=32 grid"), (11008, "nw=15 round=24 grid"), (11776, "nw=16 round=24 grid"),
+         (12288, "nw=16 round=24 exact"),
          (14336, "nw=16 round=32 grid"), (16384, "nw=16 round=32 exact")]
 
 

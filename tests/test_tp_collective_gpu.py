@@ -309,5 +309,7 @@ def test_hip_shards_behind_a_real_collective_two_ranks_one_gpu(capfd):
     assert "[tp_bench] sharded == unsharded on 2 rank(s)" in out
     assert "[tp_bench] row-parallel sums: one-shot peer-write kernel" in out and '"oneshot_all_reduce_us_16KB"' in out
     assert "[tp_bench] step runs as: hipGraph replay" in out   # (every sum of the step is one of the library's kernels: it captures under gloo too)
-    assert "[tp_bench] row-parallel GEMV + all-reduce: fused (one launch)" in out and '"row_parallel_all_reduce_fused_into_gemv": true' in out
+    # both forms are timed and the faster one is reported (on a shared GPU that may be either)
+    assert "[tp_bench] row-parallel GEMV + all-reduce: fused (one launch)" in out and "-> reporting the" in out
+    assert '"ms_per_step_fused_all_reduce"' in out and '"ms_per_step_unfused_all_reduce"' in out
     assert '"ranks": 2' in out and '"all_reduces_per_layer": 2' in out
