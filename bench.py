@@ -155,6 +155,10 @@ def capture(fn, warm=2):
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         out = fn()
+    # (capturing executes nothing: `out` is graph-pool memory nobody has written yet -- one replay makes it the step's real output
+    #  before any caller looks at it; round 5: a run after 11 minutes of other GPU work found non-finite garbage there)
+    g.replay()
+    torch.cuda.synchronize()
     return g, out
 
 

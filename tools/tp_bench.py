@@ -86,6 +86,8 @@ def _capture(fn, warm=2):
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         out = fn()
+    g.replay()   # (capturing executes nothing: make `out` the step's real output before a caller checks it -- bench.capture)
+    torch.cuda.synchronize()
     return g, out
 
 
