@@ -18,7 +18,7 @@ def demangle(names):
 
 
 rows = []
-for src in ("strip_sm.hip", "strip_sm_ra.hip", "strip_dma_g32.hip", "strip_dma_g64.hip", "strip_dma_g128.hip", "strip.hip", "native.hip", "skinny.hip", "gemm3.hip", "panel.hip", "gemm2.hip", "gemm.hip", "dequant.hip", "gather.hip", "comm.hip", "ortblob.hip"):
+for src in ("strip1.hip", "strip_sm.hip", "strip_sm_ra.hip", "strip_dma_g32.hip", "strip_dma_g64.hip", "strip_dma_g128.hip", "strip.hip", "native.hip", "skinny.hip", "gemm3.hip", "panel.hip", "gemm2.hip", "gemm.hip", "dequant.hip", "gather.hip", "comm.hip", "ortblob.hip"):
     asm = f"/tmp/qllm_kres_{src}.s"
     subprocess.run([HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-S", "--cuda-device-only",
                     os.path.join(CSRC, src), "-o", asm], check=True, capture_output=True)

@@ -75,7 +75,7 @@ L = [f"# {tag}: decode step under rocprofv3, per launch", "",
      "`rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 20 --warmup 3 --no-extra`;",
      "HBM counters from two separate passes `--kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (5 steps) of the same command",
      "(`tools/profile_round3.sh`).  The step: 4 launches per decoder layer on one stream (q/k/v and gate/up grouped), the modules",
-     "decoding from their native strip-major copies, one-round instantiations of the strip kernel.", "",
+     "decoding from their native strip-major copies, every launch on the batch-1 kernel (`csrc/strip1_kernel.hpp`).", "",
      f"bench line under the profiler: value={bench['value']} {bench['unit']}, ms_per_step={bench['ms_per_step']}, "
      f"avg launch {bench['roofline']['avg_launch_us']} us incl. gaps", ""]
 if full:
