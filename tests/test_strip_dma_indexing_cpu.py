@@ -44,17 +44,53 @@ def test_fragment_reads_are_bank_conflict_free():
             assert len(set(banks)) == 64, (e, grp)        # 16 lanes x 4 dwords on 64 distinct banks: one LDS cycle
 
 
+def strip_dma_ring(cpl, spg, bits, zf16, mt=1):  # strip_dma.hpp: strip_dma_ring<CPL, SPG, BITS, ZF16, MT>()
+    if spg == 1:
+        return 2 if (cpl >= 2 or mt >= 2) else 3
+    return 3 if (spg == 2 and (cpl >= 6 or (bits == 3 and cpl >= 4 and not zf16))) else 4
+
+
 def test_request_counts_fit_the_wait_counter():
-    """The hand-counted vmcnt waits: requests per ring slot for every built (strips, bits, group) combination; waits above 63 are
-    written as 63 (conservative), and a slot's own requests never exceed the counter."""
+    """The hand-counted vmcnt waits (round 5: a ring slot requests its 2 MT activation pieces and ONE word per strip and k-step -- the
+    scale / zero words travel in front of the ring, 3-bit fragments are one load): a wait is `vmcnt(all slots - own)`, the counter
+    has six bits; whatever is built must fit without the conservative cap of 63 ever being needed."""
     for bits in (4, 3):
-        for spg in (2, 4):
-            for cpl in (1, 2, 4, 6):
-                for zf16 in (False, True):
-                    if bits == 3 and cpl == 6:
-                        continue
-                    z2 = bits == 3 and not zf16
-                    lz = cpl * (2 + (1 if z2 else 0))
-                    lx = 2 + 2 * cpl * (1 if bits == 4 else 2)
-                    l_even, l_odd = lx + (lz if spg == 2 else 0), lx + lz
-                    assert max(l_even, l_odd) <= 63
+        for spg in (1, 2, 4):
+            if bits == 3 and spg == 1:
+                continue
+            for mt, cpls in ((1, (1, 2, 3, 4, 6)), (2, (1,))):
+                for cpl in cpls:
+                    for zf16 in (False, True):
+                        if bits == 3 and cpl == 6 and not (zf16 and spg == 2):
+                            continue          # (strip_dma_launch.hpp: six 3-bit strips only with fp16 zero points at 64-wide groups)
+                        if spg == 1 and cpl > 2:
+                            continue          # (32-wide groups: one or two strips)
+                        ns = strip_dma_ring(cpl, spg, bits, zf16, mt)
+                        lx = 2 * mt + 2 * cpl
+                        assert ns * lx <= 63, (bits, spg, mt, cpl, zf16, ns * lx)
+                        assert (2 * ns) % spg == 0     # a round of the ring is whole groups
+
+
+def test_three_bit_fragment_from_one_load_and_the_lane_below():
+    """3 bits: a column's k-step is 96 bits = words 0..2; lane (g, i) owns the 24 bits from bit 24 g.  Each lane loads word (0,1,2,2)[g]
+    and takes the lower word of its pair from lane - 16 (g = 1, 2) or itself (g = 0, 3); v_alignbit(own, below, (32 - 8 g) & 31) then
+    holds its eight 3-bit values at bits 0, 3, .., 21 (strip_dma.hpp b_frag; round 5: was two loads per fragment)."""
+    import random
+    rnd = random.Random(5)
+    for _ in range(50):
+        cols = [[rnd.getrandbits(32) for _ in range(3)] for _ in range(16)]   # column i: its three words
+        loaded = {}
+        for lane in range(64):
+            g, i = lane >> 4, lane & 15
+            loaded[lane] = cols[i][2 if g == 3 else g]
+        for lane in range(64):
+            g, i = lane >> 4, lane & 15
+            own = loaded[lane]
+            below = loaded[lane - 16 if g in (1, 2) else lane]
+            sh = (32 - 8 * g) & 31
+            f = (((own << 32) | below) >> sh) & 0xffffffff          # v_alignbit_b32
+            stream = cols[i][0] | (cols[i][1] << 32) | (cols[i][2] << 64)
+            want = (stream >> (24 * g)) & 0xffffff
+            assert f & 0xffffff == want, (lane, hex(f), hex(want))
+            for j in range(8):                                       # k = 8 g + j of the k-step
+                assert (f >> (3 * j)) & 7 == (stream >> (3 * (8 * g + j))) & 7
