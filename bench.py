@@ -162,7 +162,12 @@ def capture(fn, warm=2):
     return g, out
 
 
-def time_events(fn, iters):
+def time_events(fn, iters, warm=10):
+    """ms per call over `iters` calls (HIP events on the current stream), after `warm` untimed calls: a leg that starts right after
+    its stack was built sees the clock ramp for its first milliseconds (round 5, tools/rounds5/g22_warm.py: the first 20 replays of
+    the configs[3] stack ran 1.5-3 % slower than the next 120) -- the headline leg has always had its --warmup steps."""
+    for _ in range(warm):
+        fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):

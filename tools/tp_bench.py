@@ -91,7 +91,9 @@ def _capture(fn, warm=2):
     return g, out
 
 
-def _time(fn, iters):
+def _time(fn, iters, warm=10):
+    for _ in range(warm):   # (untimed: the clock ramp after the stack was built -- bench.time_events)
+        fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
