@@ -292,3 +292,15 @@ def test_gather_columns_argument_checks(lib):
     assert g(64, 128, 256, 4, 4100, _lib.DT_F16, None) == U                          # K % 8
     assert g(64, 128, 256, 4, 32768, _lib.DT_BF16, None) == U                        # K beyond the LDS row buffers
     assert g(64, 128, 256, 0, 4096, _lib.DT_F16, None) == 0                          # empty batch: nothing launched
+
+
+def test_release_library_has_no_reachable_one_row_tile_panel(lib, monkeypatch):
+    """Round 5: below 17 rows every native layer is on the strips -- the shipped library is the release build (its knobs are compile-time
+    constants: an environment variable cannot bring the round-4 route back) and announces no panel plan there, whatever the shape."""
+    assert lib.qllm_is_lab_build() == 0
+    monkeypatch.setenv("QLLM_PANEL_MIN_M", "9")
+    for K, N, g, bits, lay in ((11008, 4096, 128, 4, NATIVE), (11008, 4096, 64, 4, NATIVE_F16Z), (11008, 4096, 64, 3, NATIVE_F16Z),
+                               (28672, 8192, 128, 4, NATIVE), (4096, 4096, 32, 4, NATIVE), (8192, 1024, 128, 4, NATIVE)):
+        for m in range(2, 17):
+            assert plan(lib, [W(K, N, g, bits, lay)], m).startswith("strip "), (K, N, g, bits, m)
+        assert plan(lib, [W(K, N, g, bits, lay)], 33).startswith("panel "), (K, N, g, bits)
