@@ -388,15 +388,51 @@ def stub_main(args, world, rank):
         t = torch.tensor([wall], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t[0])
+    result = {"metric": "decode_tokens_per_s_llama2_7b_w4a16_g128_linear_stack", "value": None, "unit": "tokens/s",
+              "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(wall * 1e3 / args.steps, 4),
+              "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16",
+              "data": "STUB (QLLM_BENCH_STUB=1: launch-path test on CPU, not a measurement)",
+              "config": {"workload": "stub", "parallelism": f"replicas x{world}", "backend": "gloo" if world > 1 else None},
+              "roofline": None, "cpu_baseline": None}
+    if world > 1:   # the same second leg as the real run: every rank enters it, rank 0 gets the record (watchdog included)
+        from tools import tp_bench
+        tp_leg_guarded(result, rank, lambda: tp_bench.stub_measure(args, world, rank), args.tp_timeout_s)
     if rank == 0:
-        print(json.dumps({"metric": "decode_tokens_per_s_llama2_7b_w4a16_g128_linear_stack", "value": None, "unit": "tokens/s",
-                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(wall * 1e3 / args.steps, 4),
-                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16",
-                          "data": "STUB (QLLM_BENCH_STUB=1: launch-path test on CPU, not a measurement)",
-                          "config": {"workload": "stub", "parallelism": f"replicas x{world}", "backend": "gloo" if world > 1 else None},
-                          "roofline": None, "cpu_baseline": None}), flush=True)
+        print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def tp_leg_guarded(result, rank, leg, timeout_s):
+    """`--gpus N` (N > 1), after the replica measurement: the tensor-parallel leg of BASELINE configs[4] (Llama-2-70B sharded over the
+    run's N ranks, tools/tp_bench.py) -> result["extra"]["tp70b"].  The replica line must survive whatever that leg does on hardware
+    it has never run on (round-5 verdict: "the first 8-GPU lease must not come back empty"): an exception is recorded in the object;
+    a leg still running after `timeout_s` (a rank stuck in a collective) makes rank 0 print the line WITH the replica numbers and an
+    error entry and every rank leave with os._exit(0) -- the stuck collective cannot be joined."""
+    import threading
+    done = threading.Event()
+
+    def watchdog():
+        if done.wait(timeout_s):
+            return
+        if rank == 0:
+            result.setdefault("extra", {})["tp70b"] = {"error": f"timeout: the tensor-parallel leg was still running after {timeout_s} s; "
+                                                                "the replica measurement above is unaffected"}
+            print(json.dumps(result), flush=True)
+        else:
+            time.sleep(5.0)   # (rank 0 prints first: a launcher may tear the job down when the first rank leaves)
+        os._exit(0)
+
+    threading.Thread(target=watchdog, daemon=True).start()
+    try:
+        rec = leg()
+        if rank == 0:
+            result.setdefault("extra", {})["tp70b"] = rec
+    except BaseException as e:  # noqa: BLE001  (SystemExit included: the line is printed by the caller either way)
+        if rank == 0:
+            result.setdefault("extra", {})["tp70b"] = {"error": f"{type(e).__name__}: {e}"}
+    finally:
+        done.set()
 
 
 def main():
@@ -408,6 +444,9 @@ def main():
                     help="1: sibling groups (q/k/v and gate/up as one grouped launch each: 4 launches per layer instead of 7)")
     ap.add_argument("--tp", type=int, default=0, help="Llama-2-70B tensor-parallel leg (BASELINE configs[4]); 1 = shard shapes on one GPU")
     ap.add_argument("--tp-layers", type=int, default=0, help="--tp: decoder layers of the stack (default: all 80)")
+    ap.add_argument("--tp-timeout-s", type=float, default=420.0,
+                    help="--gpus N > 1: seconds the tensor-parallel leg behind extra.tp70b may take before the line is printed without it")
+    ap.add_argument("--no-tp-leg", action="store_true", help="--gpus N > 1: replicas only, no extra.tp70b")
     ap.add_argument("--no-extra", action="store_true", help="skip the per-shape / prefill / CPU legs")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 PMC passes behind roofline.traffic")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
@@ -428,12 +467,20 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (or run without a launcher: bench.py starts the ranks itself)")
     if os.environ.get("QLLM_BENCH_STUB") == "1":
         return stub_main(args, world, rank)
+    # QLLM_BENCH_SHARE_GPU0=1 (tests/test_tp_collective_gpu.py on the 1-GPU box): every rank on cuda:0 and gloo over device tensors --
+    # RCCL refuses two ranks on one device.  The line says so (config.backend "gloo"); never set by the driver.
+    share_gpu0 = os.environ.get("QLLM_BENCH_SHARE_GPU0") == "1"
+    if share_gpu0:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share_gpu0:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from qllm_amd import _lib
     from qllm_amd.modeling.q_layers import QuantLinearGPTQ, WQLinear_GEMM
@@ -613,6 +660,19 @@ def main():
         result["cpu_baseline"] = cpu_baseline_leg(dev)
     elif rank == 0:
         result["cpu_baseline"] = None
+
+    if world > 1 and not args.no_tp_leg:
+        # BASELINE configs[4] on the ranks of THIS run: Llama-2-70B column / row-parallel over `world` GPUs, one all-reduce per
+        # Megatron pair (tools/tp_bench.measure) -- the driver's scaling run only ever passes --gpus N, so the leg rides on its line
+        from tools import tp_bench
+        try:
+            del graph
+        except NameError:
+            pass
+        del stack
+        torch.cuda.empty_cache()
+        tp_leg_guarded(result, rank, lambda: tp_bench.summary(tp_bench.measure(args, world, rank, dev, info)) if rank == 0
+                       else tp_bench.measure(args, world, rank, dev, info), args.tp_timeout_s)
 
     if rank == 0:
         print(json.dumps(result), flush=True)

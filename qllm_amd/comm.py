@@ -126,16 +126,25 @@ class OneShotAllReduce:
         if (self.world == 1 or self.disabled_reason is not None or x2d.shape[0] != 1 or x2d.dtype not in (torch.float16, torch.bfloat16)
                 or out.dtype != x2d.dtype):
             return False
-        if w.N * 2 > self.slot_bytes or w.N % 16 or out.data_ptr() % 16 or x2d.data_ptr() % 16:
+        if w.N * 2 > self.slot_bytes or w.N % 16:
             return False
+        # Rank-local pointer alignment must not pick the path: a misaligned input / output is staged through an aligned
+        # scratch tensor (torch allocations are 256-byte aligned), exactly as all_reduce() does.  (Should a rank still end in the
+        # unfused pair -- UNSUPPORTED below is decided from the layer's shape and layout, which the ranks of a tensor-parallel layer
+        # share -- the two forms interoperate: same slots, epochs and flags.)
+        xin = x2d if x2d.is_contiguous() and x2d.data_ptr() % 16 == 0 else x2d.contiguous().clone()
+        direct = out.is_contiguous() and out.data_ptr() % 16 == 0
+        dst = out if direct else torch.empty(out.shape, dtype=out.dtype, device=out.device)
         with torch.cuda.device(self.device):
-            rc = self._lib.qllm_linear_forward_allreduce(C.byref(w), x2d.data_ptr(), out.data_ptr(), 1,
+            rc = self._lib.qllm_linear_forward_allreduce(C.byref(w), xin.data_ptr(), dst.data_ptr(), 1,
                                                          _lib.DT_F16 if x2d.dtype == torch.float16 else _lib.DT_BF16,
                                                          self._table.data_ptr(), self.rank, self.world, self.slot_bytes,
                                                          self._status.data_ptr(), torch.cuda.current_stream().cuda_stream)
         if rc == _lib.QLLM_ERR_UNSUPPORTED:
             return False
         _lib.check(rc)
+        if not direct:
+            out.copy_(dst)
         return True
 
     def check(self):

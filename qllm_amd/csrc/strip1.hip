@@ -64,8 +64,10 @@ int launch_strip1_allreduce(const Strip1Params &p, int nw, int maxs, int n_strip
   if (nw == 7 && maxs == 16) return launch_ar<7, 16>(p, n_strips, stream);
   if (nw == 8 && maxs == 24) return launch_ar<8, 24>(p, n_strips, stream);
   if (nw == 8 && maxs == 32) return launch_ar<8, 32>(p, n_strips, stream);
+  if (nw == 16 && maxs == 16) return launch_ar<16, 16>(p, n_strips, stream);
   if (nw == 16 && maxs == 24) return launch_ar<16, 24>(p, n_strips, stream);
   if (nw == 15 && maxs == 24) return launch_ar<15, 24>(p, n_strips, stream);
+  if (nw == 16 && maxs == 32) return launch_ar<16, 32>(p, n_strips, stream);   // K per rank up to 16384 (Llama-2-70B down_proj at TP = 2)
   return set_error(QLLM_ERR_UNSUPPORTED, "fused all-reduce: no batch-1 instantiation for nw=%d round=%d", nw, maxs);
 }
 

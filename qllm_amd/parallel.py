@@ -237,6 +237,7 @@ class RowParallelQuantLinear(nn.Module):
         self.static_output = static_output
         self.reducer = reducer
         self.fuse_reduce = fuse_reduce   # batch 1 + one-shot reducer: GEMV and all-reduce in one launch (False: two launches)
+        self._fuse_refused: set = set()  # activation dtypes for which the library refused the fused launch (shape / layout: final)
         self._bufs: dict = {}
 
     @classmethod
@@ -257,7 +258,7 @@ class RowParallelQuantLinear(nn.Module):
         # (input_is_parallel with an act-order shard: the producer was sharded with columns=shard.input_index)
         x = x.contiguous()
         fuse = (world > 1 and self.fuse_reduce and self.reducer is not None and x.is_cuda and x.numel() == x.shape[-1]
-                and hasattr(self.shard, "forward_allreduce_into"))
+                and x.dtype not in self._fuse_refused and hasattr(self.shard, "forward_allreduce_into"))
         if self.static_output or fuse:
             lead = tuple(x.shape[:-1])
             if self.static_output:
@@ -269,8 +270,12 @@ class RowParallelQuantLinear(nn.Module):
                 y = torch.empty(lead + (self.shard.outfeatures,), dtype=x.dtype, device=x.device)
             # batch 1 with a one-shot reducer: the shard's launch pushes its partial outputs to the peers itself and its last block
             # sums -- ONE launch instead of GEMV + all-reduce (csrc/strip1_kernel.hpp, AR); bit-identical to the two-step path
-            if fuse and self.shard.forward_allreduce_into(x, y.view(-1, self.shard.outfeatures), self.reducer):
-                return y
+            if fuse:
+                if self.shard.forward_allreduce_into(x, y.view(-1, self.shard.outfeatures), self.reducer):
+                    return y
+                # refused (3 bits, g != 128, K beyond the batch-1 forms ...): a property of the layer, not of the call -- do not pay
+                # for a descriptor, a library call and an error string on every later token
+                self._fuse_refused.add(x.dtype)
             self.shard.forward_into(x, y.view(-1, self.shard.outfeatures))
         else:
             y = self.shard(x)

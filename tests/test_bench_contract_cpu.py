@@ -49,6 +49,20 @@ def test_gpus_n_starts_its_own_ranks():
     assert len(lines) == 1, r.stdout
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1 and "STUB" in rec["data"]
+    # ... and the tensor-parallel leg of BASELINE configs[4] rides on the same line (round-5 verdict item 2: the driver's scaling run
+    # only passes --gpus N): same keys as the real leg's record, stub-marked
+    tp = rec["extra"]["tp70b"]
+    for key in ("tokens_per_s", "ms_per_step", "ranks_seen", "backend", "all_reduce_us_16KB", "oneshot_all_reduce_us_16KB",
+                "row_parallel_sums", "ms_per_step_fused_all_reduce", "ms_per_step_unfused_all_reduce", "sharded_vs_unsharded", "tp_degree"):
+        assert key in tp, key
+    assert tp["ranks_seen"] == 2 and tp["backend"] == "gloo" and tp["tp_degree"] == 2 and "stub" in tp
+    # a rank stuck in the leg's collectives must not cost the run its line: the watchdog prints the replica numbers with an error entry
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--tp-timeout-s", "4"],
+                       env=dict(env, QLLM_BENCH_STUB_HANG="1"), capture_output=True, text=True, timeout=240)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, (r.stdout, r.stderr[-2000:])
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and "timeout" in rec["extra"]["tp70b"]["error"]
     # under a launcher that set WORLD_SIZE the flag must agree with it
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="3", RANK="0"),
                        capture_output=True, text=True, timeout=60)

@@ -187,22 +187,26 @@ def verify_sharding(world, rank, dev, group=None):
         print(f"[tp_bench] sharded == unsharded on {world} rank(s): column-parallel bit-exact, Megatron pairs rel err {report}", flush=True)
     del q, o, gate, down
     torch.cuda.empty_cache()
+    return report
 
 
-def run(args, world, rank, dev, info):
-    """bench.py --tp N: N ranks (or 1 rank running the TP=8 shard shapes without a collective).  `args.tp_layers` (default: all
-    80) shortens the stack for smoke runs (tests/test_tp_collective_gpu.py drives this function with two gloo ranks on one GPU,
-    so that the first 8-GPU lease is not its first execution)."""
+def measure(args, world, rank, dev, info):
+    """The tensor-parallel leg on `world` ranks (or 1 rank running the TP=8 shard shapes without a collective): returns the record
+    on rank 0, None on the others.  EVERY rank must call it (collectives inside).  `args.tp_layers` (default: all 80) shortens the
+    stack for smoke runs (tests/test_tp_collective_gpu.py drives this function with two gloo ranks on one GPU, so that the first
+    8-GPU lease is not its first execution).  Callers: run() (`bench.py --tp N`) and bench.py's `--gpus N` run, which puts the
+    record on its JSON line as extra.tp70b (round-5 verdict: the driver only ever passes --gpus N)."""
     import torch.distributed as dist
     P = world if world > 1 else 8
-    if world > 1 and args.tp != world:
+    if world > 1 and getattr(args, "tp", 0) not in (0, world):   # (0: bench.py --gpus N without --tp: the degree is the world size)
         raise SystemExit(f"--tp {args.tp} needs --gpus {args.tp} (one rank per GPU)")
     n_layers = int(getattr(args, "tp_layers", 0) or L70)
     backend = dist.get_backend() if world > 1 else None
     if rank == 0:
         print(f"[tp_bench] world_size={dist.get_world_size() if world > 1 else 1} backend={backend} tp_degree={P} layers={n_layers}", flush=True)
+    parity = None
     if world > 1:
-        verify_sharding(world, rank, dev)
+        parity = verify_sharding(world, rank, dev)
     # the timed stack is built at shard shapes from per-rank seeds (as good as slices of synthetic full-size integers and 8 x
     # less to generate; the slicing itself was just verified on one full-size layer)
     # decode-sized all-reduces ([1, 8192] fp16 = 16 KB): the one-shot peer-write kernel (qllm_amd/comm.py) unless QLLM_TP_ONESHOT=0
@@ -234,7 +238,9 @@ def run(args, world, rank, dev, info):
     # Any other backend (gloo: host-side collectives) runs eagerly BY DESIGN; a failed RCCL capture is reported, not hidden.
     # (round 5: with the one-shot reducer every sum of the step is one of the library's own kernels -- fused into the row-parallel
     #  launch at batch 1 -- so the step captures whatever the backend)
-    want_graph = world == 1 or ((backend == "nccl" or reducer is not None) and os.environ.get("QLLM_TP_GRAPH", "1") != "0")
+    #  -- a reducer whose self-test failed serves nothing: its sums are dist.all_reduce calls again, host-side under gloo)
+    oneshot_live = reducer is not None and reducer.disabled_reason is None
+    want_graph = world == 1 or ((backend == "nccl" or oneshot_live) and os.environ.get("QLLM_TP_GRAPH", "1") != "0")
     graph_mode = "eager (backend %s: collectives are not stream operations)" % backend if not want_graph else None
     run_step = step
     out = None
@@ -324,8 +330,9 @@ def run(args, world, rank, dev, info):
             ar1_us = _time(lambda: reducer.all_reduce(buf), 200) * 1e3
             reducer.check()
     nbytes = shard_bytes_per_token(P, n_layers, M)
+    rec = None
     if rank == 0:
-        print(json.dumps({
+        rec = {
             "metric": "decode_tokens_per_s_llama2_70b_w4a16_g128_linear_stack_tp", "value": round(M * args.steps / wall, 2),
             "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
@@ -341,8 +348,69 @@ def run(args, world, rank, dev, info):
             "oneshot_all_reduce_us_16KB": None if ar1_us is None else round(ar1_us, 2), "row_parallel_sums": reducer_mode,
             "ms_per_step_unfused_all_reduce": None if ms_unfused is None else round(ms_unfused, 4),
             "ms_per_step_fused_all_reduce": None if ms_unfused is None else round(ms_fused, 4),
-            "cpu_baseline": None}), flush=True)
+            "sharded_vs_unsharded": None if parity is None else {"column_parallel": "bit-exact", "megatron_pairs_rel_err": parity},
+            "cpu_baseline": None}
     if reducer is not None:
         reducer.close()
+    del blocks
+    torch.cuda.empty_cache()
+    return rec
+
+
+def stub_measure(args, world, rank):
+    """QLLM_BENCH_STUB=1 (tests/test_bench_contract_cpu.py, no GPU): the collective pattern of measure() -- broadcast of the input,
+    barriers, max-over-ranks of the wall time -- on gloo with a trivial CPU step, so that `bench.py --gpus N` carries an
+    extra.tp70b object whose keys are the real leg's.  Marked as a stub; carries no measurement."""
+    import torch.distributed as dist
+    h0 = torch.ones(1, 8)
+    if os.environ.get("QLLM_BENCH_STUB_HANG") == str(rank):   # (the watchdog's test: this rank never reaches the collective)
+        time.sleep(3600)
+    if world > 1:
+        dist.broadcast(h0, 0)
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        h0 = h0 * 1.0
+    if world > 1:
+        dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank != 0:
+        return None
+    return summary({"value": None, "ms_per_step": round(float(t[0]) * 1e3 / max(args.steps, 1), 4), "n_gpus": world,
+                    "config": {"workload": "stub", "tp_degree": world, "ranks_seen": dist.get_world_size() if world > 1 else 1,
+                               "backend": dist.get_backend() if world > 1 else None, "graph": None, "layers": 0,
+                               "row_parallel_all_reduce_fused_into_gemv": None},
+                    "roofline": None, "all_reduce_us_16KB": None, "oneshot_all_reduce_us_16KB": None,
+                    "row_parallel_sums": "STUB", "ms_per_step_unfused_all_reduce": None, "ms_per_step_fused_all_reduce": None,
+                    "sharded_vs_unsharded": None}, stub=True)
+
+
+def summary(rec, stub=False):
+    """extra.tp70b of bench.py's `--gpus N` line: the tensor-parallel record, flattened to the keys the round-5 verdict names."""
+    c = rec["config"]
+    out = {"what": "Llama-2-70B AWQ w4 g128 decode, batch 1, column/row-parallel over the run's ranks, one all-reduce per Megatron pair "
+                   "(BASELINE configs[4]; tools/tp_bench.py)",
+           "tokens_per_s": rec["value"], "ms_per_step": rec["ms_per_step"], "tp_degree": c["tp_degree"], "layers": c["layers"],
+           "ranks_seen": c["ranks_seen"], "backend": c["backend"], "graph": c["graph"],
+           "all_reduce_us_16KB": rec["all_reduce_us_16KB"], "oneshot_all_reduce_us_16KB": rec["oneshot_all_reduce_us_16KB"],
+           "row_parallel_sums": rec["row_parallel_sums"],
+           "ms_per_step_fused_all_reduce": rec["ms_per_step_fused_all_reduce"],
+           "ms_per_step_unfused_all_reduce": rec["ms_per_step_unfused_all_reduce"],
+           "reported_step_fuses_all_reduce": c["row_parallel_all_reduce_fused_into_gemv"],
+           "sharded_vs_unsharded": rec["sharded_vs_unsharded"],
+           "per_rank_roofline": rec["roofline"]}
+    if stub:
+        out["stub"] = "QLLM_BENCH_STUB=1: launch-path test on CPU, not a measurement"
+    return out
+
+
+def run(args, world, rank, dev, info):
+    """bench.py --tp N: the tensor-parallel leg as the run's ONE JSON line."""
+    import torch.distributed as dist
+    rec = measure(args, world, rank, dev, info)
+    if rank == 0:
+        print(json.dumps(rec), flush=True)
     if world > 1 and not getattr(args, "keep_process_group", False):
         dist.destroy_process_group()
