@@ -13,3 +13,5 @@ $HIPCC --offload-arch=gfx950 -O3 -I $R/include -o $R/tools/lab/gbench $R/tools/l
 $HIPCC --offload-arch=gfx950 -O3 -I $R/include -o $R/tools/lab/gbench_lab $R/tools/lab/gbench.cpp -L $R/tools/lab -lqllm_lab -Wl,-rpath,'$ORIGIN'
 $HIPCC --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I $R/include -I $R/qllm_amd/csrc -o $R/tools/lab/dbisect $R/tools/lab/dbisect.hip -L $R/tools/lab -lqllm_lab -Wl,-rpath,'$ORIGIN'
 ls -la $R/tools/lab/g4lab $R/tools/lab/cbench $R/tools/lab/cbench_lab $R/tools/lab/dbisect $R/tools/lab/libqllm_lab.so
+# round 6: the chained-links prototype and the batch-1 kernel's A/B variants (its own copy of the kernel header: strip1_lab_kernel.hpp)
+$HIPCC --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I $R/include -I $R/qllm_amd/csrc -I $R/tools/lab -o $R/tools/lab/chainlab $R/tools/lab/chainlab.hip -L $R/tools/lab -lqllm_lab -Wl,-rpath,'$ORIGIN'

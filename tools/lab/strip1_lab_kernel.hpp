@@ -1,0 +1,432 @@
+// Batch-1 decode kernel of the native strip-major layout (round 5): y[1, N] = x . dequant(W) for 4-bit layers with 128-wide groups.
+// The same decomposition as strip_kernel.hpp's lds-slab form -- one block = one 16-column strip for ALL of K, its NW waves split K,
+// every wave issues all of its loads before its first wait, no cross-block reduction -- rebuilt around what a launch costs BESIDES
+// its bytes (profiles/r05_decode_bisect.md: the production kernel ran 1.2-1.5 us per launch above a read + reduce + store skeleton of
+// the same launch shape):
+//
+//   * ONE batch of scalar loads.  The problem (layer) of a grouped launch is blockIdx.y, so the problem record's address depends on
+//     nothing that has to be loaded first: header and record leave together (strip_kernel: n_prob -> block_begin8[1..] -> prob[pi]
+//     -> late header words: 2 dependent round trips on single launches, 3 on gate/up, 4 on q/k/v).  Groups whose layers differ in
+//     width launch max(n_strips) columns of blocks; the surplus blocks leave at once.
+//   * ONE scale and ONE zero-point load per lane.  Lane (g, i) fetches group G0 + g of column i (strip_kernel: every lane all four
+//     groups of its column) and finishes exactly that group:
+//   * one accumulator for all groups.  The A operand's 16 rows are free at batch 1 (one real row): rows 4j..4j+3 carry x on the
+//     k-steps of the wave's group j and zeros elsewhere (the lane's ds_read address is chosen per group, once: no instruction in the
+//     loop), so after the wave's 16 (24) MFMAs lane (g, i) holds  sum_{k in group g} x_k (1024 + q_k)  of column i in its own
+//     accumulator rows -- no accumulator reset per group, no select, and the per-group correction
+//         y_g = s_g (acc_g - (z_g Sx_g + 1024 Sx'_g))
+//     is ONE fma per lane after the last MFMA: s_g and c_g = s_g (z_g Sx_g + 1024 Sx'_g) are computed while the weights are still
+//     in flight (Sx_g / Sx'_g are already in the lane: the 16-lane DPP row reduce of the staging pass leaves group g's sums in
+//     every lane of row g, so they never go through LDS).  strip_kernel did the four groups one after the other on 16 lanes
+//     behind the last MFMA (~100 instructions and a scalar load in the tail).
+//   * chains: the MFMAs alternate between NCH accumulators (k-step s -> chain s % NCH) so that the last k-steps to arrive do not
+//     queue behind one dependent chain.
+//   * the cross-wave and cross-group sum is one pass: every lane stores its value to red[column][wave][g] and the first 16 lanes
+//     of wave 0 read their column's NW x 4 values as float4s.
+//
+// Arithmetic contract: strip_kernel.hpp's (x . s(q - z) for the unrounded W, fp32): raw 0x6400 | nibble patterns as B fragments, the
+// x16 of the odd nibbles undone by staging x / 16 in those A slots, one fp32 correction per group.
+//
+// LVL (lab builds only; the library instantiates LVL = 4): the bisect of tools/lab/dbisect.hip -- 0: loads + xor + reduce + store
+// (the memlab2 skeleton behind this kernel's prologue), 1: + scale / zero loads, 2: + x staged through LDS (permute, Sx / Sx' DPP
+// sums) and the A fragments read back, 3: + pattern build and MFMAs, 4: + corrections = the kernel.
+//
+// Replaces gemv<half> (/root/reference/csrc/ort_cuda/dq_gemv.cu:41-150).
+#pragma once
+#include "kernels.hpp"
+// LAB COPY of qllm_amd/csrc/strip1_kernel.hpp (round 6, tools/lab/chainlab.hip): the product header + the CH (chained) and LABV (variant)
+// template parameters.  The product header does not carry them: restructuring its scale / zero loads into a lambda cost the <8,24>
+// instantiation one spilled register.
+namespace qllm {
+struct Strip1ParamsLab : Strip1Params {
+  // chained form (CH instantiations): polls of the armed input before giving up, and where giving up is reported (nullable)
+  uint32_t ch_spin_limit;
+  int *ch_err;
+};
+}  // namespace qllm
+
+namespace qllm {
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_add1(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
+// bytes of LDS per block: red[16 columns][36 floats >= NW * 4] | per wave: staged x (XL KB) + 256 zero bytes
+// floats per column of the reduction buffer: NW x 4 values, rows 16-byte aligned and never a multiple of 32 floats apart (7 and 15
+// waves would otherwise put all 16 columns on the same banks)
+constexpr int strip1_rs(int nw) { return nw * 4 + 4 + (((nw * 4 + 4) % 32 == 0) ? 4 : 0); }
+
+template <int NW, int MAXS>
+constexpr int strip1_lds_bytes() {
+  constexpr int XL = (MAXS * 4 + 63) / 64;
+  static_assert(NW * 4 <= 64, "at most 16 waves");
+  return 16 * strip1_rs(NW) * 4 + NW * (XL * 1024 + 256);
+}
+
+// NW waves x MAXS k-steps cover T (host: NW * MAXS >= T >= MAXS; EXACT: NW * MAXS == T, no masking of a shifted window)
+// AR: the row-parallel form (one layer per launch, p.ar_* set): instead of storing y the block pushes its 16 partial outputs, rounded to
+//     the activation type like the unfused path's y, into slot [parity][rank] of EVERY peer's staging buffer (comm.hip's layout and
+//     protocol) and takes a ticket; the rank's last block publishes the world's flags, waits for the peers' and writes the sum of the
+//     slots in rank order -- the o_proj / down_proj launch and its all-reduce are ONE launch (160 kernel boundaries per Llama-2-70B token).
+// CH: the chained form (tools/lab/chainlab.hip, round 6): the launch may be resident BEFORE its input exists.  Every wave issues its
+//     weight loads first and then polls its own chunk of x IN BAND -- the producer's output buffer is armed with 0xFFFF halves (a NaN
+//     pattern no result can take: the store below rewrites it) before the step, the producer stores write-through, the consumer reads
+//     with L1-bypassing loads until no half of its chunk is 0xFFFF (bounded: p.ch_err) -- and stores its own y write-through.
+// LABV (lab instantiations only; 0 in the library): bit 0 -- y stored write-through (sc1) like the AR / CH forms; bit 1 -- scale and zero
+//     point of a (group, column) as ONE dword {fp16 scale | zero << 16} read from pr.scales as [strip][group][16] words (a synthetic
+//     buffer in tools/lab/chainlab.hip: one request per wave instead of two); bit 2 -- the scale / zero loads issued BEHIND the weights;
+//     bit 3 -- the scale fetched as a dword (lane pairs share it) instead of a 2-byte load, layout unchanged.
+template <int NW, int MAXS, bool EXACT, int NCH = 2, int LVL = 4, bool DBG = false, bool AR = false, bool CH = false, int LABV = 0>
+// (second launch bound = minimum waves per SIMD: 64 registers up to rounds of 24 k-steps -- a CU full of waves -- 128 above)
+__global__ __launch_bounds__(NW * 64, (MAXS <= 24) ? 8 : 4) void strip1_kernel(const Strip1ParamsLab p) {
+  static_assert(MAXS % 4 == 0 && MAXS >= 8 && MAXS <= 32, "rounds are whole 128-wide groups, at most 8 of them");
+  constexpr int NG = MAXS / 4;            // groups per wave
+  constexpr int NPASS = (NG + 3) / 4;     // accumulator sets: groups 0-3, groups 4-7
+  constexpr int XL = (MAXS * 4 + 63) / 64;  // 16-byte activation chunks per lane
+  constexpr int RS = strip1_rs(NW);       // floats per column of the reduction buffer (16-byte aligned rows, 2-way banks at most)
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, i = lane & 15;
+  const int b = blockIdx.x;
+  // the problem record and the header in ONE batch of scalar loads: the empty asm "uses" every word here, so hipcc cannot leave
+  // any of them for a second round trip behind the surplus-block test
+  const Strip1Problem pr = p.prob[blockIdx.y];
+  asm volatile("" ::"s"(pr.qweight), "s"(pr.scales), "s"(pr.qzeros), "s"(pr.bias), "s"(pr.y), "s"(pr.n_strips), "s"(pr.zero_kind), "s"(p.x),
+               "s"(p.T), "s"(p.n_groups), "s"(p.add_zero_bias), "s"(p.act_bf16));
+  uint64_t *dbg_slot = nullptr;
+  if constexpr (DBG) {
+    if (p.dbg && wave == 0 && blockIdx.y == 0) {
+      if (b == 0) dbg_slot = p.dbg;
+      else if (b == (int)gridDim.x / 2) dbg_slot = p.dbg + 8;
+      else if (b == (int)gridDim.x - 1) dbg_slot = p.dbg + 16;
+    }
+    if (dbg_slot && lane == 0) dbg_slot[0] = __builtin_amdgcn_s_memrealtime();
+  }
+  if (b >= pr.n_strips) return;  // (groups of layers of different widths)
+
+  const int T = p.T;
+  const int t0 = wave * MAXS;                              // the wave owns k-steps [t0, min(t0 + MAXS, T))
+  const int tb = EXACT ? t0 : min(t0, T - MAXS);           // its window [tb, tb + MAXS): shifted back into the strip at the end of K
+  // ---- every load of the wave, back to back: x chunk(s), one scale + one zero word per pass, MAXS weight words -----------------
+  uint4_t xa[XL];
+  bool xkeep[XL];
+#pragma unroll
+  for (int u = 0; u < XL; ++u) {
+    const int c = lane + 64 * u;                           // 16-byte chunk of the window: k-step tb + c / 4
+    const int cc = min(c, MAXS * 4 - 1);
+    if constexpr (!CH) xa[u] = *(const uint4_t *)((const uint16_t *)p.x + 32 * tb + 8 * cc);
+    const int t = tb + (c >> 2);
+    xkeep[u] = EXACT ? (c < MAXS * 4) : (c < MAXS * 4 && t >= t0 && t < T);
+  }
+  const int G0 = tb >> 2;
+  const size_t grow = (size_t)b * p.n_groups + G0;         // first group row of the wave in the strip's scale / zero tables
+  const int zk = pr.zero_kind;
+  const uint32_t *zbase = (zk == ZK_SYM) ? (const uint32_t *)pr.scales : (const uint32_t *)pr.qzeros;
+  const int zmul = (zk == ZK_PACKED) ? 2 : 8;              // dwords per group row
+  const int zoff = (zk == ZK_PACKED) ? (i >> 3) : (i >> 1);
+  half_t sc[NPASS];
+  uint32_t zraw[NPASS];
+  auto load_sz = [&]() {
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const int gj = min(4 * ps + g, NG - 1);                // (lanes past the last group re-read it; their sums of x are zero)
+      if constexpr (LABV & 2) {
+        const uint32_t v = ((const uint32_t *)pr.scales)[(grow + gj) * 16 + i];
+        sc[ps] = __builtin_bit_cast(half_t, (uint16_t)(v & 0xffffu));
+        zraw[ps] = (v >> 16) << (4 * (i & 7));               // (the lab buffer carries the zero point as a plain integer)
+      } else if constexpr (LABV & 8) {
+        // the scale as a DWORD load (lanes i, i ^ 1 fetch the same word and take their half): no sub-dword vector load
+        const uint32_t v = ((const uint32_t *)pr.scales)[(grow + gj) * 8 + (i >> 1)];
+        sc[ps] = __builtin_bit_cast(half_t, (uint16_t)((i & 1) ? (v >> 16) : (v & 0xffffu)));
+        zraw[ps] = zbase[(grow + gj) * zmul + zoff];
+      } else {
+        sc[ps] = pr.scales[(grow + gj) * 16 + i];
+        zraw[ps] = zbase[(grow + gj) * zmul + zoff];
+      }
+    }
+  };
+  if constexpr (!(LABV & 4)) load_sz();
+  const uint32_t *wl = pr.qweight + ((size_t)b * T + tb) * 64 + lane;
+  uint32_t w[MAXS];
+#pragma unroll
+  for (int s = 0; s < MAXS; ++s) w[s] = __builtin_nontemporal_load(wl + s * 64);
+  if constexpr (LABV & 4) load_sz();
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (DBG) {
+    if (dbg_slot && lane == 0) dbg_slot[1] = __builtin_amdgcn_s_memrealtime();
+  }
+  if constexpr (CH) {
+    // ---- the input, in band: poll this wave's chunk(s) until every half has been written (loads return in order: the first answer
+    //      arrives behind the wave's weights) ---------------------------------------------------------------------------------------
+    unsigned spins = 0;
+    for (;;) {
+      bool armed = false;
+#pragma unroll
+      for (int u = 0; u < XL; ++u) {
+        const int cc = min(lane + 64 * u, MAXS * 4 - 1);
+        const uint64_t *src = (const uint64_t *)((const uint16_t *)p.x + 32 * tb + 8 * cc);
+        const uint64_t lo = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint64_t hi = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        xa[u] = uint4_t{(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
+        // a 16-bit field of ~v is zero <=> that half is 0xFFFF
+        const uint64_t nl = ~lo, nh = ~hi, k1 = 0x0001000100010001ull, k8 = 0x8000800080008000ull;
+        armed = armed || (((nl - k1) & ~nl & k8) != 0) || (((nh - k1) & ~nh & k8) != 0);
+      }
+      if (!__builtin_amdgcn_ballot_w64(armed)) break;
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > p.ch_spin_limit) {  // the producer never wrote (a broken chain): report instead of hanging the GPU
+        if (p.ch_err && lane == 0) *p.ch_err = 1;
+        break;
+      }
+    }
+    if constexpr (DBG) {
+      if (dbg_slot && lane == 0) { dbg_slot[6] = __builtin_amdgcn_s_memrealtime(); dbg_slot[7] = spins; }
+    }
+  }
+
+  // wave-private LDS: staged activations (XL KB: chunk c at 16 c) and 256 zero bytes
+  char *wbase = (char *)lds + 16 * RS * 4 + wave * (XL * 1024 + 256);
+  char *zeros = wbase + XL * 1024;
+  uint32_t fold = 0;  // (LVL < 4: keeps the loaded values alive)
+
+  // ---- activations -> LDS (needs only the OLDEST loads; the weights stay in flight) ---------------------------------------------
+  float sx[XL], sxp[XL];
+  if constexpr (LVL >= 2) {
+#pragma unroll
+    for (int u = 0; u < XL; ++u) asm volatile("" : "+v"(xa[u]));  // (pins the staging below the weight loads: strip_kernel.hpp)
+    *(uint32_t *)(zeros + 4 * lane) = 0u;
+#pragma unroll
+    for (int u = 0; u < XL; ++u) {
+      const half8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+      half8_t xv = p.act_bf16 ? bf16x8_to_h8(xa[u]) : __builtin_bit_cast(half8_t, xa[u]);
+      xv = xkeep[u] ? xv : zero8;
+      const half8_t pv = a_perm_04152637(xv);
+      const half2_t p0 = {pv[0], pv[1]}, p1 = {pv[2], pv[3]}, p2 = {pv[4], pv[5]}, p3 = {pv[6], pv[7]};
+      const half2_t sixteenth = {(half_t)0.0625f, (half_t)0.0625f};
+      const half2_t q1 = p1 * sixteenth, q3 = p3 * sixteenth;
+      const half2_t one = {(half_t)1.f, (half_t)1.f};
+      float a = __builtin_amdgcn_fdot2(p0, one, 0.f, false);
+      a = __builtin_amdgcn_fdot2(p1, one, a, false);
+      a = __builtin_amdgcn_fdot2(p2, one, a, false);
+      a = __builtin_amdgcn_fdot2(p3, one, a, false);
+      float c = __builtin_amdgcn_fdot2(p0, one, 0.f, false);
+      c = __builtin_amdgcn_fdot2(q1, one, c, false);
+      c = __builtin_amdgcn_fdot2(p2, one, c, false);
+      c = __builtin_amdgcn_fdot2(q3, one, c, false);
+      // all-reduce over the 16 lanes of the row (= the 128 k of one group): xor 1, xor 2, half-row mirror, row mirror
+      a = dpp_add1<0xB1>(a); c = dpp_add1<0xB1>(c);
+      a = dpp_add1<0x4E>(a); c = dpp_add1<0x4E>(c);
+      a = dpp_add1<0x141>(a); c = dpp_add1<0x141>(c);
+      a = dpp_add1<0x140>(a); c = dpp_add1<0x140>(c);
+      sx[u] = a; sxp[u] = c;   // lane (g, i): sums of group 4 u + g of the wave
+      *(half8_t *)(wbase + 16 * (lane + 64 * u)) = half8_t{p0.x, p0.y, q1.x, q1.y, p2.x, p2.y, q3.x, q3.y};
+    }
+  } else {
+#pragma unroll
+    for (int u = 0; u < XL; ++u) { fold ^= xa[u].x ^ xa[u].y ^ xa[u].z ^ xa[u].w; sx[u] = 0.f; sxp[u] = 0.f; }
+  }
+  if constexpr (DBG) {
+    if (dbg_slot && lane == 0) dbg_slot[2] = __builtin_amdgcn_s_memrealtime();
+  }
+
+  // ---- per lane: scale and correction of ITS group (pass ps: group 4 ps + g), while the weights are in flight ------------------
+  float sf[NPASS], cf[NPASS];
+  if constexpr (LVL >= 4) {
+    const uint32_t zsel_p = (zk == ZK_PACKED) ? 0xffffffffu : 0u, zsel_h = (zk == ZK_F16) ? 0xffffffffu : 0u;
+    const uint32_t zsel_s = (zk == ZK_SYM) ? __builtin_bit_cast(uint32_t, 8.0f) : 0u;
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const float zp = (float)(((zraw[ps] >> (4 * (i & 7))) + (uint32_t)p.add_zero_bias) & 15u);
+      const float zh = (float)__builtin_bit_cast(half_t, (uint16_t)((i & 1) ? (zraw[ps] >> 16) : (zraw[ps] & 0xffffu)));
+      const float zf = __builtin_bit_cast(float, (__builtin_bit_cast(uint32_t, zp) & zsel_p) | (__builtin_bit_cast(uint32_t, zh) & zsel_h) | zsel_s);
+      sf[ps] = (float)sc[ps];
+      cf[ps] = sf[ps] * __builtin_fmaf(zf, sx[ps], 1024.f * sxp[ps]);
+    }
+  } else if constexpr (LVL >= 1) {
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) fold ^= zraw[ps] ^ (uint32_t)__builtin_bit_cast(uint16_t, sc[ps]);
+  }
+
+  // ---- A fragment addresses: lane (g, i) is row i of the A operand; rows 4 j .. 4 j + 3 belong to group j of the pass -----------
+  // k-step s reads at byte offset 64 s (an immediate): from the staged chunk if the row belongs to the k-step's group, else from
+  // the zero block (whose address is pre-biased by the group's first offset)
+  uint32_t a_addr[NG];
+  const uint32_t xs_lane = (uint32_t)(wbase - (char *)lds) + 16 * g, z_lane = (uint32_t)(zeros - (char *)lds) + 16 * g;
+#pragma unroll
+  for (int j = 0; j < NG; ++j) a_addr[j] = ((i >> 2) == (j & 3)) ? xs_lane : z_lane - 256 * j;
+
+  float4_t acc[NPASS][NCH];
+  const uint32_t mask_lo = nib_mask_vgpr();  // 0x000f000f
+  const uint32_t mask_hi = mask_lo << 4;     // 0x00f000f0
+#pragma unroll
+  for (int s = 0; s < MAXS; ++s) {
+    const int j = s >> 2, ps = j >> 2, ch = s % NCH;
+    if constexpr (LVL >= 2) {
+      const half8_t av = *(const half8_t *)((const char *)lds + a_addr[j] + 64 * s);
+      if constexpr (LVL >= 3) {
+        const uint32_t wv = w[s], w8 = wv >> 8;
+        const half2_t b0 = as_h2((wv & mask_lo) | kMagic), b1 = as_h2((wv & mask_hi) | kMagic);
+        const half2_t b2 = as_h2((w8 & mask_lo) | kMagic), b3 = as_h2((w8 & mask_hi) | kMagic);
+        const half8_t bf = {b0.x, b0.y, b1.x, b1.y, b2.x, b2.y, b3.x, b3.y};
+        const bool first = (s - 16 * ps) < NCH;  // the chain's first k-step of this pass
+        const float4_t cin = first ? float4_t{0.f, 0.f, 0.f, 0.f} : acc[ps][ch];
+        acc[ps][ch] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bf, cin, 0, 0, 0);
+      } else {
+        const uint4_t ar = __builtin_bit_cast(uint4_t, av);
+        fold ^= w[s] ^ ar.x ^ ar.y ^ ar.z ^ ar.w;
+      }
+    } else {
+      fold ^= w[s];
+    }
+  }
+  if constexpr (DBG) {
+    if (dbg_slot && lane == 0) dbg_slot[3] = __builtin_amdgcn_s_memrealtime();
+  }
+
+  // ---- the lane's value: its group's partial of column i; then one pass over [column][wave][g] -------------------------------------
+  float val;
+  if constexpr (LVL >= 3) {
+    float term[NPASS];
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      float a = acc[ps][0][0];
+#pragma unroll
+      for (int ch = 1; ch < NCH; ++ch)
+        if (16 * ps + ch < MAXS) a += acc[ps][ch][0];
+      if constexpr (LVL >= 4) term[ps] = __builtin_fmaf(sf[ps], a, -cf[ps]);
+      else term[ps] = a;
+    }
+    val = term[0];
+    if constexpr (NPASS > 1) val += term[1];
+    if constexpr (LVL < 4) val = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, val) ^ fold);
+  } else {
+    val = __builtin_bit_cast(float, fold);
+  }
+  lds[i * RS + wave * 4 + g] = val;
+  __syncthreads();
+  if constexpr (DBG) {
+    if (dbg_slot && lane == 0) dbg_slot[4] = __builtin_amdgcn_s_memrealtime();
+  }
+  float vfin = 0.f;  // (lanes 0..15 of wave 0: the block's 16 outputs)
+  if (threadIdx.x < 16) {
+    const float4_t *row = (const float4_t *)(lds + threadIdx.x * RS);
+    float4_t t[NW];
+#pragma unroll
+    for (int q = 0; q < NW; ++q) t[q] = row[q];
+    float v;
+    if constexpr (LVL >= 3) {
+#pragma unroll
+      for (int st = 1; st < NW; st *= 2)
+#pragma unroll
+        for (int q = 0; q + st < NW; q += 2 * st) t[q] = t[q] + t[q + st];
+      v = (t[0][0] + t[0][1]) + (t[0][2] + t[0][3]);
+    } else {
+      uint32_t f = 0;
+#pragma unroll
+      for (int q = 0; q < NW; ++q) { const uint4_t r = __builtin_bit_cast(uint4_t, t[q]); f ^= r.x ^ r.y ^ r.z ^ r.w; }
+      v = (float)(f & 1023u);
+    }
+    const int n = b * 16 + threadIdx.x;
+    if (pr.bias) v += (float)pr.bias[n];
+    vfin = v;
+    if constexpr (CH) {
+      uint16_t bits = p.act_bf16 ? f32_to_bf16(v) : __builtin_bit_cast(uint16_t, (half_t)v);
+      if (bits == 0xFFFFu) bits = 0xFE00u;  // (a NaN either way; 0xFFFF is the "not written yet" pattern of the chain)
+      // lanes 2j, 2j + 1 -> one dword, stored write-through by the even lane
+      const uint32_t other = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bits, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
+      if (!(threadIdx.x & 1)) __hip_atomic_store((uint32_t *)pr.y + (n >> 1), (uint32_t)bits | (other << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if constexpr (LABV & 1) {
+      const uint16_t bits = p.act_bf16 ? f32_to_bf16(v) : __builtin_bit_cast(uint16_t, (half_t)v);
+      const uint32_t other = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bits, 0xB1, 0xF, 0xF, true);
+      if (!(threadIdx.x & 1)) __hip_atomic_store((uint32_t *)pr.y + (n >> 1), (uint32_t)bits | (other << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if constexpr (!AR) {
+      if (p.act_bf16) ((uint16_t *)pr.y)[n] = f32_to_bf16(v);
+      else ((half_t *)pr.y)[n] = (half_t)v;
+    }
+  }
+  if constexpr (AR) {
+    // ---- push: the 16 partial outputs as two 16-byte system-scope stores per peer (lanes 0 and 1 of wave 0, through LDS) ------------
+    const int world = p.ar_world, rank = p.ar_rank;
+    const size_t slot = p.ar_slot_bytes, payload = 2 * (size_t)world * slot;
+    CommCtl *own = (CommCtl *)((char *)p.ar_peers[rank] + payload);
+    // (every block reads the epoch before it takes its ticket; the last block bumps it after the last ticket)
+    const uint32_t epoch = __hip_atomic_load(&own->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    const int parity = (int)(epoch & 1u);
+    uint16_t *stage = (uint16_t *)(lds + 16 * RS);  // (the first wave's staging area: its activations are long consumed)
+    int *s_last = (int *)(lds + 16 * RS) + 16;
+    if (wave == 0) {
+      if (lane < 16) stage[lane] = p.act_bf16 ? f32_to_bf16(vfin) : __builtin_bit_cast(uint16_t, (half_t)vfin);
+      if (lane < 2) {
+        const uint4_t chunk = *(const uint4_t *)(stage + 8 * lane);
+        for (int q = 0; q < world; ++q) {
+          char *dst = (char *)p.ar_peers[q] + ((size_t)parity * world + rank) * slot + ((size_t)b * 16 + 8 * lane) * 2;
+          store16_sys(dst, chunk);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-through stores have left ...
+      if (lane == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // ... (system scope) before the ticket says so
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t ticket = __hip_atomic_fetch_add(&own->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *s_last = (ticket == gridDim.x - 1) ? 1 : 0;
+      }
+    }
+    __syncthreads();
+    if (*s_last == 0) return;
+    // ---- the rank's last block: every block's slice is in every peer's slot.  Publish, wait for the world, sum in rank order ----------
+    if (threadIdx.x == 0) __hip_atomic_store(&own->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm (graph replay)
+    if ((int)threadIdx.x < world) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the other blocks' tickets (and the stores in front of them)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      CommCtl *peer = (CommCtl *)((char *)p.ar_peers[threadIdx.x] + payload);
+      __hip_atomic_store(&peer->flag[parity][rank], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      unsigned spins = 0;
+      while (__hip_atomic_load(&own->flag[parity][threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != epoch) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > (1u << 26)) {  // a peer never arrived (seconds): report instead of hanging the GPU
+          if (p.ar_status) *p.ar_status = 1;
+          break;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    }
+    __syncthreads();
+    const char *mine = (const char *)p.ar_peers[rank] + (size_t)parity * world * slot;
+    const int n16 = (int)gridDim.x * 2;  // 16-byte chunks of the output row (16 columns per block)
+    for (int c = threadIdx.x; c < n16; c += NW * 64) {
+      float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      for (int r = 0; r < world; ++r) {
+        const uint4_t v = load16_sys(mine + (size_t)r * slot + (size_t)c * 16);
+        const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (p.act_bf16) {
+            a8[2 * j] += __builtin_bit_cast(float, wds[j] << 16);
+            a8[2 * j + 1] += __builtin_bit_cast(float, wds[j] & 0xffff0000u);
+          } else {
+            const half2_t h = as_h2(wds[j]);
+            a8[2 * j] += (float)h.x;
+            a8[2 * j + 1] += (float)h.y;
+          }
+        }
+      }
+      uint32_t o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (p.act_bf16) o[j] = (uint32_t)f32_to_bf16(a8[2 * j]) | ((uint32_t)f32_to_bf16(a8[2 * j + 1]) << 16);
+        else o[j] = as_u32(half2_t{(half_t)a8[2 * j], (half_t)a8[2 * j + 1]});
+      }
+      *((uint4_t *)pr.y + c) = uint4_t{o[0], o[1], o[2], o[3]};
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(&own->epoch, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if constexpr (DBG) {
+    if (dbg_slot && lane == 0) dbg_slot[5] = __builtin_amdgcn_s_memrealtime();
+  }
+}
+
+}  // namespace qllm
