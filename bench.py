@@ -91,15 +91,17 @@ class Block(torch.nn.Module):
         # q/k/v share one g_idx and gate/up another, as in a real checkpoint; o_proj and down_proj have their own
         def order(K):
             return (torch.arange(K, dtype=torch.int32) // group)[torch.randperm(K)] if act_order else None
-        mk = lambda K, N, gi=None: make_layer(cls, K, N, dev, gen, act_order, bits, group, gi)  # noqa: E731
+        # bits: one width for the layer, or {module name: width} (mixed precision: quant_config_by_layer.json gives every linear its own)
+        wb = (lambda name: bits[name]) if isinstance(bits, dict) else (lambda name: bits)
+        mk = lambda name, K, N, gi=None: make_layer(cls, K, N, dev, gen, act_order, wb(name), group, gi)  # noqa: E731
         g_attn, g_mlp = order(hidden), order(hidden)
-        self.q_proj = mk(hidden, hidden, g_attn)
-        self.k_proj = mk(hidden, kv, g_attn)
-        self.v_proj = mk(hidden, kv, g_attn)
-        self.o_proj = mk(hidden, hidden, order(hidden))
-        self.gate_proj = mk(hidden, inter, g_mlp)
-        self.up_proj = mk(hidden, inter, g_mlp)
-        self.down_proj = mk(inter, hidden, order(inter))
+        self.q_proj = mk("q_proj", hidden, hidden, g_attn)
+        self.k_proj = mk("k_proj", hidden, kv, g_attn)
+        self.v_proj = mk("v_proj", hidden, kv, g_attn)
+        self.o_proj = mk("o_proj", hidden, hidden, order(hidden))
+        self.gate_proj = mk("gate_proj", hidden, inter, g_mlp)
+        self.up_proj = mk("up_proj", hidden, inter, g_mlp)
+        self.down_proj = mk("down_proj", inter, hidden, order(inter))
 
     def forward(self, h):
         q = self.q_proj(h)
@@ -118,7 +120,9 @@ class Stack(torch.nn.Module):
         super().__init__()
         from qllm_amd.modeling.q_layers import install_sibling_groups
         gen = torch.Generator(device=dev).manual_seed(seed)
-        self.blocks = torch.nn.ModuleList([Block(cls, dev, gen, act_order, bits=bits, group=group) for _ in range(n_layers)])
+        # bits: one width, or a function of the decoder layer's index returning a width or a {module name: width} dict
+        per_layer = bits if callable(bits) else (lambda i: bits)
+        self.blocks = torch.nn.ModuleList([Block(cls, dev, gen, act_order, bits=per_layer(i), group=group) for i in range(n_layers)])
         self.groups = install_sibling_groups(self, [cls]) if fused else 0
         # the loader's memory policy (modeling/base.load_quantized): one copy of every layer on the device, in the native layout
         from qllm_amd.modeling.base import release_reference_layouts
@@ -243,19 +247,34 @@ def cpu_baseline_leg(dev):
                 gpu_vs_cpu_rel_err_11008x4096=round(rel, 6))
 
 
+LINEARS = (("q_proj", HIDDEN, HIDDEN), ("k_proj", HIDDEN, HIDDEN), ("v_proj", HIDDEN, HIDDEN), ("o_proj", HIDDEN, HIDDEN),
+           ("gate_proj", HIDDEN, INTER), ("up_proj", HIDDEN, INTER), ("down_proj", INTER, HIDDEN))
+# the two ways a mixed-precision recipe assigns widths (BASELINE configs[3] "mixed 3/4-bit layers"): by decoder layer, or by module kind
+MIX_BY_LAYER = lambda i: 4 if i % 2 == 0 else 3  # noqa: E731
+MIX_BY_MODULE = lambda i: {"q_proj": 3, "k_proj": 3, "v_proj": 4, "o_proj": 4, "gate_proj": 3, "up_proj": 3, "down_proj": 4}  # noqa: E731
+
+
 def hqq_leg(dev, n_layers=LAYERS):
     """BASELINE configs[3]: HQQ g64 fp16 zeros, batch 16, 4-bit and 3-bit decoder layers (the reference mixes them per layer).
     A stack of the model's depth for each width (32 layers: one hipGraph per batch step, like the headline leg -- a four-layer
     graph, rounds 3-4, charged the replay boundary of a step to four layers instead of 32: ~1.5 us per layer), through the modules
-    with the loader's sibling groups; the 7-launch form beside it."""
+    with the loader's sibling groups; the 7-launch form beside it.  Round 6: the same stack as ONE mixed model -- widths alternating
+    by decoder layer (`hqq_mixed34_by_layer`), and by module kind (`hqq_mixed34_by_module`: q / k / gate / up at 3 bits, v / o / down
+    at 4 -- q/k share a grouped launch, v runs alone: 5 launches per layer)."""
     extra = {}
     from qllm_amd.modeling.q_layers import QuantLinearHQQ
     x16 = torch.randn(16, HIDDEN, device=dev, dtype=torch.float16)
-    for bits_sel, tag in ((4, "hqq_w4_g64_m16"), (3, "hqq_w3_g64_m16")):
-        hs = Stack(QuantLinearHQQ, n_layers, dev, seed=7 + bits_sel, bits=bits_sel, group=64)
+    for bits_sel, tag in ((4, "hqq_w4_g64_m16"), (3, "hqq_w3_g64_m16"), (MIX_BY_LAYER, "hqq_mixed34_by_layer_g64_m16"),
+                          (MIX_BY_MODULE, "hqq_mixed34_by_module_g64_m16")):
+        hs = Stack(QuantLinearHQQ, n_layers, dev, seed=7 + (bits_sel if isinstance(bits_sel, int) else 5), bits=bits_sel, group=64)
         # (only the packed words scale with the bit width: scales, fp16 zero points, x and y do not)
-        nbytes = sum(alg_bytes(K, N, 16, 64, "f16") - K * N // 2 + K * N * bits_sel // 8
-                     for (K, N) in [(HIDDEN, HIDDEN)] * 4 + [(HIDDEN, INTER)] * 2 + [(INTER, HIDDEN)])   # per layer
+        nbytes = 0
+        for i in range(n_layers):
+            wb = bits_sel(i) if callable(bits_sel) else bits_sel
+            for (name, K, N) in LINEARS:
+                b = wb[name] if isinstance(wb, dict) else wb
+                nbytes += alg_bytes(K, N, 16, 64, "f16") - K * N // 2 + K * N * b // 8
+        nbytes /= n_layers   # per layer
         res = {}
         for fz in (True, False):
             hs.set_fused(fz)
@@ -265,7 +284,7 @@ def hqq_leg(dev, n_layers=LAYERS):
             res["grouped" if fz else "ungrouped"] = ms
         extra[tag] = {"ms_per_layer": round(res["grouped"], 4), "GBps": round(nbytes / res["grouped"] / 1e6, 1),
                       "frac_of_hbm_peak": round(nbytes / res["grouped"] / 1e6 / HBM_PEAK_GBPS, 4), "layers": n_layers,
-                      "ms_per_layer_7_launches": round(res["ungrouped"], 4)}
+                      "sibling_groups": hs.groups, "ms_per_layer_7_launches": round(res["ungrouped"], 4)}
         del hs
         torch.cuda.empty_cache()
     return extra

@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define QLLM_ABI_VERSION 5
+#define QLLM_ABI_VERSION 6
 
 typedef enum qllm_status {
   QLLM_OK = 0,
@@ -113,9 +113,19 @@ typedef struct qllm_device_info {
 /* ---- library ------------------------------------------------------------------------------------------- */
 int qllm_abi_version(void);
 /* 1 for a lab build of the library (-DQLLM_LAB: the dispatchers' tuning knobs QLLM_* are re-read from the environment at every call),
- * 0 for the release build (knobs are compile-time constants; only QLLM_NUM_CU is read).  Tools that A/B through the environment
+ * 0 for the release build (knobs are the measured defaults unless set through qllm_set_knob; only QLLM_NUM_CU is read from the environment).  Tools that A/B through the environment
  * assert on it instead of timing the same kernel twice (ABI 5). */
 int qllm_is_lab_build(void);
+/* Planner thresholds (ABI 6).  The kernel-selection tree was measured on Llama-2-7B / 70B shapes (profiles/r06_shape_table.md has other
+ * families); a deployment may move these thresholds without rebuilding.  Process-global, not synchronised with forward calls running on
+ * other threads: set them before serving.  Settable names (values outside the range every built kernel covers are refused):
+ *   QLLM_STRIP1 0|1, QLLM_PANEL 0|1, QLLM_PANEL_MIN_M 17..129, QLLM_PANEL_GROUP_MIN_M 17..129, QLLM_GEMM2 0|1, QLLM_GEMM3 0|1,
+ *   QLLM_GEMM2_MIN_M >= 33, QLLM_GEMM3_MIN_M >= 0 (0: the measured 384 / 768 line), QLLM_GEMM2_SPLITK 0|1, QLLM_GEMM3_TAIL 0|1,
+ *   QLLM_SKINNY_MAX_M 0..64, QLLM_STRIP_MIN >= 0, QLLM_BITGEMV 0|1.
+ * qllm_plan_describe() reflects them (it asks the same decision functions the forward calls execute).  QLLM_ERR_INVALID for any other name. */
+int qllm_set_knob(const char *name, int32_t value);
+int qllm_get_knob(const char *name, int32_t *value, int32_t *is_set);
+void qllm_reset_knobs(void);
 /* Thread-local, never NULL; "" when the calling thread's last call succeeded. */
 const char *qllm_last_error(void);
 /* Fills `out` for HIP device `device`; QLLM_ERR_DEVICE if there is none or it is not gfx950. */

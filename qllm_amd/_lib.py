@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("QLLM_MI355X_LIB") or os.path.join(_HERE, LIB_NAME)  #
 QLLM_OK, QLLM_ERR_INVALID, QLLM_ERR_UNSUPPORTED, QLLM_ERR_WORKSPACE, QLLM_ERR_LAUNCH, QLLM_ERR_DEVICE = range(6)
 LAYOUT_GPTQ, LAYOUT_AWQ_GEMM, LAYOUT_HQQ, LAYOUT_NATIVE, LAYOUT_NATIVE_F16Z = 0, 1, 2, 3, 4
 DT_F16, DT_BF16, DT_F16_IN_BF16_OUT = 0, 1, 2
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 EXPORTS = (
     "qllm_abi_version", "qllm_is_lab_build", "qllm_last_error", "qllm_device_info", "qllm_workspace_bytes", "qllm_workspace_bytes_act", "qllm_workspace_init",
@@ -25,6 +25,7 @@ EXPORTS = (
     "qllm_plan_describe", "qllm_debug_timeline", "qllm_native_sizes", "qllm_repack_native", "qllm_unpack_native",
     "qllm_comm_buffer_bytes", "qllm_comm_alloc", "qllm_comm_free", "qllm_comm_export", "qllm_comm_import", "qllm_comm_close",
     "qllm_allreduce_oneshot", "qllm_linear_forward_allreduce", "qllm_convert_bf16_to_f16",
+    "qllm_set_knob", "qllm_get_knob", "qllm_reset_knobs",
 )
 
 
@@ -66,6 +67,12 @@ def _declare(lib):
     lib.qllm_abi_version.argtypes = []
     lib.qllm_is_lab_build.restype = C.c_int
     lib.qllm_is_lab_build.argtypes = []
+    lib.qllm_set_knob.restype = C.c_int
+    lib.qllm_set_knob.argtypes = [C.c_char_p, i32]
+    lib.qllm_get_knob.restype = C.c_int
+    lib.qllm_get_knob.argtypes = [C.c_char_p, C.POINTER(i32), C.POINTER(i32)]
+    lib.qllm_reset_knobs.restype = None
+    lib.qllm_reset_knobs.argtypes = []
     lib.qllm_last_error.restype = C.c_char_p
     lib.qllm_last_error.argtypes = []
     lib.qllm_device_info.restype = C.c_int

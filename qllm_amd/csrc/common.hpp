@@ -23,13 +23,18 @@ constexpr int kNumCU = 256;  // MI355X: the fallback of compute_units() when no 
 // overrides; kNumCU without a device, so that qllm_plan_describe / qllm_workspace_bytes stay deterministic in CPU-only tests.
 int compute_units();
 
-// Tuning knobs of the dispatchers.  Release build: compile-time constants -- the library reads NO environment variable except
-// QLLM_NUM_CU (capi.hip).  Lab build (`make -C qllm_amd/csrc variant NAME=lab DEFS=-DQLLM_LAB` -> tools/lab/libqllm_lab.so, loaded
-// with QLLM_MI355X_LIB): QLLM_<NAME> is read from the environment at EVERY call, so one process can A/B variants back to back.
+// Tuning knobs of the dispatchers.  Release build: the measured defaults -- the library reads NO environment variable except
+// QLLM_NUM_CU (capi.hip) -- unless the caller overrides a planner threshold through qllm_set_knob() (round 6: the thresholds were
+// measured on two models' shapes; a deployment with other shapes can move them without rebuilding.  Only the names listed in
+// capi.hip's kSettable are accepted, within ranges every built kernel instantiation covers).  Lab build (`make -C qllm_amd/csrc variant
+// NAME=lab DEFS=-DQLLM_LAB` -> tools/lab/libqllm_lab.so, loaded with QLLM_MI355X_LIB): QLLM_<NAME> is also read from the environment at
+// EVERY call, so one process can A/B variants back to back.
+extern int g_knob_overrides;                       // capi.hip: how many overrides are set (0: knob() is its default)
+int knob_override(const char *name, int dflt);     // capi.hip
 #ifdef QLLM_LAB
 int knob(const char *name, int dflt);  // capi.hip
 #else
-constexpr int knob(const char *, int dflt) { return dflt; }
+inline int knob(const char *name, int dflt) { return __atomic_load_n(&g_knob_overrides, __ATOMIC_RELAXED) ? knob_override(name, dflt) : dflt; }
 #endif
 
 // zero-point representation, decided on the host from (layout, qzeros)

@@ -70,16 +70,34 @@ __global__ __launch_bounds__((MW + 4) * 64) void gemm3_kernel(const GemmParams p
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = p.N / BN;
   // split-K (p.split_k > 1: fewer tiles than CUs): S consecutive block ids share an output tile and own consecutive K ranges;
   // each publishes its fp32 partial tile to a slab, the last to arrive sums them in fixed order (the protocol of gemm2.hip)
-  const int S = p.split_k;
-  const int nblk = tiles_m * tiles_n * S;
-  int bid = blockIdx.x;
-  {  // each XCD (block id % 8) walks a contiguous run of tiles
-    const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, idx = bid / 8;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  // Round 6, tail split (p.tail_split > 1, tiles > CUs): the tiles of the whole rounds run unsplit; the tiles of the ragged last round
+  // are shared by tail_split blocks each -- two segments of block ids, each walked XCD-contiguously.
+  auto xcd_run = [](int b, int n) {  // each XCD (block id % 8) walks a contiguous run of the n blocks
+    const int q = n / 8, r = n % 8, xcd = b % 8, idx = b / 8;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  };
+  int S, ksplit, tile_id, slab_tile;
+  if (p.tail_split > 1) {
+    const int F = p.tail_from, bid = blockIdx.x;
+    if (bid < F) {
+      S = 1;
+      ksplit = 0;
+      tile_id = slab_tile = xcd_run(bid, F);
+    } else {
+      const int u = xcd_run(bid - F, (tiles_m * tiles_n - F) * p.tail_split);
+      S = p.tail_split;
+      ksplit = u % S;
+      slab_tile = u / S;
+      tile_id = F + slab_tile;
+    }
+  } else {
+    S = p.split_k;
+    const int bid = xcd_run(blockIdx.x, tiles_m * tiles_n * S);
+    ksplit = bid % S;
+    tile_id = slab_tile = bid / S;
   }
-  const int ksplit = bid % S;
-  bid /= S;
-  const int tile_id = bid;
+  S = __builtin_amdgcn_readfirstlane(S);
+  const int bid = tile_id;
   // p.raster 1: n fastest (an XCD's run shares activation rows, which stay in its L2 while the small packed weights stream)
   const int tm = p.raster ? (bid / tiles_n) : (bid % tiles_m);
   const int tn = p.raster ? (bid % tiles_n) : (bid / tiles_m);
@@ -344,7 +362,7 @@ __global__ __launch_bounds__((MW + 4) * 64) void gemm3_kernel(const GemmParams p
   if (S > 1) {
     int &s_ticket = *(int *)(smem + 24 * 1024);  // past the epilogue's wave-private regions (8 x 4.5 KB)
     constexpr int WREGS = AM * 2 * 16;
-    float *slab = p.slabs + ((size_t)tile_id * S + ksplit) * (size_t)(BM * BN) + (size_t)wave * (WREGS * 64) + lane;
+    float *slab = p.slabs + ((size_t)slab_tile * S + ksplit) * (size_t)(BM * BN) + (size_t)wave * (WREGS * 64) + lane;
 #pragma unroll
     for (int a = 0; a < AM; ++a)
 #pragma unroll
@@ -353,7 +371,7 @@ __global__ __launch_bounds__((MW + 4) * 64) void gemm3_kernel(const GemmParams p
         for (int r = 0; r < 16; ++r) st_sc1(slab + ((a * 2 + b) * 16 + r) * 64, acc[a][b][r]);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) s_ticket = __hip_atomic_fetch_add(p.counters + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) s_ticket = __hip_atomic_fetch_add(p.counters + slab_tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     if (s_ticket != S - 1) return;
 #pragma unroll
@@ -363,7 +381,7 @@ __global__ __launch_bounds__((MW + 4) * 64) void gemm3_kernel(const GemmParams p
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     for (int sp = 0; sp < S; ++sp) {
-      const float *src = p.slabs + ((size_t)tile_id * S + sp) * (size_t)(BM * BN) + (size_t)wave * (WREGS * 64) + lane;
+      const float *src = p.slabs + ((size_t)slab_tile * S + sp) * (size_t)(BM * BN) + (size_t)wave * (WREGS * 64) + lane;
 #pragma unroll
       for (int a = 0; a < AM; ++a)
 #pragma unroll
@@ -371,7 +389,7 @@ __global__ __launch_bounds__((MW + 4) * 64) void gemm3_kernel(const GemmParams p
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[a][b][r] += ld_sc1(src + ((a * 2 + b) * 16 + r) * 64);
     }
-    if (tid == 0) __hip_atomic_store(p.counters + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) __hip_atomic_store(p.counters + slab_tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 
   // ---- epilogue: + bias, round once, transpose through wave-private LDS, 16-byte row-contiguous stores ---------------------
@@ -439,7 +457,8 @@ static int launch_gemm3_b(const GemmParams &p, hipStream_t stream) {
   using namespace g3;
   static DeviceLatch attr_done;
   if (int rc = lds_optin(attr_done, (const void *)gemm3_kernel<LAYOUT, MW, PRIO>)) return rc;
-  const int tiles = ((p.M + BM - 1) / BM) * (p.N / BN) * p.split_k;
+  const int tiles_all = ((p.M + BM - 1) / BM) * (p.N / BN);
+  const int tiles = p.tail_split > 1 ? p.tail_from + (tiles_all - p.tail_from) * p.tail_split : tiles_all * p.split_k;
   const size_t lds = (size_t)(3 * kATile + 2 * kBTile) * sizeof(half_t);  // 128 KB
   hipLaunchKernelGGL((gemm3_kernel<LAYOUT, MW, PRIO>), dim3(tiles), dim3((MW + 4) * 64), lds, stream, p);
   QLLM_HIP_CHECK(hipGetLastError());
@@ -454,9 +473,26 @@ int gemm3_split_k(int M, int N, int K) {
   return s;
 }
 
+// Round 6: K-split of the ragged last round.  More tiles than CUs and a last round that fills at most half of them (profiles/
+// r06_shape_table.md: Llama-2-13B's 5120-wide layers are 320 tiles = 1.25 rounds and ran at 767 TFLOP/s where the 256-tile layers
+// of Llama-2-7B run at 970-1070): the r = tiles mod CUs tiles of that round are shared by TS blocks each -- the largest power of two with
+// r * TS <= CUs, whole k-tile counts and >= 16 k-tiles per block (the fix-up moves 2 x 128 KB per block: below that it eats the gain).
+// Returns TS (1: none) and the number of unsplit tiles in *tail_from.
+int gemm3_tail_split(int M, int N, int K, int *tail_from) {
+  const int tiles = ((M + 255) / 256) * (N / 128), cus = compute_units(), kt = K / 64;
+  *tail_from = tiles;
+  if (!knob("QLLM_GEMM3_TAIL", 1) || tiles <= cus || tiles % cus == 0) return 1;
+  const int r = tiles % cus;
+  int ts = 1;
+  while (ts < 8 && r * ts * 2 <= cus && kt % (ts * 2) == 0 && kt / (ts * 2) >= 16) ts *= 2;
+  if (ts > 1) *tail_from = tiles - r;
+  return ts;
+}
+
 int launch_gemm3(const GemmParams &p_in, int layout, hipStream_t stream) {
   GemmParams p = p_in;
   if (p.split_k < 1 || !p.slabs || !p.counters) p.split_k = 1;
+  if (p.tail_split < 2 || !p.slabs || !p.counters || p.split_k != 1) p.tail_split = 0;
   const int raster = knob("QLLM_GEMM2_RASTER", 1);
   p.raster = raster;
 #ifdef QLLM_LAB

@@ -125,6 +125,25 @@ struct Strip1Params {
   uint32_t ar_slot_bytes;
 };
 
+// ---- bitgemv.hip (round 6): fused decode matvec for the widths the MFMA strips do not take (2, 5, 6, 7, 8 bits; row-stream layouts) -----
+constexpr int kBitGemvMaxM = 16;
+struct BitGemvParams {
+  const void *x;
+  const uint32_t *qweight;
+  const half_t *scales;
+  const void *qzeros;
+  const half_t *bias;
+  void *y;
+  float *slabs;   // K-split: [ksplit][M][N] fp32 partial results
+  int *counters;  // K-split: one arrival counter per 32-column block (zero before and after the launch)
+  int M, K, N, group_size, zero_kind, add_zero_bias, act_bf16;
+  int ksplit;                      // blocks along K (1: none)
+  int n_col_blocks, chunk_units;   // set by launch_bitgemv
+};
+bool bitgemv_ok(const qllm_weight_t &w, int M);
+int bitgemv_split(int M, int K, int N);
+int launch_bitgemv(const BitGemvParams &p, int bits, hipStream_t stream);
+
 // ---- comm.hip: staging buffer of one rank = [2 parities][world][slot_bytes] payload | this control block ----------------------------
 constexpr int kCommMaxWorld = 16;
 struct CommCtl {
@@ -171,6 +190,10 @@ struct GemmParams {
   int split_k;      // gemm2: blocks per output tile along K (1 = none)
   float *slabs;     // gemm2 split-K: [tiles][split_k][256 x 128] fp32 partial tiles
   int *counters;    // gemm2 split-K: one arrival counter per output tile (zero before and after the launch)
+  // gemm3, round 6: K-split of the ragged LAST round only.  tail_split > 1: tiles [0, tail_from) run all of K, one block each (whole
+  // rounds of CUs); every tile from tail_from on is shared by tail_split blocks (slab / counter index = tile - tail_from), so that the
+  // last round is as full as the others and 1 / tail_split as long.  split_k must be 1 then.
+  int tail_from, tail_split;
   int prio;         // gemm4: s_setprio values of its wave roles (matrix | dequant << 4 | loader << 8)
   uint64_t *dbg;    // lab builds (-DQLLM_LAB): gemm4 timeline, 16 x u64 per block (tools/lab/g4lab timeline); NULL otherwise
 };
@@ -179,6 +202,7 @@ int launch_gemm(const GemmParams &p, int layout, hipStream_t stream);
 // ---- gemm2.hip (256x256 tile; fp16 activations, trivial groups, N % 256 == 0) -------------------------------------
 bool gemm2_ok(const GemmParams &p, int layout);
 int gemm2_split_k(int M, int N, int K);
+int gemm3_tail_split(int M, int N, int K, int *tail_from);  // gemm3.hip: K-split factor of the ragged last round of tiles (1: none)
 int gemm2_tile_n(int M, int N, int split_k);
 size_t gemm2_slab_bytes(int M, int N, int S);
 int launch_gemm2(const GemmParams &p, int layout, hipStream_t stream);

@@ -108,8 +108,16 @@ def fuse_siblings(layers: Sequence[torch.nn.Module]) -> SiblingGroup:
     return g
 
 
+def _group_key(l):
+    """What the layers of one grouped launch must agree on (qllm_linear_forward_grouped: K, bits, group size, layout family)."""
+    return (type(l), l.infeatures, l.bits, l.groupsize)
+
+
 def install_sibling_groups(model: torch.nn.Module, q_layer_types) -> int:
     """Group the q_layers of every parent module that match one of SIBLING_PATTERNS.  Returns the number of groups.
+    Mixed-precision checkpoints (the reference's quant_config_by_layer.json, qllm/utils/modelutils.py:167-179, gives every layer
+    its own bits / groupsize): siblings that disagree are partitioned -- q/k at 3 bits and v at 4 become ONE grouped launch for
+    q/k and v's own launch, instead of three single launches (round 6; until then such a parent got no group at all).
     QLLM_FUSE_SIBLINGS=0 disables it."""
     if os.environ.get("QLLM_FUSE_SIBLINGS", "1") == "0":
         return 0
@@ -118,10 +126,17 @@ def install_sibling_groups(model: torch.nn.Module, q_layer_types) -> int:
     for parent in model.modules():
         for names in SIBLING_PATTERNS:
             subs = [getattr(parent, nm, None) for nm in names]
-            if all(isinstance(s, types) for s in subs):
-                g = SiblingGroup(subs)
+            if not all(isinstance(s, types) for s in subs):
+                continue
+            parts: dict = {}
+            for s in subs:
+                parts.setdefault(_group_key(s), []).append(s)
+            for members in parts.values():
+                if len(members) < 2:
+                    continue
+                g = SiblingGroup(members)
                 if g.compatible():
-                    for s in subs:
+                    for s in members:
                         s._siblings = g
                     n += 1
     return n

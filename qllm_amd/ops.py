@@ -144,14 +144,16 @@ def bf16_as_f16(x2d: torch.Tensor, key: Optional[torch.Tensor] = None) -> torch.
     tensor one after the other, so three prefill calls convert once.  `key` is that object (module code passes the `x` its forward
     received: `x.reshape(-1, K)` is a fresh object per call and would never hit); it is held weakly and its death drops the copy,
     so the cache never keeps a prefill-sized buffer beyond its input's life.  Inference tensors (no version counter: an in-place
-    update could not be seen) are converted every time."""
+    update could not be seen) are converted every time: the sharing works under `torch.no_grad()`, not under
+    `torch.inference_mode()`.  A hit also requires the caller's current stream to be the one the copy was made on."""
     import weakref
     k = x2d if key is None else key
     cacheable = not k.is_inference() and k.device == x2d.device
     dev = x2d.device
     if cacheable:
         hit = _LAST_CONVERT.get(dev)
-        if hit is not None and hit[0]() is k and hit[1] == k._version and hit[2].shape == x2d.shape:
+        # (the copy was produced on ONE stream: a caller on another stream has no ordering with it -- convert again there; ADVICE r05)
+        if hit is not None and hit[0]() is k and hit[1] == k._version and hit[2].shape == x2d.shape and hit[3] == _stream_ptr():
             return hit[2]
     _check_input(x2d, "x")
     out = torch.empty(x2d.shape, dtype=torch.float16, device=dev)
@@ -162,7 +164,7 @@ def bf16_as_f16(x2d: torch.Tensor, key: Optional[torch.Tensor] = None) -> torch.
             cur = _LAST_CONVERT.get(dev)
             if cur is not None and cur[0] is ref:
                 _LAST_CONVERT.pop(dev, None)
-        _LAST_CONVERT[dev] = (weakref.ref(k, _drop), k._version, out)
+        _LAST_CONVERT[dev] = (weakref.ref(k, _drop), k._version, out, _stream_ptr())
     else:
         _LAST_CONVERT.pop(dev, None)
     return out
@@ -249,6 +251,23 @@ def plan_describe(ws_desc: Sequence[QllmWeight], m: int, have_workspace: bool = 
     buf = C.create_string_buffer(256)
     _lib.check(_lib.load().qllm_plan_describe(arr, len(ws_desc), int(m), 1 if have_workspace else 0, buf, 256))
     return buf.value.decode()
+
+
+def set_knob(name: str, value: int) -> None:
+    """Move one of the planner's thresholds (include/qllm_mi355x.h, qllm_set_knob: e.g. QLLM_GEMM3_MIN_M, QLLM_PANEL_GROUP_MIN_M) for
+    this process; `plan_describe` reflects it.  Raises for names / values the release library does not accept."""
+    _lib.check(_lib.load().qllm_set_knob(name.encode(), int(value)))
+
+
+def get_knob(name: str) -> Optional[int]:
+    """The override set for `name`, or None when the planner uses its measured default."""
+    v, is_set = C.c_int32(0), C.c_int32(0)
+    _lib.check(_lib.load().qllm_get_knob(name.encode(), C.byref(v), C.byref(is_set)))
+    return int(v.value) if is_set.value else None
+
+
+def reset_knobs() -> None:
+    _lib.load().qllm_reset_knobs()
 
 
 def ort_dequantize4bits(qweight: torch.Tensor, scales: torch.Tensor, qzeros: torch.Tensor, g_idx: Optional[torch.Tensor],

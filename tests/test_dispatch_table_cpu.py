@@ -92,7 +92,13 @@ def test_other_layouts_and_widths(lib):
     assert plan(lib, [W(4096, 4096, 64, 3, HQQ)], 2048) == "gemm3 tile=256x128 matrix-waves=8 staging-waves=4 bits=3"
     assert plan(lib, [W(4096, 11008, 128, 3, GPTQ)], 1024).endswith("bits=3")
     assert plan(lib, [W(4096, 4000, 64, 3, HQQ)], 300).startswith("unsupported")    # ragged N: dequant + GEMM
-    assert plan(lib, [W(4096, 4096, 128, 8)], 1).startswith("unsupported")
+    # 2 / 5 / 6 / 7 / 8 bits at decode sizes: the bit-stream matvec (round 6; until then dequant + GEMM); prefill sizes stay "unsupported"
+    assert plan(lib, [W(4096, 4096, 128, 8)], 1) == "bitgemv bits=8 cols=32 waves=8 split_k=4"
+    assert plan(lib, [W(4096, 4096, 64, 2, HQQ)], 16) == "bitgemv bits=2 cols=32 waves=8 split_k=4"
+    assert plan(lib, [W(4096, 11008, 128, 5)], 4) == "bitgemv bits=5 cols=32 waves=8 split_k=2"
+    assert plan(lib, [W(4096, 4096, 128, 8)], 1, have_ws=0).endswith("split_k=1")
+    assert plan(lib, [W(4096, 4096, 128, 8)], 17).startswith("unsupported") and plan(lib, [W(4096, 4096, 128, 6, g_idx=16)], 1).startswith("unsupported")
+    assert plan(lib, [W(4096, 4096, 128, 8)] * 2, 1).startswith("unsupported")     # (no grouped form: the layers run one by one)
     # raw act-order descriptors (the modules use a row-sorted view instead): in-place gather in the 128x128 kernel
     assert plan(lib, [W(4096, 4096, g_idx=16)], 300) == "gemm tile=128x128 act-order-gather"
     # narrow layers: the full-K strips even when they cannot fill the chip (measured 2x faster than split-K's three round trips)
@@ -304,3 +310,59 @@ def test_release_library_has_no_reachable_one_row_tile_panel(lib, monkeypatch):
         for m in range(2, 17):
             assert plan(lib, [W(K, N, g, bits, lay)], m).startswith("strip "), (K, N, g, bits, m)
         assert plan(lib, [W(K, N, g, bits, lay)], 33).startswith("panel "), (K, N, g, bits)
+
+
+def test_planner_thresholds_can_be_moved_at_run_time(lib):
+    """Round-5 verdict, weak #9: the decision tree's thresholds were compile-time constants in the release build.  qllm_set_knob
+    (ABI 6) moves the settable ones; qllm_plan_describe -- which asks the decision functions the forward calls execute -- follows."""
+    from qllm_amd import ops
+    sm = " layout=strip-major"
+    attn, up = W(4096, 4096, layout=NATIVE), W(4096, 11008, layout=NATIVE)
+    try:
+        assert ops.get_knob("QLLM_STRIP1") is None
+        assert plan(lib, [attn], 1).startswith("strip1 ")
+        ops.set_knob("QLLM_STRIP1", 0)
+        assert ops.get_knob("QLLM_STRIP1") == 0
+        assert plan(lib, [attn], 1) == "strip nw=8 cpl=1 spw=16 form=lds-slab row_tiles=1" + sm      # the round-4 batch-1 path
+        assert plan(lib, [up] * 2, 17).startswith("panel ")
+        ops.set_knob("QLLM_PANEL_GROUP_MIN_M", 33)
+        assert plan(lib, [up] * 2, 17).startswith("strip ") and plan(lib, [up] * 2, 33).startswith("panel ")
+        assert plan(lib, [W(4096, 4096)], 1024).startswith("gemm3 ")
+        ops.set_knob("QLLM_GEMM3_MIN_M", 2048)
+        assert plan(lib, [W(4096, 4096)], 1024).startswith("gemm2 ") and plan(lib, [W(4096, 4096)], 2048).startswith("gemm3 ")
+        ops.set_knob("QLLM_GEMM3", 0)
+        assert plan(lib, [W(4096, 4096)], 2048).startswith("gemm2 ")
+        # names and values outside what every built kernel covers are refused, and change nothing
+        with pytest.raises(Exception, match="not a settable"):
+            ops.set_knob("QLLM_GEMM4", 1)
+        with pytest.raises(Exception, match="17..129"):
+            ops.set_knob("QLLM_PANEL_MIN_M", 9)
+    finally:
+        ops.reset_knobs()
+    assert ops.get_knob("QLLM_STRIP1") is None and plan(lib, [attn], 1).startswith("strip1 ")
+    assert plan(lib, [W(4096, 4096)], 1024).startswith("gemm3 ")
+
+
+def test_ragged_last_round_of_tiles_is_split_over_k(lib):
+    """Round 6 (profiles/r06_shape_table.md): more 256x128 tiles than CUs with a last round that fills at most half of them -- the tiles of
+    that round are shared by 2 / 4 / 8 blocks each (gemm3.hip, tail split); Llama-2-7B's own shapes are unchanged."""
+    g3 = "gemm3 tile=256x128 matrix-waves=8 staging-waves=4"
+    sm = " layout=strip-major"
+    assert plan(lib, [W(5120, 5120)], 2048) == g3 + " tail_split=4"              # Llama-2-13B: 320 tiles = 256 + 64 x 4
+    assert plan(lib, [W(5120, 5120, layout=NATIVE)], 2048) == g3 + " tail_split=4" + sm
+    assert plan(lib, [W(13824, 5120)], 2048) == g3 + " tail_split=4"
+    assert plan(lib, [W(5120, 13824)], 2048) == g3 + " tail_split=2"             # 864 tiles = 768 + 96 x 2
+    assert plan(lib, [W(4096, 14336)], 2048) == g3 + " tail_split=2"             # Llama-3-8B / Mistral-7B: 896 = 768 + 128 x 2
+    assert plan(lib, [W(4096, 4096)], 2304) == g3 + " tail_split=4"              # 288 tiles: 32 x 8 would leave 8 k-tiles per block
+    assert plan(lib, [W(5120, 5120)], 2048, have_ws=0) == g3                     # no workspace: no split, still fused
+    assert plan(lib, [W(4096, 11008)], 2048) == g3 and plan(lib, [W(11008, 4096)], 2048) == g3   # 688 = 512 + 176: nothing to split
+    assert plan(lib, [W(8192, 28672)], 2048) == g3                               # 1792 tiles: seven whole rounds
+    from qllm_amd import ops
+    try:
+        ops.set_knob("QLLM_GEMM3_TAIL", 0)
+        assert plan(lib, [W(5120, 5120)], 2048) == g3
+    finally:
+        ops.reset_knobs()
+    # the workspace a caller is told to bring covers the tail's partial tiles (64 tiles x 4 blocks x 128 KB) + the counters
+    arr = (_lib.QllmWeight * 1)(W(5120, 5120))
+    assert lib.qllm_workspace_bytes_act(arr, 2048, _lib.DT_F16) >= 16384 + 64 * 4 * 256 * 128 * 4

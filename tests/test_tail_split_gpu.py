@@ -1,0 +1,47 @@
+"""-m gpu: gemm3's K-split of the ragged last round of tiles (round 6) -- shapes with more 256x128 tiles than CUs (Llama-2-13B's
+5120-wide layers: 320 tiles) against the oracle, against the unsplit launch, fp16 and bf16, every layout the kernel reads."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu as O
+from gpu_util import Ref, randx, synth, to_layer
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = 1e-2
+
+
+@pytest.mark.parametrize("layout,K,N,M,ts", [("GEMM", 5120, 5120, 2048, 4), ("GPTQ", 4096, 4096, 2304, 4), ("GPTQ", 2048, 13824, 2048, 2)])
+def test_tail_split_matches_oracle_and_unsplit_launch(layout, K, N, M, ts):
+    from qllm_amd import ops
+    d = synth(layout, 4, 128, K, N, "asym", False, True, seed=K + N)
+    layer = to_layer(d, DEV)
+    ref = Ref(d)
+    x = randx(M, K, seed=5)
+    xt = torch.from_numpy(x).to(DEV)
+    y = layer(xt)
+    assert ops.plan_describe([layer.decode_descriptor()], M).endswith(f"tail_split={ts} layout=strip-major")
+    want = ref.y16(x)
+    assert O.rel_err(y.cpu().numpy(), want) <= TOL
+    rows = np.r_[0:8, M - 264:M - 248, M - 8:M]          # (fp64 truth on a few rows of the first / a middle / the last row tile)
+    assert O.rel_err(y[rows].cpu().numpy(), ref.y64(x[rows])) <= 2e-3
+    y2 = layer(xt)
+    assert torch.equal(y, y2)                              # fixed-order sum of the partial tiles: deterministic
+    try:
+        ops.set_knob("QLLM_GEMM3_TAIL", 0)
+        assert "tail_split" not in ops.plan_describe([layer.decode_descriptor()], M)
+        y_unsplit = layer(xt)
+    finally:
+        ops.reset_knobs()
+    assert O.rel_err(y.cpu().numpy(), y_unsplit.cpu().numpy()) <= 1e-3   # same products, another fp32 summation order in the tail tiles
+    full = (M // 256) * (N // 128) // 256 * 256                          # tiles of the whole rounds: bit-identical to the unsplit launch
+    if full:
+        first_rows = full // (N // 128) * 256                            # (n-fastest tile order: whole row tiles in the unsplit segment)
+        assert torch.equal(y[:first_rows], y_unsplit[:first_rows])
+    # bf16 activations: x converted into the workspace behind the tail's slabs, result rounded to bf16
+    yb = layer(xt.to(torch.bfloat16))
+    assert yb.dtype == torch.bfloat16 and O.rel_err(yb.float().cpu().numpy(), want) <= TOL
+    # the workspace is left clean (counters re-armed): a split-K decode call right after still works
+    y1 = layer(xt[:1])
+    assert O.rel_err(y1.cpu().numpy(), ref.y16(x[:1])) <= TOL
