@@ -6,40 +6,58 @@
 // (/root/reference/qllm/quantization/hqq/_hqq_quantizer.py:18).
 //
 // HBM-bound integer work: no MFMA (a batch-1 product has no reuse to feed a matrix core with, and the 16x16 tiles of the strips exist
-// for bit widths whose fields do not straddle words).  Decomposition:
+// for bit widths whose fields do not straddle words).  Decomposition (third version; profiles/r06_bitgemv.md has the A/B of block shapes):
 //   * unit = 32 consecutive k of one column = `bits` consecutive words of that column's stream (a field may straddle two of them);
-//   * wave = 32 columns x 2 unit parities: a wave-load of one word row is two full 128-byte lines; a block = 32 columns, NW waves
-//     taking units round-robin, one K chunk of the layer (blocks split K until the launch covers the CUs twice);
-//   * every lane keeps two sets of its next units' words in flight (loads first, arithmetic behind them);
+//   * block = 32 columns for a K range of the layer: 8 waves x 2 unit parities x 32 columns, so a wave-load of one word row is two full
+//     128-byte lines; K is split over blocks until the launch has two blocks per CU (measured: 16 / 32 / 64 columns and one / two blocks
+//     per CU are within 15 % of each other at batch 1; 32 x 2 is best on the 11008-wide shapes and at 16 rows.  QLLM_BG_COLS = 16 is a
+//     build-time lab variant: the two 64-byte halves of a line then go to two blocks on the same XCD);
+//   * ONE round of loads: a lane issues the words of ALL its units of the round (up to 48 registers) with their groups' scales and zero
+//     points before anything waits -- in front of the activation staging, so the weights are in flight while x is staged;
 //   * a pair of fields becomes one packed fp16 operand: widths dividing 16 (2, 4, 8) pair the fields 16 bits apart in a word -- one
 //     shift and one v_and_or give (1024 + q_a, 1024 + q_b); the others (3, 5, 6, 7) take a 32-bit window of the stream with
 //     v_alignbit and place its two fields; minus 1024 (exact: q <= 255) and ONE v_dot2_f32_f16 per activation row accumulates
-//     x_a q_a + x_b q_b in fp32.  The activations of the block's K chunk are staged once in LDS as fp16 pairs in exactly that pairing
-//     (bf16 callers: converted on the way in), with the sum of every unit's 32 activations beside them;
+//     x_a q_a + x_b q_b in fp32.  The activations of the block's K range are staged in LDS as fp16 pairs in exactly that pairing
+//     (bf16 callers: converted on the way in), with the sum of every unit's 32 activations (a 16-lane butterfly in the staging pass);
 //   * per unit and row: y += s_g (acc - z_g Sx) in fp32 -- x W for the UNROUNDED W = s (q - z), the contract of the strip kernels
 //     (DESIGN.md section 2): no per-weight fp16 rounding at all; packed, fp16 (HQQ) and symmetric zero points;
-//   * lanes -> waves -> (K-split) blocks are summed in fixed order: LDS, then fp32 slabs + ticket (the protocol of skinny.hip).
+//   * parities -> waves -> (K-split) blocks are summed in fixed order: LDS, then fp32 slabs + ticket (the protocol of skinny.hip).
 #include "kernels.hpp"
 
 namespace qllm {
 namespace bg {
 
-constexpr int kCols = 32;     // columns per block
+#ifndef QLLM_BG_COLS
+#define QLLM_BG_COLS 32
+#endif
+#ifndef QLLM_BG_FILL
+#define QLLM_BG_FILL 2   // K is split over blocks until the launch has this many blocks per CU (rounded up)
+#endif
+constexpr int kCols = QLLM_BG_COLS;     // columns per block
+constexpr int kPar = 64 / kCols;        // unit parities per wave (64 lanes = kCols columns x kPar)
 constexpr int kNW = 8;        // waves per block
-constexpr int kXsBytes = 16 * 1024;  // LDS budget of the staged activations (with the sums and the reduction scratch: < 64 KB at 16 rows)
+constexpr int kSlots = kNW * kPar;  // lane slots a block's units are dealt to
+constexpr int kXsBytes = 112 * 1024;  // LDS budget of the staged activations (+ their sums; the reduction scratch reuses it)
+
+// units of a lane whose words are in flight together: at most 32 registers of packed words at 1-2 rows (80 registers in all: three blocks per CU; 48 words cost a third of the resident blocks and 25 % on the 11008-wide shapes), 40 at 4 rows -- fewer with many activation rows, whose
+// accumulators need the registers (16 rows: 16 words; every instantiation spill-free, tests/test_kernel_resources_cpu.py)
+__host__ __device__ constexpr int round_units(int bits, int mt) {
+  const int budget = mt <= 2 ? 32 : (mt == 4 ? 40 : (mt == 8 ? 24 : 16)), most = mt <= 4 ? 8 : (mt == 8 ? 4 : 2);
+  return budget / bits > most ? most : (budget / bits < 1 ? 1 : budget / bits);
+}
 
 // how the 32 fields of a unit pair up into 16 packed operands: pair p = fields (a(p), b(p))
 template <int BITS>
 struct Pairing {
   static constexpr bool kShared = (16 % BITS) == 0;  // fields 16 bits apart in one word share a shift
-  static constexpr int kPerWord = 32 / BITS, kHalf = 16 / (BITS ? BITS : 1);
-  __host__ __device__ static constexpr int a(int p) { return kShared ? (p / kHalf) * kPerWord + p % kHalf : 2 * p; }
+  static constexpr int kPerWord = 32 / BITS, kHalf = 16 / BITS;
+  __host__ __device__ static constexpr int a(int p) { return kShared ? (p / (kHalf ? kHalf : 1)) * kPerWord + p % (kHalf ? kHalf : 1) : 2 * p; }
   __host__ __device__ static constexpr int b(int p) { return kShared ? a(p) + kHalf : 2 * p + 1; }
 };
 
 // packed operand (q_a, q_b) as exact fp16 of pair P (compile-time) from the unit's words
 template <int BITS, int P>
-__device__ __forceinline__ half2_t pair_of(const uint32_t (&w)[BITS]) {
+__device__ __forceinline__ half2_t pair_of(const uint32_t *w) {
   constexpr uint32_t mask = (1u << BITS) - 1u;
   uint32_t v;
   if constexpr (Pairing<BITS>::kShared) {
@@ -55,43 +73,60 @@ __device__ __forceinline__ half2_t pair_of(const uint32_t (&w)[BITS]) {
   return as_h2(v) - splat2((half_t)1024.0f);  // exact: 1024 + q, q <= 255, is an integer below 2048
 }
 
-template <int BITS, int MT, int... P>
-__device__ __forceinline__ void unit_dot(const uint32_t (&w)[BITS], const uint32_t *xs_u, int x_stride, float (&acc)[MT],
-                                         std::integer_sequence<int, P...>) {
-  // 4 pairs per ds_read_b128 (every lane of a unit parity reads the same address: a broadcast)
-  auto quad = [&](auto qi) {
-    constexpr int Q = decltype(qi)::value;
-    const half2_t q0 = pair_of<BITS, 4 * Q>(w), q1 = pair_of<BITS, 4 * Q + 1>(w), q2 = pair_of<BITS, 4 * Q + 2>(w), q3 = pair_of<BITS, 4 * Q + 3>(w);
+// staging: pair K (0..7) of a half unit from its 16 natural-order halves (lo = halves 0..7, hi = 8..15), converted to fp16 if the
+// caller's activations are bf16; adds the pair's two values to `sum`.  The pairings keep a half unit's pairs inside it.
+template <int I>
+__device__ __forceinline__ uint32_t half_of(const uint4_t &lo, const uint4_t &hi) {
+  constexpr int r = I >> 1;
+  const uint32_t word = r == 0 ? lo.x : r == 1 ? lo.y : r == 2 ? lo.z : r == 3 ? lo.w : r == 4 ? hi.x : r == 5 ? hi.y : r == 6 ? hi.z : hi.w;
+  return (I & 1) ? (word >> 16) : (word & 0xffffu);
+}
+template <int BITS, int K>
+__device__ __forceinline__ uint32_t stage_pair(const uint4_t &lo, const uint4_t &hi, bool bf16, float &sum) {
+  constexpr int a = Pairing<BITS>::a(K), b = Pairing<BITS>::b(K);
+  static_assert(a < 16 && b < 16, "a half unit's pairs stay inside it");
+  uint32_t v = half_of<a>(lo, hi) | (half_of<b>(lo, hi) << 16);
+  if (bf16) v = as_u32(bf16x2_to_h2(v));
+  const half2_t hh = as_h2(v);
+  sum += (float)hh.x + (float)hh.y;
+  return v;
+}
+
+template <int BITS, int MT, int Q>
+__device__ __forceinline__ void quad_dot(const uint32_t *w, const uint32_t *xs_u, int x_stride, float (&acc)[MT]) {
+  // 4 pairs per ds_read_b128 (the 16 lanes of a unit parity read the same address: a broadcast)
+  const half2_t q0 = pair_of<BITS, 4 * Q>(w), q1 = pair_of<BITS, 4 * Q + 1>(w), q2 = pair_of<BITS, 4 * Q + 2>(w), q3 = pair_of<BITS, 4 * Q + 3>(w);
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      const uint4_t xv = *(const uint4_t *)(xs_u + m * x_stride + 4 * Q);
-      float a = acc[m];
-      a = __builtin_amdgcn_fdot2(as_h2(xv.x), q0, a, false);
-      a = __builtin_amdgcn_fdot2(as_h2(xv.y), q1, a, false);
-      a = __builtin_amdgcn_fdot2(as_h2(xv.z), q2, a, false);
-      a = __builtin_amdgcn_fdot2(as_h2(xv.w), q3, a, false);
-      acc[m] = a;
-    }
-  };
-  (quad(std::integral_constant<int, P>{}), ...);
+  for (int m = 0; m < MT; ++m) {
+    const uint4_t xv = *(const uint4_t *)(xs_u + m * x_stride + 4 * Q);
+    float a = acc[m];
+    a = __builtin_amdgcn_fdot2(as_h2(xv.x), q0, a, false);
+    a = __builtin_amdgcn_fdot2(as_h2(xv.y), q1, a, false);
+    a = __builtin_amdgcn_fdot2(as_h2(xv.z), q2, a, false);
+    a = __builtin_amdgcn_fdot2(as_h2(xv.w), q3, a, false);
+    acc[m] = a;
+  }
 }
 
 template <int BITS, int MT>
 __global__ __launch_bounds__(kNW * 64) void bitgemv_kernel(const BitGemvParams p) {
+  constexpr int UB = round_units(BITS, MT);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int col = lane & 31, par = lane >> 5;
-  const int nb = blockIdx.x % p.n_col_blocks, kb = blockIdx.x / p.n_col_blocks;
+  const int col = lane % kCols, slot = wave * kPar + lane / kCols;
+  const int nbc = p.n_col_blocks;
+  const int j = blockIdx.x % nbc, kb = blockIdx.x / nbc;
+  // block id -> column block: consecutive ids go round the 8 XCDs, so ids j and j + 8 run on one XCD back to back -- give them the two
+  // 64-byte halves of one 128-byte line of the word rows (whole multiples of 16 column blocks only; else the identity)
+  const int nb = (kCols == 16 && nbc % 16 == 0) ? 2 * (((j >> 3) >> 1) * 8 + (j & 7)) + ((j >> 3) & 1) : j;
   const int n = nb * kCols + col;
-  const bool live = n < p.N;
-  const int nc = live ? n : p.N - 1;  // (dead lanes of a ragged last block re-read the last column and store nothing)
+  const int nc = n < p.N ? n : p.N - 1;  // (dead lanes of a ragged last block re-read the last column and store nothing)
   const int U = p.K / 32;
   const int u_begin = (int)((long long)U * kb / p.ksplit), u_end = (int)((long long)U * (kb + 1) / p.ksplit);
-  // LDS: [MT][chunk units][16 pairs] u32 | [MT][chunk units] f32 sums | reduction scratch
+  // LDS: [MT][chunk units][16 pairs] u32 | [MT][chunk units] f32 sums; the reduction scratch reuses it at the end
   uint32_t *xs = (uint32_t *)smem;
   const int cu = p.chunk_units, x_stride = cu * 16;
   float *sx = (float *)(smem + (size_t)MT * cu * 64);
-  float *red = sx + MT * cu;
 
   float y[MT];
 #pragma unroll
@@ -99,87 +134,113 @@ __global__ __launch_bounds__(kNW * 64) void bitgemv_kernel(const BitGemvParams p
   const uint32_t *wcol = p.qweight + nc;
   const int zk = p.zero_kind;
   const int zwords = (p.N * BITS) >> 5;  // packed zero points: words per group row
+  uint32_t w[UB][BITS];
+  uint32_t sc[UB];   // raw fp16 bits
+  uint32_t zr0[UB], zr1[UB];  // zero point of (group, column), raw: the fp16 value, or the two words its packed field may straddle
+  const int zbit = nc * BITS, zw = zbit >> 5, zw1 = min(zw + 1, zwords - 1);
+  // the words of round r of the chunk starting at unit c0: units c0 + slot + kSlots (r UB + i) -- with their group's scale and zero
+  // point (a lane's units are kSlots apart: nearly every one is in another group, and a load inside the arithmetic would be one
+  // exposed round trip per unit)
+  auto load_round = [&](int c0, int c1, int r) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < UB; ++i) {
+      const int u = c0 + slot + kSlots * (r * UB + i);
+      if (u < c1) {
+        const uint32_t *src = wcol + (size_t)u * BITS * p.N;
+#pragma unroll
+        for (int b = 0; b < BITS; ++b) w[i][b] = __builtin_nontemporal_load(src + (size_t)b * p.N);
+        const size_t g = (size_t)((32 * u) / p.group_size);
+        sc[i] = ((const uint16_t *)p.scales)[g * p.N + nc];
+        // (ONE store pattern for every zero-point kind: stores under a per-kind branch get merged into a dynamically indexed one, and
+        //  the arrays then live in scratch memory)
+        if (zk != ZK_SYM) {
+          const size_t i0 = zk == ZK_F16 ? (g * p.N + nc) >> 1 : g * zwords + zw;   // fp16 zero points: the dword holding the half (N is even)
+          const size_t i1 = zk == ZK_F16 ? i0 : g * zwords + zw1;
+          zr0[i] = ((const uint32_t *)p.qzeros)[i0];
+          zr1[i] = ((const uint32_t *)p.qzeros)[i1];
+        }
+      }
+    }
+  };
+  auto zero_of = [&](int i) __attribute__((always_inline)) -> float {
+    if (zk == ZK_F16) return (float)__builtin_bit_cast(half_t, (uint16_t)((nc & 1) ? (zr0[i] >> 16) : zr0[i]));
+    if (zk == ZK_SYM) return (float)(1 << (BITS - 1));
+    const uint64_t v = ((uint64_t)zr1[i] << 32) | zr0[i];   // (zw1 == zw only when the field ends inside word zw)
+    return (float)(((uint32_t)(v >> (zbit & 31)) + (uint32_t)p.add_zero_bias) & ((1u << BITS) - 1u));
+  };
 
   for (int c0 = u_begin; c0 < u_end; c0 += cu) {
     const int c1 = min(c0 + cu, u_end), nu = c1 - c0;
-    __syncthreads();  // (the previous chunk's readers are done)
-    // ---- stage x[m][32 c0 .. 32 c1) as fp16 pairs in the unit's pairing; rows past M are zeros ------------------------------------
-    for (int i = tid; i < MT * nu * 16; i += kNW * 64) {
-      const int pr = i & 15, u = (i >> 4) % nu, m = (i >> 4) / nu;
-      uint32_t v = 0;
+    load_round(c0, c1, 0);            // in flight while x is staged
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();                  // (the previous chunk's readers are done)
+    // ---- stage x[m][32 c0 .. 32 c1) as fp16 pairs in the unit's pairing (rows past M: zeros) + the sum of every unit's activations.
+    //      One thread = half a unit: two 16-byte loads, its 8 pairs (the pairings keep a half unit's pairs inside it), two 16-byte
+    //      LDS stores; the two halves of a unit are neighbouring lanes ------------------------------------------------------------
+    for (int i0 = 0; i0 < MT * nu * 2; i0 += kNW * 64) {
+      const int i = i0 + tid;
+      const bool in = i < MT * nu * 2;
+      const int h = i & 1, u = in ? (i >> 1) % nu : 0, m = in ? (i >> 1) / nu : MT;
+      uint4_t lo = uint4_t{0, 0, 0, 0}, hi = uint4_t{0, 0, 0, 0};
       if (m < p.M) {
-        const uint16_t *xr = (const uint16_t *)p.x + (size_t)m * p.K + 32 * (c0 + u);
-        // (compile-time pairing tables as arithmetic: a = first field of the pair, b = its partner)
-        const int a = Pairing<BITS>::kShared ? (pr / Pairing<BITS>::kHalf) * Pairing<BITS>::kPerWord + pr % Pairing<BITS>::kHalf : 2 * pr;
-        const int b = Pairing<BITS>::kShared ? a + Pairing<BITS>::kHalf : a + 1;
-        v = (uint32_t)xr[a] | ((uint32_t)xr[b] << 16);
-        if (p.act_bf16) v = as_u32(bf16x2_to_h2(v));
+        const uint4_t *xr = (const uint4_t *)((const uint16_t *)p.x + (size_t)m * p.K + 32 * (c0 + u) + 16 * h);
+        lo = xr[0];
+        hi = xr[1];
       }
-      xs[m * x_stride + u * 16 + pr] = v;
-    }
-    __syncthreads();
-    for (int i = tid; i < MT * nu; i += kNW * 64) {
-      const int u = i % nu, m = i / nu;
-      float s = 0.f;
-#pragma unroll
-      for (int pr = 0; pr < 16; ++pr) {
-        const half2_t h = as_h2(xs[m * x_stride + u * 16 + pr]);
-        s += (float)h.x + (float)h.y;
+      float sum = 0.f;
+      const bool bf = p.act_bf16;
+      const uint32_t o0 = stage_pair<BITS, 0>(lo, hi, bf, sum), o1 = stage_pair<BITS, 1>(lo, hi, bf, sum), o2 = stage_pair<BITS, 2>(lo, hi, bf, sum),
+                     o3 = stage_pair<BITS, 3>(lo, hi, bf, sum), o4 = stage_pair<BITS, 4>(lo, hi, bf, sum), o5 = stage_pair<BITS, 5>(lo, hi, bf, sum),
+                     o6 = stage_pair<BITS, 6>(lo, hi, bf, sum), o7 = stage_pair<BITS, 7>(lo, hi, bf, sum);
+      sum += __shfl_xor(sum, 1, 64);
+      if (in) {
+        uint4_t *dst = (uint4_t *)(xs + m * x_stride + u * 16 + 8 * h);
+        dst[0] = uint4_t{o0, o1, o2, o3};
+        dst[1] = uint4_t{o4, o5, o6, o7};
+        if (h == 0) sx[m * cu + u] = sum;
       }
-      sx[m * cu + u] = s;
     }
     __syncthreads();
 
-    // ---- this lane's units: c0 + 2 wave + par, step 2 NW; the next unit's words are in flight while one is consumed ----------------
-    auto load_unit = [&](int u, uint32_t (&w)[BITS]) {
-      const uint32_t *src = wcol + (size_t)u * BITS * p.N;
+    const int rounds = (nu + kSlots * UB - 1) / (kSlots * UB);
+    for (int r = 0; r < rounds; ++r) {
+      if (r) load_round(c0, c1, r);
 #pragma unroll
-      for (int j = 0; j < BITS; ++j) w[j] = __builtin_nontemporal_load(src + (size_t)j * p.N);
-    };
-    int u = c0 + 2 * wave + par;
-    uint32_t w0[BITS], w1[BITS];
-    if (u < c1) load_unit(u, w0);
-    int g_have = -1;
-    float s_g = 0.f, z_g = 0.f;
-    while (u < c1) {
-      const int un = u + 2 * kNW;
-      if (un < c1) load_unit(un, w1);
-      // scale / zero point of (group, column): reloaded when the group changes
-      const int g = (32 * u) / p.group_size;
-      if (g != g_have) {
-        g_have = g;
-        s_g = (float)p.scales[(size_t)g * p.N + nc];
-        if (zk == ZK_F16) z_g = (float)((const half_t *)p.qzeros)[(size_t)g * p.N + nc];
-        else if (zk == ZK_SYM) z_g = (float)(1 << (BITS - 1));
-        else z_g = (float)packed_zero((const uint32_t *)p.qzeros + (size_t)g * zwords, nc, BITS, p.add_zero_bias);
+      for (int i = 0; i < UB; ++i) {
+        const int u = c0 + slot + kSlots * (r * UB + i);
+        if (u < c1) {  // (no `break`: the loop must unroll completely, or the register arrays above turn into scratch memory)
+          const float s_g = (float)__builtin_bit_cast(half_t, (uint16_t)sc[i]), z_g = zero_of(i);
+          float acc[MT];
+#pragma unroll
+          for (int m = 0; m < MT; ++m) acc[m] = 0.f;
+          const uint32_t *xu = xs + (u - c0) * 16;
+          quad_dot<BITS, MT, 0>(w[i], xu, x_stride, acc);
+          quad_dot<BITS, MT, 1>(w[i], xu, x_stride, acc);
+          quad_dot<BITS, MT, 2>(w[i], xu, x_stride, acc);
+          quad_dot<BITS, MT, 3>(w[i], xu, x_stride, acc);
+#pragma unroll
+          for (int m = 0; m < MT; ++m) y[m] += s_g * (acc[m] - z_g * sx[m * cu + (u - c0)]);
+        }
       }
-      float acc[MT];
-#pragma unroll
-      for (int m = 0; m < MT; ++m) acc[m] = 0.f;
-      unit_dot<BITS, MT>(w0, xs + (u - c0) * 16, x_stride, acc, std::make_integer_sequence<int, 4>{});
-#pragma unroll
-      for (int m = 0; m < MT; ++m) y[m] += s_g * (acc[m] - z_g * sx[m * cu + (u - c0)]);
-#pragma unroll
-      for (int j = 0; j < BITS; ++j) w0[j] = w1[j];
-      u = un;
     }
   }
 
-  // ---- lanes (two unit parities) and waves: fixed-order sum through LDS ---------------------------------------------------------------
+  // ---- parities and waves: fixed-order sum through LDS (the staged activations are dead) -----------------------------------------------
   __syncthreads();
+  float *red = (float *)smem;
 #pragma unroll
-  for (int m = 0; m < MT; ++m) red[((wave * 2 + par) * MT + m) * kCols + col] = y[m];
+  for (int m = 0; m < MT; ++m) red[(slot * MT + m) * kCols + col] = y[m];
   __syncthreads();
+  float *blk = red + kSlots * MT * kCols;  // [MT][16] sums of this block
   const int S = p.ksplit;
   for (int i = tid; i < MT * kCols; i += kNW * 64) {
     const int c = i % kCols, m = i / kCols;
     float v = 0.f;
 #pragma unroll
-    for (int q = 0; q < 2 * kNW; ++q) v += red[(q * MT + m) * kCols + c];
-    red[2 * kNW * MT * kCols + i] = v;  // (kept for the split-K publication below)
+    for (int q = 0; q < kSlots; ++q) v += red[(q * MT + m) * kCols + c];
+    blk[i] = v;
   }
   __syncthreads();
-  float *blk = red + 2 * kNW * MT * kCols;  // [MT][32] sums of this block
   int &s_ticket = *(int *)(blk + MT * kCols);
   if (S > 1) {
     // fp32 slab [ksplit][M][N]: write-through stores, drained; one relaxed agent-scope ticket per column block; the last arriver sums
@@ -215,8 +276,12 @@ __global__ __launch_bounds__(kNW * 64) void bitgemv_kernel(const BitGemvParams p
 
 template <int BITS>
 static int launch_b(const BitGemvParams &p, int mt, int grid, size_t lds, hipStream_t stream) {
-#define QLLM_BG(MT_)                                                                                         \
-  hipLaunchKernelGGL((bitgemv_kernel<BITS, MT_>), dim3(grid), dim3(kNW * 64), lds, stream, p);              \
+#define QLLM_BG(MT_)                                                                                              \
+  {                                                                                                               \
+    static DeviceLatch attr_done; /* per (kernel, device): the LDS opt-in is a per-device attribute */              \
+    if (int rc = lds_optin(attr_done, (const void *)bitgemv_kernel<BITS, MT_>)) return rc;                         \
+    hipLaunchKernelGGL((bitgemv_kernel<BITS, MT_>), dim3(grid), dim3(kNW * 64), lds, stream, p);                  \
+  }                                                                                                               \
   break
   switch (mt) {
     case 1: QLLM_BG(1);
@@ -232,6 +297,7 @@ static int launch_b(const BitGemvParams &p, int mt, int grid, size_t lds, hipStr
 
 }  // namespace bg
 
+int bitgemv_cols() { return bg::kCols; }
 int bitgemv_mt(int M) { return M <= 1 ? 1 : (M <= 2 ? 2 : (M <= 4 ? 4 : (M <= 8 ? 8 : 16))); }
 
 // shapes served: row-stream layouts, whole 32-k units inside one group, decode sizes
@@ -239,15 +305,16 @@ bool bitgemv_ok(const qllm_weight_t &w, int M) {
   if (w.layout != QLLM_LAYOUT_GPTQ && w.layout != QLLM_LAYOUT_HQQ) return false;
   if (w.bits < 2 || w.bits > 8 || w.g_idx || M < 1 || M > kBitGemvMaxM) return false;
   if (w.K % 32 != 0 || w.group_size % 32 != 0 || w.N < 1) return false;
+  if (w.layout == QLLM_LAYOUT_HQQ && (w.N % 2 != 0 || (uintptr_t)w.qzeros % 4)) return false;  // (fp16 zero points are fetched as dwords)
   if ((uintptr_t)w.qweight % 4 || (uintptr_t)w.scales % 2) return false;
   return (double)w.K * w.N * w.bits / 8 < 8e9;
 }
 
-// K blocks: until the launch covers the CUs twice, at least 2 units per lane slot, at most the workspace's slab count
+// K blocks: until the launch has QLLM_BG_FILL (2) blocks per CU, at least one unit per lane slot, at most the workspace's slab count
 int bitgemv_split(int M, int K, int N) {
   const int nb = (N + bg::kCols - 1) / bg::kCols, U = K / 32;
-  int S = (2 * compute_units() + nb - 1) / nb;
-  const int cap = skinny_max_split(M), by_len = U / (4 * bg::kNW) > 0 ? U / (4 * bg::kNW) : 1;
+  int S = (QLLM_BG_FILL * compute_units() + nb - 1) / nb;
+  const int cap = skinny_max_split(M), by_len = U / bg::kSlots > 0 ? U / bg::kSlots : 1;
   S = S > cap ? cap : S;
   S = S > by_len ? by_len : S;
   return S < 1 ? 1 : S;
@@ -259,9 +326,10 @@ int launch_bitgemv(const BitGemvParams &p_in, int bits, hipStream_t stream) {
   p.n_col_blocks = (p.N + bg::kCols - 1) / bg::kCols;
   if (p.ksplit < 1 || !p.slabs || !p.counters) p.ksplit = 1;
   const int U = p.K / 32, per_block = (U + p.ksplit - 1) / p.ksplit;
-  const int fit = bg::kXsBytes / (mt * 64);  // units whose staged activations fit the LDS budget
+  const int fit = bg::kXsBytes / (mt * 68);  // units whose staged activations (64 B per row) and sums (4 B) fit the LDS budget
   p.chunk_units = per_block < fit ? per_block : fit;
-  const size_t lds = (size_t)mt * p.chunk_units * 64 + (size_t)mt * p.chunk_units * 4 + (size_t)(2 * bg::kNW + 1) * mt * bg::kCols * 4 + 16;
+  const size_t x_bytes = (size_t)mt * p.chunk_units * 68, red_bytes = (size_t)(bg::kSlots + 1) * mt * bg::kCols * 4 + 16;
+  const size_t lds = x_bytes > red_bytes ? x_bytes : red_bytes;
   const int grid = p.n_col_blocks * p.ksplit;
   switch (bits) {
     case 2: return bg::launch_b<2>(p, mt, grid, lds, stream);

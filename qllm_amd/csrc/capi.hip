@@ -769,7 +769,7 @@ static Decision decide_group(const qllm_weight_t *w, int n, int M) {
 
 static int bitgemv_split_for(int M, int K, int N, size_t ws_bytes) {
   const int S = bitgemv_split(M, K, N);
-  if (S <= 1 || ws_bytes < kCounterBytes + (size_t)S * M * N * sizeof(float) || (N + 31) / 32 > (int)(kCounterBytes / sizeof(int))) return 1;
+  if (S <= 1 || ws_bytes < kCounterBytes + (size_t)S * M * N * sizeof(float) || (N + 15) / 16 > (int)(kCounterBytes / sizeof(int))) return 1;
   return S;
 }
 static int run_bitgemv(const qllm_weight_t *w, void *y, const void *x, int M, int act_dtype, void *workspace, size_t workspace_bytes, hipStream_t stream) {
@@ -864,7 +864,7 @@ static void describe(const Decision &d, const qllm_weight_t *w, int n, int M, si
       return;
     }
     case ROUTE_BITGEMV:
-      snprintf(buf, buflen, "bitgemv bits=%d cols=32 waves=8 split_k=%d", w[0].bits, bitgemv_split_for(M, w[0].K, w[0].N, ws_bytes));
+      snprintf(buf, buflen, "bitgemv bits=%d cols=%d waves=8 split_k=%d", w[0].bits, bitgemv_cols(), bitgemv_split_for(M, w[0].K, w[0].N, ws_bytes));
       return;
     default: snprintf(buf, buflen, "unsupported (%s)", g_err[0] ? g_err : "dequant + GEMM");
   }

@@ -142,6 +142,7 @@ struct BitGemvParams {
 };
 bool bitgemv_ok(const qllm_weight_t &w, int M);
 int bitgemv_split(int M, int K, int N);
+int bitgemv_cols();
 int launch_bitgemv(const BitGemvParams &p, int bits, hipStream_t stream);
 
 // ---- comm.hip: staging buffer of one rank = [2 parities][world][slot_bytes] payload | this control block ----------------------------

@@ -93,10 +93,11 @@ def test_other_layouts_and_widths(lib):
     assert plan(lib, [W(4096, 11008, 128, 3, GPTQ)], 1024).endswith("bits=3")
     assert plan(lib, [W(4096, 4000, 64, 3, HQQ)], 300).startswith("unsupported")    # ragged N: dequant + GEMM
     # 2 / 5 / 6 / 7 / 8 bits at decode sizes: the bit-stream matvec (round 6; until then dequant + GEMM); prefill sizes stay "unsupported"
-    assert plan(lib, [W(4096, 4096, 128, 8)], 1) == "bitgemv bits=8 cols=32 waves=8 split_k=4"
+    assert plan(lib, [W(4096, 4096, 128, 8)], 1) == "bitgemv bits=8 cols=32 waves=8 split_k=4"      # 128 column blocks x 4 K parts: two per CU
     assert plan(lib, [W(4096, 4096, 64, 2, HQQ)], 16) == "bitgemv bits=2 cols=32 waves=8 split_k=4"
     assert plan(lib, [W(4096, 11008, 128, 5)], 4) == "bitgemv bits=5 cols=32 waves=8 split_k=2"
-    assert plan(lib, [W(4096, 4096, 128, 8)], 1, have_ws=0).endswith("split_k=1")
+    assert plan(lib, [W(4096, 1024, 128, 8)], 1) == "bitgemv bits=8 cols=32 waves=8 split_k=8"      # narrow layer: 32 column blocks, one unit per lane slot
+    assert plan(lib, [W(4096, 1024, 128, 8)], 1, have_ws=0).endswith("split_k=1")
     assert plan(lib, [W(4096, 4096, 128, 8)], 17).startswith("unsupported") and plan(lib, [W(4096, 4096, 128, 6, g_idx=16)], 1).startswith("unsupported")
     assert plan(lib, [W(4096, 4096, 128, 8)] * 2, 1).startswith("unsupported")     # (no grouped form: the layers run one by one)
     # raw act-order descriptors (the modules use a row-sorted view instead): in-place gather in the 128x128 kernel

@@ -131,3 +131,17 @@ def test_panel_kernel_budget():
         assert cpl == 1 and kh == (2 if mt <= 4 else 1), n
         assert not (mt == 8 and spg == 1), n
         assert vgpr <= (256 if kh == 2 else 512), (n, vgpr)
+
+
+def test_bit_stream_matvec_never_spills():
+    """csrc/bitgemv.hip (round 6): 7 widths x 5 row tiles; the rounds of loads shrink with the row count so that none spills."""
+    res = {n: v for n, v in _resources("bitgemv.hip").items() if "bitgemv_kernel" in n}
+    assert len(res) == 35
+    for n, (vgpr, spill) in res.items():
+        assert spill == 0 and vgpr <= 256, (n, vgpr, spill)
+    # ... and no register array may end up in scratch memory (a `break` inside an unrolled loop, or stores under per-kind branches,
+    # turned the per-unit scale / zero-point arrays into private memory in the first versions: round 6)
+    out = [f for f in os.listdir("/tmp") if f.startswith("qllm_res_bitgemv.hip_")]
+    text = open(os.path.join("/tmp", sorted(out)[-1])).read()
+    assert "scratch_load" not in text and "scratch_store" not in text
+    assert all(int(v) == 0 for v in re.findall(r"\.private_segment_fixed_size:\s+(\d+)", text))

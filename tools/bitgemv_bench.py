@@ -17,8 +17,9 @@ dev = torch.device("cuda:0")
 gen = torch.Generator(device=dev).manual_seed(3)
 print("| layout | bits | K | N | M | plan | fused us | GB/s (packed bytes) | of 8 TB/s | dequant + GEMM us | speed-up |")
 print("|---|---|---|---|---|---|---|---|---|---|---|")
-for cls, g, zeros in ((QuantLinearHQQ, 64, "f16"), (QuantLinearGPTQ, 128, "packed")):
-    for bits in (2, 5, 6, 7, 8):
+quick = "--quick" in sys.argv   # (A/B runs: HQQ only, widths 2 / 5 / 8, no dequant + GEMM leg)
+for cls, g, zeros in ((QuantLinearHQQ, 64, "f16"),) if quick else ((QuantLinearHQQ, 64, "f16"), (QuantLinearGPTQ, 128, "packed")):
+    for bits in (2, 5, 8) if quick else (2, 5, 6, 7, 8):
         for (K, N) in ((4096, 4096), (4096, 11008), (11008, 4096)):
             wbytes = K * N * bits // 8
             ncopy = max(2, min(24, (512 << 20) // wbytes + 1))
@@ -26,7 +27,7 @@ for cls, g, zeros in ((QuantLinearHQQ, 64, "f16"), (QuantLinearGPTQ, 128, "packe
             for M in (1, 4, 16):
                 x = torch.randn(M, K, device=dev, dtype=torch.float16)
                 res = {}
-                for tag, on in (("fused", 1), ("dequant", 0)):
+                for tag, on in (("fused", 1),) if quick else (("fused", 1), ("dequant", 0)):
                     ops.set_knob("QLLM_BITGEMV", on)
                     try:
                         plan = ops.plan_describe([layers[0].decode_descriptor()], M) if on else None
@@ -39,6 +40,7 @@ for cls, g, zeros in ((QuantLinearHQQ, 64, "f16"), (QuantLinearGPTQ, 128, "packe
                         ops.reset_knobs()
                 G = K // g
                 nbytes = wbytes + G * N * 2 + (G * N * 2 if zeros == "f16" else G * N * bits // 8) + 2 * M * K + 2 * M * N
+                res.setdefault("dequant", float("nan"))
                 print(f"| {cls.__name__[11:]} g{g} | {bits} | {K} | {N} | {M} | {res['plan']} | {res['fused'] * 1e3:.2f} | {nbytes / res['fused'] / 1e6:.0f} | "
                       f"{nbytes / res['fused'] / 1e6 / 8000:.3f} | {res['dequant'] * 1e3:.2f} | {res['dequant'] / res['fused']:.1f}x |", flush=True)
             del layers
