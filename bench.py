@@ -647,12 +647,20 @@ def main():
         # prefill M=2048 (BASELINE configs[2]: GPTQ act-order) and AWQ, one layer's 7 linears x 4 layers
         # (awq_bf16: bf16 activations on the same kernel -- x converted to fp16 by a pre-pass, the result rounded to bf16, the
         #  arithmetic of the reference's shim, quant_linear_awq.py:29-36)
+        # (round 6: awq_bf16 = NATIVE bf16 -- bf16 W, v_mfma_f32_32x32x16_bf16, no conversion pre-pass; awq_bf16_shim = the path until
+        #  round 5, kept behind qllm_set_knob("QLLM_GEMM3_BF16", 0): x -> fp16 pre-pass, fp16 kernel, result rounded to bf16)
+        from qllm_amd import ops as _ops
         for tag, cls, act, xdt in (("awq", WQLinear_GEMM, False, torch.float16), ("gptq_actorder", QuantLinearGPTQ, True, torch.float16),
-                                   ("awq_bf16", WQLinear_GEMM, False, torch.bfloat16)):
+                                   ("awq_bf16", WQLinear_GEMM, False, torch.bfloat16), ("awq_bf16_shim", WQLinear_GEMM, False, torch.bfloat16)):
             ps = Stack(cls, 4, dev, seed=99, act_order=act)
             xp = torch.randn(2048, HIDDEN, device=dev, dtype=xdt)
-            gp, _ = capture(lambda: ps(xp))  # graph replay, like the headline leg: kernel time, not Python / allocator time
-            ms = time_events(gp.replay, 10)
+            if tag.endswith("_shim"):
+                _ops.set_knob("QLLM_GEMM3_BF16", 0)
+            try:
+                gp, _ = capture(lambda: ps(xp))  # graph replay, like the headline leg: kernel time, not Python / allocator time
+                ms = time_events(gp.replay, 10)
+            finally:
+                _ops.reset_knobs()
             del gp
             tf = flops_per_pass(4, 2048) / ms / 1e9
             extra[f"prefill_m2048_{tag}"] = {"ms_per_4_layers": round(ms, 3), "TFLOPs": round(tf, 1),
@@ -668,6 +676,7 @@ def main():
             "achieved": pf["TFLOPs"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": pf["frac_of_mfma_peak"],
             "gptq_actorder_frac": extra["prefill_m2048_gptq_actorder"]["frac_of_mfma_peak"],
             "awq_bf16_frac": extra["prefill_m2048_awq_bf16"]["frac_of_mfma_peak"],
+            "awq_bf16_shim_frac": extra["prefill_m2048_awq_bf16_shim"]["frac_of_mfma_peak"],
             "mfma_busy_frac": busy, "mfma_busy_source": busy_src, "traffic": None}
         extra.update(hqq_leg(dev))
         try:  # BASELINE configs[4] on one GPU: the per-rank shard shapes of Llama-2-70B at TP = 8

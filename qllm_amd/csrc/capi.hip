@@ -47,6 +47,7 @@ static Settable kSettable[] = {
     {"QLLM_GEMM3_MIN_M", 0, 1 << 30, 0, 0},    // rows from which gemm3 takes over from gemm2 (0: the measured line, 384 / 768)
     {"QLLM_GEMM2_SPLITK", 0, 1, 0, 0},         // 0: never split K over blocks in the tile GEMMs
     {"QLLM_GEMM3_TAIL", 0, 1, 0, 0},           // 0: no K-split of the ragged last round of tiles (gemm3.hip, round 6)
+    {"QLLM_GEMM3_BF16", 0, 1, 0, 0},           // 0: bf16 prefill through the fp16 conversion pre-pass (the reference's shim) instead of bf16 MFMA
     {"QLLM_SKINNY_MAX_M", 0, 64, 0, 0},        // rows up to which the split-K decode kernel serves the reference layouts in place
     {"QLLM_STRIP_MIN", 0, 1 << 20, 0, 0},      // fewest 16-column strips the full-K strip kernels take (0: never)
     {"QLLM_BITGEMV", 0, 1, 0, 0},              // 0: 2 / 5 / 6 / 7 / 8-bit decode calls refused (callers then dequantise + GEMM: the reference's branch)
@@ -575,6 +576,7 @@ struct TileChoice {
   int split_k;
   size_t copy_off;  // kernel 3 with bf16 activations: where the fp16 copy of x sits in the workspace
   int tail_from, tail_split;  // kernel 3, more tiles than CUs: K-split of the ragged last round (tail_split > 1)
+  int native_bf16;            // kernel 3, bf16 activations: no fp16 copy -- bf16 W and bf16 MFMA (gemm3.hip, round 6)
 };
 // large M: the wave-specialised 256x128 kernel (no split-K needed: every CU has at least one tile), also where it can split K; gemm2
 // below.  bf16 activations: gemm3's activation tiles travel by LDS-DMA, which cannot convert, so x is converted to fp16 once into the
@@ -586,22 +588,28 @@ static TileChoice choose_tile(const GemmParams &p, int layout, size_t ws_bytes) 
   if (gemm3_ok(q, layout)) {
     const int S3 = gemm3_split_for(p.M, p.N, p.K, ws_bytes);
     if (gemm2_split_k(p.M, p.N, p.K) == 1 || S3 > 1) {
-      const size_t copy = bf16_copy_bytes(p.M, p.K, p.act_bf16);
+      const int native = p.act_bf16 && gemm3_bf16_native(layout);
+      const size_t copy = native ? 0 : bf16_copy_bytes(p.M, p.K, p.act_bf16);
       const int tiles = ((p.M + 255) / 256) * (p.N / 128);
       int tail_from = tiles;
       // (the slabs of the tail split and the fp16 copy of bf16 activations share the workspace: the copy comes first)
       const int TS = S3 > 1 ? 1 : gemm3_tail_for(p.M, p.N, p.K, ws_bytes > copy ? ws_bytes - copy : 0, &tail_from);
       const size_t used = kCounterBytes + (S3 > 1 ? align_up(gemm2_slab_bytes(p.M, p.N, S3), 256) : align_up(gemm3_tail_slab_bytes(tiles - tail_from, TS), 256));
-      if (!copy || ws_bytes >= used + copy) return TileChoice{3, S3, used, tail_from, TS};
+      if (!copy || ws_bytes >= used + copy) return TileChoice{3, S3, used, tail_from, TS, native};
     }
   }
-  return TileChoice{2, gemm2_split_for(p.M, p.N, p.K, ws_bytes), 0, 0, 0};
+  return TileChoice{2, gemm2_split_for(p.M, p.N, p.K, ws_bytes), 0, 0, 0, 0};
 }
 
 static int run_tile_gemm(GemmParams &p, int layout, void *workspace, size_t workspace_bytes, hipStream_t stream) {
   const TileChoice c = choose_tile(p, layout, usable_ws(workspace, workspace_bytes));
   set_split(p, c.split_k, workspace, c.tail_from, c.tail_split);
   if (c.kernel == 2) return launch_gemm2(p, layout, stream);
+  if (c.native_bf16) {
+    p.native_bf16 = 1;
+    p.act_bf16 = 0;  // (gemm3's own flag means "x was converted": not here)
+    return launch_gemm3(p, layout, stream);
+  }
   if (p.act_bf16) {
     void *xh = (char *)workspace + c.copy_off;
     if (int rc = launch_bf16_to_f16(p.x, xh, (size_t)p.M * p.K, stream)) return rc;
@@ -1034,7 +1042,7 @@ int qllm_linear_forward(const qllm_weight_t *w, const void *x, void *y, int32_t 
     const Decision d = decide_single(w, M, QLLM_F16);
     GemmParams p;
     fill_gemm_params(p, w, x, y, M, QLLM_F16);
-    const TileChoice c = d.route == ROUTE_TILE ? choose_tile(p, d.layout, usable_ws(workspace, workspace_bytes)) : TileChoice{0, 1, 0, 0, 0};
+    const TileChoice c = d.route == ROUTE_TILE ? choose_tile(p, d.layout, usable_ws(workspace, workspace_bytes)) : TileChoice{0, 1, 0, 0, 0, 0};
     if (c.kernel != 3) return set_error(QLLM_ERR_UNSUPPORTED, "QLLM_F16_IN_BF16_OUT: M=%d K=%d N=%d is not served by the 256x128 prefill kernel", M, w->K, w->N);
     set_split(p, c.split_k, workspace, c.tail_from, c.tail_split);
     p.out_bf16 = 1;

@@ -54,8 +54,17 @@ __device__ __forceinline__ int tile_off(int row, int slot) { return row * BK + (
 // 4 x 64 B apart inside its strip instead of 4 x 4N B apart.  fp16 activations.  Requires K % 64 == 0, N % 128 == 0, power-of-two group size >= 32, no g_idx.
 // MW: matrix waves, 4 (one per SIMD, 128x64 each) or 8 (two per SIMD, 64x64 each: 8 fragment reads per 8 MFMAs instead of 6,
 // but the two waves cover each other's LDS / barrier waits); always 4 dequant waves behind them.
-template <int LAYOUT, int MW, bool PRIO = true>
+// BF (round 6, LAYOUT 0 only): NATIVE bf16 -- the activation tiles are the caller's bf16 rows as they are (LDS-DMA moves bytes), the
+// staging waves dequantise to bf16 (q as fp32 via v_cvt_f32_ubyte, one v_pk_fma_f32 per pair: W = bf16(s q - s z), ONE rounding;
+// v_cvt_pk_bf16_f32), the matrix waves run v_mfma_f32_32x32x16_bf16 and the epilogue rounds the fp32 sums to bf16 once.  No conversion
+// pre-pass, no fp16 overflow for |x| > 65504 (the reference's shim casts x to fp16: quant_linear_awq.py:29-36).
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float float2_t __attribute__((ext_vector_type(2)));
+
+template <int LAYOUT, int MW, bool PRIO = true, bool BF = false>
 __global__ __launch_bounds__((MW + 4) * 64) void gemm3_kernel(const GemmParams p) {
+  static_assert(!BF || LAYOUT == 0, "native bf16: row-stream / strip-major 4-bit layers");
   using namespace g3;
   constexpr int AM = 8 / MW * 2;       // 32-row MFMA tiles per matrix wave along M: 4 or 2
   constexpr int WROWS = AM * 32;       // rows per matrix wave: 128 or 64
@@ -189,9 +198,29 @@ __global__ __launch_bounds__((MW + 4) * 64) void gemm3_kernel(const GemmParams p
         const half_t zp = (half_t)(float)(((bs.z >> (4 * (nB & 7))) + (uint32_t)p.add_zero_bias) & 15u);
         const half_t zf = __builtin_bit_cast(half_t, (uint16_t)((nB & 1) ? (bs.z >> 16) : (bs.z & 0xffffu)));
         const half_t sc = __builtin_bit_cast(half_t, (uint16_t)bs.sraw);
-        const ColConst cc = make_col_const(sc, (zk == ZK_PACKED) ? zp : ((zk == ZK_F16) ? zf : (half_t)8.f));
+        if constexpr (BF) {
+          // bf16 W: even / odd nibbles as bytes (k = 2 i / 2 i + 1 in byte i), q -> fp32, (q_a, q_b) s - z s in one packed fma, one
+          // rounding to bf16; pairs come out in natural k order.  (The empty asm keeps hipcc from splitting the two masks back into
+          // one shift + and per nibble.)
+          const float sf = (float)sc, zf32 = (zk == ZK_PACKED) ? (float)zp : ((zk == ZK_F16) ? (float)zf : 8.f);
+          const float2_t s2 = {sf, sf}, nzs2 = {-(zf32 * sf), -(zf32 * sf)};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) *(half8_t *)(Bb + tile_off(bcol, brow + r)) = unperm_04152637(deq_word_k04(bs.w[r], cc, nibmask));
+          for (int r = 0; r < 4; ++r) {
+            uint32_t e = bs.w[r] & 0x0f0f0f0fu, o = (bs.w[r] >> 4) & 0x0f0f0f0fu;
+            asm volatile("" : "+v"(e), "+v"(o));
+            uint32_t out[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float2_t q = {(float)((e >> (8 * i)) & 0xffu), (float)((o >> (8 * i)) & 0xffu)};
+              out[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(__builtin_elementwise_fma(q, s2, nzs2), bf16x2_t));
+            }
+            *(uint4_t *)(Bb + tile_off(bcol, brow + r)) = uint4_t{out[0], out[1], out[2], out[3]};
+          }
+        } else {
+          const ColConst cc = make_col_const(sc, (zk == ZK_PACKED) ? zp : ((zk == ZK_F16) ? zf : (half_t)8.f));
+#pragma unroll
+          for (int r = 0; r < 4; ++r) *(half8_t *)(Bb + tile_off(bcol, brow + r)) = unperm_04152637(deq_word_k04(bs.w[r], cc, nibmask));
+        }
       } else {
         // rows brow..brow+3 of 8 interleaved columns: column c of the word sits at nibble awq_nibble_of_col(c).  Two
         // v_perm build, per column pair, the (k0,k1) and (k2,k3) nibble-bearing 16-bit halves side by side.
@@ -285,7 +314,10 @@ __global__ __launch_bounds__((MW + 4) * 64) void gemm3_kernel(const GemmParams p
 #pragma unroll
     for (int a = h * (AM / 2); a < (h + 1) * (AM / 2); ++a)
 #pragma unroll
-      for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+      for (int b = 0; b < 2; ++b) {
+        if constexpr (BF) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa[a]), __builtin_bit_cast(bf16x8_t, fb[b]), acc[a][b], 0, 0, 0);
+        else acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+      }
   };
 
   if constexpr (PRIO) __builtin_amdgcn_s_setprio(2);  // the matrix wave outranks its SIMD's dequant wave for issue slots
@@ -409,7 +441,8 @@ __global__ __launch_bounds__((MW + 4) * 64) void gemm3_kernel(const GemmParams p
         const float v = acc[a][b][r] + bv[b];
         // bf16 activations (x converted to fp16 by the pre-pass): the result is rounded to fp16 and then to bf16, as the
         // reference's shim does (fp16 kernel output .to(bfloat16), quant_linear_awq.py:29-36, 144-146)
-        if (p.out_bf16) ((uint16_t *)ep)[row * 72 + b * 32 + fr] = f32_to_bf16((float)(half_t)v);
+        if constexpr (BF) ((uint16_t *)ep)[row * 72 + b * 32 + fr] = f32_to_bf16(v);  // (native bf16: one rounding of the fp32 sum)
+        else if (p.out_bf16) ((uint16_t *)ep)[row * 72 + b * 32 + fr] = f32_to_bf16((float)(half_t)v);
         else ep[row * 72 + b * 32 + fr] = (half_t)v;
       }
     // 32 rows x 128 B = 256 chunks of 16 B: 4 per lane (wave-private region: no barrier, the wave's own LDS ops are ordered)
@@ -440,6 +473,9 @@ bool gemm3_ok(const GemmParams &p, int layout) {
   return p.group_size % 32 == 0 && p.gs_shift >= 5;
 }
 
+// bf16 activations served natively (no conversion pre-pass): the 4-bit row-stream / strip-major layouts (the modules' native copies)
+bool gemm3_bf16_native(int layout) { return knob("QLLM_GEMM3_BF16", 1) && layout == QLLM_LAYOUT_GPTQ; }
+
 __global__ __launch_bounds__(256) void bf16_to_f16_kernel(const uint4_t *__restrict__ src, uint4_t *__restrict__ dst, size_t n8) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i < n8) dst[i] = __builtin_bit_cast(uint4_t, bf16x8_to_h8(src[i]));
@@ -452,15 +488,15 @@ int launch_bf16_to_f16(const void *src, void *dst, size_t n, hipStream_t stream)
   return QLLM_OK;
 }
 
-template <int LAYOUT, int MW, bool PRIO = true>
+template <int LAYOUT, int MW, bool PRIO = true, bool BF = false>
 static int launch_gemm3_b(const GemmParams &p, hipStream_t stream) {
   using namespace g3;
   static DeviceLatch attr_done;
-  if (int rc = lds_optin(attr_done, (const void *)gemm3_kernel<LAYOUT, MW, PRIO>)) return rc;
+  if (int rc = lds_optin(attr_done, (const void *)gemm3_kernel<LAYOUT, MW, PRIO, BF>)) return rc;
   const int tiles_all = ((p.M + BM - 1) / BM) * (p.N / BN);
   const int tiles = p.tail_split > 1 ? p.tail_from + (tiles_all - p.tail_from) * p.tail_split : tiles_all * p.split_k;
   const size_t lds = (size_t)(3 * kATile + 2 * kBTile) * sizeof(half_t);  // 128 KB
-  hipLaunchKernelGGL((gemm3_kernel<LAYOUT, MW, PRIO>), dim3(tiles), dim3((MW + 4) * 64), lds, stream, p);
+  hipLaunchKernelGGL((gemm3_kernel<LAYOUT, MW, PRIO, BF>), dim3(tiles), dim3((MW + 4) * 64), lds, stream, p);
   QLLM_HIP_CHECK(hipGetLastError());
   return QLLM_OK;
 }
@@ -502,6 +538,10 @@ int launch_gemm3(const GemmParams &p_in, int layout, hipStream_t stream) {
 #endif
   const int mw = knob("QLLM_GEMM3_MW", 8);  // measured (profiles/r02_prefill_summary.md): 8 matrix waves 908 / 923 / 1004 TFLOP/s, 4: 873 / 915 / 1003
   const int prio = knob("QLLM_GEMM3_PRIO", 1);
+  if (p.native_bf16) {
+    if (layout != QLLM_LAYOUT_GPTQ) return set_error(QLLM_ERR_INVALID, "internal: native bf16 serves the row-stream / strip-major 4-bit layouts");
+    return launch_gemm3_b<0, 8, true, true>(p, stream);
+  }
   if (layout == kGemm3Rows3Bit) return launch_gemm3_b<2, 8>(p, stream);
   if (mw == 4 && !prio) return layout == QLLM_LAYOUT_AWQ_GEMM ? launch_gemm3_b<1, 4, false>(p, stream) : launch_gemm3_b<0, 4, false>(p, stream);
   if (mw == 8) return layout == QLLM_LAYOUT_AWQ_GEMM ? launch_gemm3_b<1, 8>(p, stream) : launch_gemm3_b<0, 8>(p, stream);

@@ -195,6 +195,7 @@ struct GemmParams {
   // rounds of CUs); every tile from tail_from on is shared by tail_split blocks (slab / counter index = tile - tail_from), so that the
   // last round is as full as the others and 1 / tail_split as long.  split_k must be 1 then.
   int tail_from, tail_split;
+  int native_bf16;  // gemm3 (round 6): x is bf16 and stays bf16 -- bf16 W, bf16 MFMA, bf16 y (LAYOUT 0; gemm3_bf16_native())
   int prio;         // gemm4: s_setprio values of its wave roles (matrix | dequant << 4 | loader << 8)
   uint64_t *dbg;    // lab builds (-DQLLM_LAB): gemm4 timeline, 16 x u64 per block (tools/lab/g4lab timeline); NULL otherwise
 };
@@ -203,7 +204,8 @@ int launch_gemm(const GemmParams &p, int layout, hipStream_t stream);
 // ---- gemm2.hip (256x256 tile; fp16 activations, trivial groups, N % 256 == 0) -------------------------------------
 bool gemm2_ok(const GemmParams &p, int layout);
 int gemm2_split_k(int M, int N, int K);
-int gemm3_tail_split(int M, int N, int K, int *tail_from);  // gemm3.hip: K-split factor of the ragged last round of tiles (1: none)
+int gemm3_tail_split(int M, int N, int K, int *tail_from);
+bool gemm3_bf16_native(int layout);  // gemm3.hip: K-split factor of the ragged last round of tiles (1: none)
 int gemm2_tile_n(int M, int N, int split_k);
 size_t gemm2_slab_bytes(int M, int N, int S);
 int launch_gemm2(const GemmParams &p, int layout, hipStream_t stream);

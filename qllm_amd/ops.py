@@ -193,10 +193,18 @@ def linear_forward_bf16_via_f16(w: QllmWeight, x2d: torch.Tensor, key: Optional[
     return out
 
 
+def _bf16_native(w: QllmWeight) -> bool:
+    """Round 6: the 256x128 prefill kernel takes bf16 activations as they are on the 4-bit row-stream / strip-major layouts (bf16 W,
+    bf16 MFMA: csrc/gemm3.hip, BF) -- nothing to convert, nothing to share.  `set_knob("QLLM_GEMM3_BF16", 0)` brings the fp16
+    conversion pre-pass (the reference's shim, quant_linear_awq.py:29-36) back."""
+    return (w.bits == 4 and w.layout in (LAYOUTS["GPTQ"], LAYOUTS["HQQ"], LAYOUTS["NATIVE"], LAYOUTS["NATIVE_F16Z"])
+            and get_knob("QLLM_GEMM3_BF16") != 0)
+
+
 def linear_forward_shared(w: QllmWeight, x2d: torch.Tensor, key: Optional[torch.Tensor] = None) -> torch.Tensor:
     """linear_forward for module code: bf16 prefill calls go through the shared fp16 copy of x where the kernel allows it.  `key`:
     the tensor object whose identity marks "the same input" across sibling calls (default: x2d itself)."""
-    if x2d.dtype == torch.bfloat16 and x2d.shape[0] > 64:
+    if x2d.dtype == torch.bfloat16 and x2d.shape[0] > 64 and not _bf16_native(w):
         try:
             return linear_forward_bf16_via_f16(w, x2d, key)
         except QllmUnsupported:

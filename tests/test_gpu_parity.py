@@ -578,41 +578,57 @@ def test_wave_specialised_prefill_kernel_vs_oracle(layout, g, K, N, zk, bias, na
         assert O.rel_err(y, ref.y64(x)) <= 2e-3, (layout, K, N, m)
     if big:
         return
-    # bf16 activations: the same kernel behind a bf16 -> fp16 pre-pass of x, the fp16 result rounded to bf16 (the reference's shim)
+    # bf16 activations.  Round 6: on the 4-bit row-stream / strip-major layouts the kernel takes them NATIVELY (bf16 W, bf16 MFMA, one
+    # rounding of the fp32 sums); AWQ words in place keep the reference's shim (x -> fp16 pre-pass, fp16 result rounded to bf16)
     xb = torch.from_numpy(randx(4096, K, seed=3)).to(torch.bfloat16)
     yb = layer(xb.to(DEV))
     assert yb.dtype == torch.bfloat16
     assert O.rel_err(yb.float().cpu().numpy(), ref.y64(xb.to(torch.float16).numpy())) <= TOL
-    # the module call above went through the SHARED fp16 copy of x (QLLM_F16_IN_BF16_OUT, ops.linear_forward_bf16_via_f16): it must
-    # be bit-identical to the plain bf16 call of the C ABI, which converts x into the workspace itself; and a sibling called with
-    # the same tensor converts nothing
     xd = xb.to(DEV)
-    y_plain = ops.linear_forward(layer.decode_descriptor(), xd)
-    assert torch.equal(layer(xd), y_plain)
-    calls = []
-    real = ops._lib.load().qllm_convert_bf16_to_f16
-    h0 = ops.bf16_as_f16(xd)
-    assert ops.bf16_as_f16(xd) is h0 and torch.equal(h0, xd.to(torch.float16))
-    xd.add_(0)   # an in-place update bumps the version: converted again
-    assert ops.bf16_as_f16(xd) is not h0
-    del calls, real
-    # ... through the MODULES the key is the tensor object the forward received (x.reshape(-1, K) is a fresh object on every call and
-    # never hit: ADVICE r04): two sibling-like calls with one 3-D tensor share one copy; a call the 256x128 kernel does not serve
-    # (here: 100 rows -> the panel kernel) converts nothing; the copy dies with its input
-    seen, real_conv = [], ops.bf16_as_f16
-    ops.bf16_as_f16 = lambda x2d, key=None: (lambda r: (seen.append(r), r)[1])(real_conv(x2d, key))
+    if ops._bf16_native(layer.decode_descriptor()):
+        try:
+            ops.set_knob("QLLM_GEMM3_BF16", 0)
+            y_shim = layer(xd)
+        finally:
+            ops.reset_knobs()
+        assert y_shim.dtype == torch.bfloat16 and not torch.equal(y_shim, yb)       # (another kernel instantiation ran)
+        assert O.rel_err(yb.float().cpu().numpy(), y_shim.float().cpu().numpy()) <= TOL    # two bf16 roundings of nearly equal sums (an output ulp is 2^-8 relative)
+        assert torch.equal(layer(xd), yb)                                            # deterministic
+    # ---- the shim path (every layout with QLLM_GEMM3_BF16 = 0; AWQ in place always) ------------------------------------------------
     try:
-        x3 = xd.reshape(2, 2048, K)
-        layer(x3), layer(x3)
-        assert len(seen) == 2 and seen[0] is seen[1], len(seen)
-        seen.clear()
-        layer(xd[:100].contiguous())
-        assert not seen
-        del x3
-        seen.clear()
+        ops.set_knob("QLLM_GEMM3_BF16", 0)
+        # the module call above went through the SHARED fp16 copy of x (QLLM_F16_IN_BF16_OUT, ops.linear_forward_bf16_via_f16): it must
+        # be bit-identical to the plain bf16 call of the C ABI, which converts x into the workspace itself; and a sibling called with
+        # the same tensor converts nothing
+        y_plain = ops.linear_forward(layer.decode_descriptor(), xd)
+        assert torch.equal(layer(xd), y_plain)
+        calls = []
+        real = ops._lib.load().qllm_convert_bf16_to_f16
+        h0 = ops.bf16_as_f16(xd)
+        assert ops.bf16_as_f16(xd) is h0 and torch.equal(h0, xd.to(torch.float16))
+        xd.add_(0)   # an in-place update bumps the version: converted again
+        assert ops.bf16_as_f16(xd) is not h0
+        del calls, real
+        # ... through the MODULES the key is the tensor object the forward received (x.reshape(-1, K) is a fresh object on every call and
+        # never hit: ADVICE r04): two sibling-like calls with one 3-D tensor share one copy; a call the 256x128 kernel does not serve
+        # (here: 100 rows -> the panel kernel) converts nothing; the copy dies with its input
+        seen, real_conv = [], ops.bf16_as_f16
+        ops.bf16_as_f16 = lambda x2d, key=None: (lambda r: (seen.append(r), r)[1])(real_conv(x2d, key))
+        try:
+            x3 = xd.reshape(2, 2048, K)
+            layer(x3), layer(x3)
+            assert len(seen) == 2 and seen[0] is seen[1], len(seen)
+            seen.clear()
+            layer(xd[:100].contiguous())
+            assert not seen
+            del x3
+            seen.clear()
+        finally:
+            ops.bf16_as_f16 = real_conv
+        assert xd.device not in ops._LAST_CONVERT or ops._LAST_CONVERT[xd.device][0]() is not None
+
     finally:
-        ops.bf16_as_f16 = real_conv
-    assert xd.device not in ops._LAST_CONVERT or ops._LAST_CONVERT[xd.device][0]() is not None
+        ops.reset_knobs()
     # determinism: same launch twice -> same bits
     x = torch.from_numpy(randx(4096, K, seed=9)).to(DEV)
     assert ops.plan_describe([layer._descriptor(None, 0)], 4096).startswith("gemm3")
