@@ -127,6 +127,8 @@ __global__ __launch_bounds__((MW + 4) * 64) void gemm3_kernel(const GemmParams p
     const int brow = ROWS ? 4 * (t >> 7) : 4 * (t >> 4);
     const int nB = n0 + bcol;
     const uint32_t nibmask = nib_mask_vgpr();
+    uint32_t himask;
+    asm volatile("v_mov_b32 %0, 0x00f000f0" : "=v"(himask));  // (held in a VGPR for the same reason as nibmask: one v_and_or_b32)
     const int zk = p.zero_kind;
     const uint32_t *zbase = (zk == ZK_SYM) ? (const uint32_t *)p.scales : (const uint32_t *)p.qzeros;
     // zero points: words per group row (zmul), this column's word inside the row (zoff), and -- strip-major storage (p.sm, row-stream
@@ -218,8 +220,20 @@ __global__ __launch_bounds__((MW + 4) * 64) void gemm3_kernel(const GemmParams p
           }
         } else {
           const ColConst cc = make_col_const(sc, (zk == ZK_PACKED) ? zp : ((zk == ZK_F16) ? zf : (half_t)8.f));
+          // Round 6: the odd nibbles are taken where they sit (bits 4..7 of each half) under the pattern 0x5400 = 64.0 -- an fp16 in
+          // [64, 128) has ulp 1/16, so mantissa bits 4..7 weigh exactly 1, 2, 4, 8: r = 64 + q -- and fma(r, s, -64 s) is q s rounded
+          // once, like fma(1024 + q, s, -1024 s) for the even ones: the same three-rounding W bit for bit, one shift per word instead
+          // of three (13 VALU per 8 weights instead of 15: the staging waves' issue slots are what the matrix waves wait for).
+          const half2_t c64 = splat2((half_t)(-64.0f) * sc);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) *(half8_t *)(Bb + tile_off(bcol, brow + r)) = unperm_04152637(deq_word_k04(bs.w[r], cc, nibmask));
+          for (int r = 0; r < 4; ++r) {
+            const uint32_t w0 = bs.w[r], w8 = bs.w[r] >> 8;
+            const half2_t b0 = deq_pair(and_or(w0, nibmask, kMagic), cc);                                                   // (k0, k4)
+            const half2_t b1 = __builtin_elementwise_fma(as_h2(and_or(w0, himask, 0x54005400u)), cc.s2, c64) - cc.zs2;     // (k1, k5)
+            const half2_t b2 = deq_pair(and_or(w8, nibmask, kMagic), cc);                                                   // (k2, k6)
+            const half2_t b3 = __builtin_elementwise_fma(as_h2(and_or(w8, himask, 0x54005400u)), cc.s2, c64) - cc.zs2;     // (k3, k7)
+            *(half8_t *)(Bb + tile_off(bcol, brow + r)) = half8_t{b0.x, b1.x, b2.x, b3.x, b0.y, b1.y, b2.y, b3.y};
+          }
         }
       } else {
         // rows brow..brow+3 of 8 interleaved columns: column c of the word sits at nibble awq_nibble_of_col(c).  Two

@@ -45,3 +45,26 @@ def test_tail_split_matches_oracle_and_unsplit_launch(layout, K, N, M, ts):
     # the workspace is left clean (counters re-armed): a split-K decode call right after still works
     y1 = layer(xt[:1])
     assert O.rel_err(y1.cpu().numpy(), ref.y16(x[:1])) <= TOL
+
+
+@pytest.mark.parametrize("layout,g,zk", [("GPTQ", 128, "asym"), ("GEMM", 128, "asym"), ("HQQ", 64, "f16"), ("GPTQ", 32, "sym")])
+def test_prefill_kernel_dequantises_bit_exactly(layout, g, zk):
+    """x = the identity (4096 one-hot rows): y IS the kernel's W, every product exact and alone in its fp32 sum -- it must equal the
+    reference's fp16(fp16(s q) - fp16(z s)) (DequantizeLinearBlockWise, quant_linear_gptq.py:46-48) bit for bit.  Pins the staging waves'
+    arithmetic of gemm3 (round 6: odd nibbles under the 64 + q pattern, even ones under 1024 + q) on the native copy and in place."""
+    import os
+    from qllm_amd import ops
+    from gpu_util import oracle_w
+    K, N = 4096, 512
+    d = synth(layout, 4, g, K, N, zk, False, False, seed=g + N)
+    want = oracle_w(d)                                   # [K, N] fp16, the oracle's (= the reference's) W
+    eye = torch.eye(K, dtype=torch.float16, device=DEV)
+    for native in ("1", "0"):
+        os.environ["QLLM_NATIVE_LAYOUT"] = native
+        try:
+            layer = to_layer(d, DEV)
+            assert ops.plan_describe([layer.decode_descriptor()], K).startswith("gemm3"), ops.plan_describe([layer.decode_descriptor()], K)
+            got = layer(eye).cpu().numpy()
+        finally:
+            os.environ.pop("QLLM_NATIVE_LAYOUT", None)
+        assert np.array_equal(got.view(np.uint16), want.view(np.uint16)), (layout, native)
