@@ -47,6 +47,7 @@ static Settable kSettable[] = {
     {"QLLM_GEMM3_MIN_M", 0, 1 << 30, 0, 0},    // rows from which gemm3 takes over from gemm2 (0: the measured line, 384 / 768)
     {"QLLM_GEMM2_SPLITK", 0, 1, 0, 0},         // 0: never split K over blocks in the tile GEMMs
     {"QLLM_GEMM3_TAIL", 0, 1, 0, 0},           // 0: no K-split of the ragged last round of tiles (gemm3.hip, round 6)
+    {"QLLM_GEMM3_GROUP", 0, 1, 0, 0},          // 0: no grouped launches of the prefill kernel (q/k/v, gate/up run layer by layer from 129 rows)
     {"QLLM_GEMM3_BF16", 0, 1, 0, 0},           // 0: bf16 prefill through the fp16 conversion pre-pass (the reference's shim) instead of bf16 MFMA
     {"QLLM_SKINNY_MAX_M", 0, 64, 0, 0},        // rows up to which the split-K decode kernel serves the reference layouts in place
     {"QLLM_STRIP_MIN", 0, 1 << 20, 0, 0},      // fewest 16-column strips the full-K strip kernels take (0: never)
@@ -704,7 +705,7 @@ static bool native_prefill_ok(const qllm_weight_t *w, GemmParams &p) {
 // decide_single / decide_group are the ONLY place a kernel family is chosen: qllm_linear_forward(_grouped) executes the Decision,
 // qllm_plan_describe prints it.  The workspace-dependent sub-choices (split-K, which 256-row-tile kernel) are choose_tile /
 // *_split_for above, again shared by both.
-enum Route { ROUTE_NONE = 0, ROUTE_STRIP, ROUTE_PANEL, ROUTE_ROWS3, ROUTE_TILE, ROUTE_GEMM, ROUTE_SKINNY, ROUTE_BITGEMV };
+enum Route { ROUTE_NONE = 0, ROUTE_STRIP, ROUTE_PANEL, ROUTE_ROWS3, ROUTE_TILE, ROUTE_GEMM, ROUTE_SKINNY, ROUTE_BITGEMV, ROUTE_TILE_GROUP };
 struct Decision {
   Route route;
   StripPlan strip;  // ROUTE_STRIP
@@ -757,11 +758,36 @@ static Decision decide_single(const qllm_weight_t *w, int M, int act_dtype) {
 }
 
 // n >= 2 validated layers sharing x; INVALID when they cannot share a launch at all, UNSUPPORTED when no grouped kernel takes them
-static Decision decide_group(const qllm_weight_t *w, int n, int M) {
+// prefill-sized groups (round 6): q/k/v, gate/up as ONE launch of the 256x128 kernel -- its grid carries the tiles of up to 4 layers, so
+// the rounds of CUs are counted over the group (Llama-2-7B gate/up: 1376 tiles = 5.4 rounds, with the last one K-split, instead of
+// 2 x 2.7 -> 2 x 3) and the group costs one launch boundary.  4-bit row-stream / strip-major layers of one storage kind, whole tiles,
+// at least one tile per CU (no split-K inside a group); bf16 only where the kernel takes it natively.
+static int group_tiles(const qllm_weight_t *w, int n, int M) {
+  int t = 0;
+  for (int i = 0; i < n; ++i) t += ((M + 255) / 256) * (w[i].N / 128);
+  return t;
+}
+static bool tile_group_serves(const qllm_weight_t *w, int n, int M, int act_dtype) {
+  if (!knob("QLLM_GEMM3_GROUP", 1) || !knob("QLLM_GEMM3", 1) || n < 2 || n > kGemm3MaxProb || M < 384) return false;
+  const int gs = w[0].group_size;
+  if (w[0].bits != 4 || w[0].K % 64 != 0 || gs < 32 || (gs & (gs - 1)) != 0) return false;
+  if (act_dtype == QLLM_BF16 && !gemm3_bf16_native(QLLM_LAYOUT_GPTQ)) return false;
+  for (int i = 0; i < n; ++i) {
+    if (w[i].layout == QLLM_LAYOUT_AWQ_GEMM || w[i].g_idx || w[i].N % 128 != 0 || is_native(w[i]) != is_native(w[0])) return false;
+    if ((uintptr_t)w[i].qweight % 16 || (uintptr_t)w[i].scales % 16 || (w[i].qzeros && (uintptr_t)w[i].qzeros % 8)) return false;
+    if ((size_t)M * w[i].K * 2 >= 0x7fffffffull || (size_t)w[i].K * w[i].N / 2 >= 0x7fffffffull) return false;
+  }
+  return group_tiles(w, n, M) >= compute_units();
+}
+
+static Decision decide_group(const qllm_weight_t *w, int n, int M, int act_dtype) {
   for (int i = 0; i < n; ++i) {
     if (w[i].K != w[0].K || w[i].group_size != w[0].group_size || w[i].bits != w[0].bits || layout_family(w[0]) != layout_family(w[i]) ||
         w[i].add_zero_bias != w[0].add_zero_bias)
       return refused(set_error(QLLM_ERR_INVALID, "grouped weights must agree on K, group_size, bits, layout family and add_zero_bias"));
+  }
+  if (tile_group_serves(w, n, M, act_dtype)) return routed(ROUTE_TILE_GROUP, QLLM_LAYOUT_GPTQ);  // (prefill sizes: M >= 384)
+  for (int i = 0; i < n; ++i) {
     if (w[i].bits == 3 || is_native(w[i])) continue;  // decided as a group by strip_plan below
     if (!skinny_ok(w[i], M))
       return refused(set_error(QLLM_ERR_UNSUPPORTED, "grouped forward needs the decode kernel (4-bit, M<=%d, K%%32==0, no act-order)", skinny_max_m()));
@@ -770,7 +796,7 @@ static Decision decide_group(const qllm_weight_t *w, int n, int M) {
   if (strip_plan(w, n, M, &d.strip)) return d;
   if (panel_group_serves(w, n, M)) return routed(ROUTE_PANEL);
   if (is_native(w[0]))
-    return refused(set_error(QLLM_ERR_UNSUPPORTED, "grouped forward: native-layout layers are served for M <= 32 (4 bits: <= 128) with group size 64 / 128 (4 bits: also 32) (M=%d g=%d)", M, w[0].group_size));
+    return refused(set_error(QLLM_ERR_UNSUPPORTED, "grouped forward: native-layout layers are served for M <= 32 (4 bits: <= 128) with group size 64 / 128 (4 bits: also 32), and 4-bit groups of at least one 256x128 tile per CU from 384 rows (M=%d g=%d)", M, w[0].group_size));
   if (w[0].bits != 4) return refused(set_error(QLLM_ERR_UNSUPPORTED, "grouped forward: no fused kernel for %d-bit weights in this shape", w[0].bits));
   return routed(ROUTE_SKINNY);
 }
@@ -804,6 +830,44 @@ static int run_bitgemv(const qllm_weight_t *w, void *y, const void *x, int M, in
   return launch_bitgemv(p, w->bits, stream);
 }
 
+static int tile_group_tail_for(const qllm_weight_t *w, int n, int M, size_t ws_bytes, int *tail_from) {
+  const int tiles = group_tiles(w, n, M);
+  const int TS = gemm3_tail_split_tiles(tiles, w[0].K, tail_from);
+  if (TS <= 1 || ws_bytes < kCounterBytes + gemm3_tail_slab_bytes(tiles - *tail_from, TS) || tiles - *tail_from > (int)(kCounterBytes / sizeof(int))) {
+    *tail_from = tiles;
+    return 1;
+  }
+  return TS;
+}
+static int run_tile_group(const qllm_weight_t *w, void *const *y, int n, const void *x, int M, int act_dtype, void *workspace, size_t workspace_bytes,
+                          hipStream_t stream) {
+  GemmParams p;
+  fill_gemm_params(p, &w[0], x, y[0], M, act_dtype);
+  p.n_prob = n;
+  int begin = 0;
+  for (int i = 0; i < n; ++i) {
+    GemmProb &q = p.prob[i];
+    q.qweight = (const uint32_t *)w[i].qweight;
+    q.scales = (const half_t *)w[i].scales;
+    q.qzeros = w[i].qzeros;
+    q.bias = (const half_t *)w[i].bias;
+    q.y = y[i];
+    q.N = w[i].N;
+    q.zero_kind = zero_kind_of(w[i]);
+    q.tile_begin = begin;
+    begin += ((M + 255) / 256) * (w[i].N / 128);
+  }
+  p.total_tiles = begin;
+  int tail_from = begin;
+  const int TS = tile_group_tail_for(w, n, M, usable_ws(workspace, workspace_bytes), &tail_from);
+  set_split(p, 1, workspace, tail_from, TS);
+  if (act_dtype == QLLM_BF16) {
+    p.native_bf16 = 1;
+    p.act_bf16 = 0;
+  }
+  return launch_gemm3(p, QLLM_LAYOUT_GPTQ, stream);
+}
+
 // the Decision, executed
 static int execute(const Decision &d, const qllm_weight_t *w, void *const *y, int n, const void *x, int M, int act_dtype, void *workspace,
                    size_t workspace_bytes, hipStream_t stream) {
@@ -811,6 +875,7 @@ static int execute(const Decision &d, const qllm_weight_t *w, void *const *y, in
     case ROUTE_STRIP: return run_strip(d.strip, w, y, n, x, M, act_dtype, stream);
     case ROUTE_PANEL: return run_panel(w, y, n, x, M, act_dtype, workspace, workspace_bytes, stream);
     case ROUTE_SKINNY: return run_skinny(w, y, n, x, M, act_dtype, workspace, workspace_bytes, stream);
+    case ROUTE_TILE_GROUP: return run_tile_group(w, y, n, x, M, act_dtype, workspace, workspace_bytes, stream);
     case ROUTE_BITGEMV: return run_bitgemv(w, y[0], x, M, act_dtype, workspace, workspace_bytes, stream);
     case ROUTE_ROWS3: case ROUTE_TILE: case ROUTE_GEMM: {
       GemmParams p;
@@ -860,6 +925,13 @@ static void describe(const Decision &d, const qllm_weight_t *w, int n, int M, si
       else if (c.kernel == 3 && c.split_k > 1) snprintf(buf, buflen, "gemm3 tile=256x128 matrix-waves=8 staging-waves=4 split_k=%d%s", c.split_k, sm);
       else if (c.kernel == 3) snprintf(buf, buflen, "gemm3 tile=256x128 matrix-waves=8 staging-waves=4%s", sm);
       else snprintf(buf, buflen, "gemm2 tile=256x%d split_k=%d%s", gemm2_tile_n(M, w[0].N, c.split_k), c.split_k, sm);
+      return;
+    }
+    case ROUTE_TILE_GROUP: {
+      int tail_from = 0;
+      const int TS = tile_group_tail_for(w, n, M, ws_bytes, &tail_from);
+      if (TS > 1) snprintf(buf, buflen, "gemm3 tile=256x128 matrix-waves=8 staging-waves=4 layers=%d tail_split=%d%s", n, TS, sm);
+      else snprintf(buf, buflen, "gemm3 tile=256x128 matrix-waves=8 staging-waves=4 layers=%d%s", n, sm);
       return;
     }
     case ROUTE_GEMM: snprintf(buf, buflen, "gemm tile=128x128%s", w[0].g_idx ? " act-order-gather" : ""); return;
@@ -996,7 +1068,7 @@ int qllm_linear_forward_grouped(const qllm_weight_t *w, void *const *y, int32_t 
     rc = check_io(x, y[i], M, act_dtype);
     if (rc) return rc;
   }
-  const Decision d = decide_group(w, n_weights, M);
+  const Decision d = decide_group(w, n_weights, M, act_dtype);
   return execute(d, w, y, n_weights, x, M, act_dtype, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
@@ -1139,7 +1211,7 @@ int qllm_plan_describe(const qllm_weight_t *w, int32_t n_weights, int32_t M, int
     const int rc = validate_weight(&w[i]);
     if (rc) return rc;
   }
-  const Decision d = n_weights == 1 ? decide_single(&w[0], M, QLLM_F16) : decide_group(w, n_weights, M);
+  const Decision d = n_weights == 1 ? decide_single(&w[0], M, QLLM_F16) : decide_group(w, n_weights, M, QLLM_F16);
   if (d.route == ROUTE_NONE && d.rc == QLLM_ERR_INVALID) return d.rc;  // (layers that cannot share a launch at all: the forward call's own status)
   describe(d, w, n_weights, M, have_workspace ? (size_t)-1 : 0, buf, buflen);
   clear_error();

@@ -76,7 +76,11 @@ __global__ __launch_bounds__((MW + 4) * 64) void gemm3_kernel(const GemmParams p
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = p.N / BN;
+  // Round 6, grouped launches (p.n_prob > 1: layers sharing x -- q/k/v, gate/up -- in ONE grid): the tiles of layer 0 come first, then
+  // layer 1's ...; a block looks its layer up from its tile id and takes that layer's pointers and width (P* below).  The rounds of
+  // tiles are counted over the whole group: gate/up of Llama-2-7B are 1376 tiles = 5.4 rounds instead of 2 x 2.7 -> 2 x 3.
+  const int tiles_m = (p.M + BM - 1) / BM;
+  const int tiles_all = p.n_prob > 1 ? p.total_tiles : tiles_m * (p.N / BN);
   // split-K (p.split_k > 1: fewer tiles than CUs): S consecutive block ids share an output tile and own consecutive K ranges;
   // each publishes its fp32 partial tile to a slab, the last to arrive sums them in fixed order (the protocol of gemm2.hip)
   // Round 6, tail split (p.tail_split > 1, tiles > CUs): the tiles of the whole rounds run unsplit; the tiles of the ragged last round
@@ -93,7 +97,7 @@ __global__ __launch_bounds__((MW + 4) * 64) void gemm3_kernel(const GemmParams p
       ksplit = 0;
       tile_id = slab_tile = xcd_run(bid, F);
     } else {
-      const int u = xcd_run(bid - F, (tiles_m * tiles_n - F) * p.tail_split);
+      const int u = xcd_run(bid - F, (tiles_all - F) * p.tail_split);
       S = p.tail_split;
       ksplit = u % S;
       slab_tile = u / S;
@@ -101,12 +105,25 @@ __global__ __launch_bounds__((MW + 4) * 64) void gemm3_kernel(const GemmParams p
     }
   } else {
     S = p.split_k;
-    const int bid = xcd_run(blockIdx.x, tiles_m * tiles_n * S);
+    const int bid = xcd_run(blockIdx.x, tiles_all * S);
     ksplit = bid % S;
     tile_id = slab_tile = bid / S;
   }
   S = __builtin_amdgcn_readfirstlane(S);
-  const int bid = tile_id;
+  const uint32_t *Pqweight = p.qweight;
+  const half_t *Pscales = p.scales, *Pbias = p.bias;
+  const void *Pqzeros = p.qzeros;
+  void *Py = p.y;
+  int PN = p.N, Pzk = p.zero_kind, bid = tile_id;
+  if (p.n_prob > 1) {
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < kGemm3MaxProb; ++i) pi += (i < p.n_prob && tile_id >= p.prob[i].tile_begin) ? 1 : 0;
+    const GemmProb &q = p.prob[pi];
+    Pqweight = q.qweight; Pscales = q.scales; Pbias = q.bias; Pqzeros = q.qzeros; Py = q.y;
+    PN = q.N; Pzk = q.zero_kind; bid = tile_id - q.tile_begin;
+  }
+  const int tiles_n = PN / BN;
   // p.raster 1: n fastest (an XCD's run shares activation rows, which stay in its L2 while the small packed weights stream)
   const int tm = p.raster ? (bid / tiles_n) : (bid % tiles_m);
   const int tn = p.raster ? (bid % tiles_n) : (bid / tiles_m);
@@ -129,14 +146,14 @@ __global__ __launch_bounds__((MW + 4) * 64) void gemm3_kernel(const GemmParams p
     const uint32_t nibmask = nib_mask_vgpr();
     uint32_t himask;
     asm volatile("v_mov_b32 %0, 0x00f000f0" : "=v"(himask));  // (held in a VGPR for the same reason as nibmask: one v_and_or_b32)
-    const int zk = p.zero_kind;
-    const uint32_t *zbase = (zk == ZK_SYM) ? (const uint32_t *)p.scales : (const uint32_t *)p.qzeros;
+    const int zk = Pzk;
+    const uint32_t *zbase = (zk == ZK_SYM) ? (const uint32_t *)Pscales : (const uint32_t *)Pqzeros;
     // zero points: words per group row (zmul), this column's word inside the row (zoff), and -- strip-major storage (p.sm, row-stream
     // layouts only) -- the word offset of the column's strip (zstrip; group rows then hold the strip's 16 columns only: 2 or 8 words)
     const int Gn = (p.K + (1 << p.gs_shift) - 1) >> p.gs_shift;
     const bool sm = ROWS && p.sm;
     const int ncs = sm ? (nB & 15) : nB;  // column index inside a row of the scale / zero tables
-    const int zmul_all = (zk == ZK_PACKED) ? (LAYOUT == 2 ? (p.N * 3) >> 5 : (p.N >> 3)) : (p.N >> 1);  // words per group over all columns
+    const int zmul_all = (zk == ZK_PACKED) ? (LAYOUT == 2 ? (PN * 3) >> 5 : (PN >> 3)) : (PN >> 1);  // words per group over all columns
     const int zmul = sm ? ((zk == ZK_PACKED) ? 2 : 8) : zmul_all;
     const int zoff = ((zk == ZK_PACKED) ? (LAYOUT == 2 ? (ncs * 3) >> 5 : (ncs >> 3)) : (ncs >> 1)) + (sm ? (nB >> 4) * Gn * zmul : 0);
     const int zoff2 = (LAYOUT == 2 && zk == ZK_PACKED && (sm ? ((ncs * 3) >> 5) == 0 : zoff + 1 < zmul)) ? 1 : 0;  // packed 3-bit zero points may straddle two words
@@ -148,16 +165,16 @@ __global__ __launch_bounds__((MW + 4) * 64) void gemm3_kernel(const GemmParams p
     };
     BSet bset[2];
     // buffer loads: per-lane byte offsets are loop constants, the k-tile / group advance is a scalar offset (SALU only)
-    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc((void *)p.qweight, 0, (int)((size_t)p.K * p.N / 2), 0x00020000);
-    const auto rs_s = __builtin_amdgcn_make_buffer_rsrc((void *)p.scales, 0, Gn * p.N * 2, 0x00020000);
+    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc((void *)Pqweight, 0, (int)((size_t)p.K * PN / 2), 0x00020000);
+    const auto rs_s = __builtin_amdgcn_make_buffer_rsrc((void *)Pscales, 0, Gn * PN * 2, 0x00020000);
     // (strip-major: every strip has whole words of its own -- 3-bit zero points take 2 words per 16 columns, not 1.5)
-    const auto rs_z = __builtin_amdgcn_make_buffer_rsrc((void *)zbase, 0, (sm ? (p.N >> 4) * Gn * zmul : Gn * zmul_all) * 4, 0x00020000);
-    const int wrow_bytes = sm ? 64 : (ROWS ? p.N * 4 : (p.N >> 3) * 4);     // bytes per packed row (strip-major: the strip's 16 words)
+    const auto rs_z = __builtin_amdgcn_make_buffer_rsrc((void *)zbase, 0, (sm ? (PN >> 4) * Gn * zmul : Gn * zmul_all) * 4, 0x00020000);
+    const int wrow_bytes = sm ? 64 : (ROWS ? PN * 4 : (PN >> 3) * 4);     // bytes per packed row (strip-major: the strip's 16 words)
     const int ktile_bytes = (LAYOUT == 0 ? 8 : (LAYOUT == 2 ? 6 : BK)) * wrow_bytes;  // packed rows per k-tile: 8 / 6 (3 bits) / 64 (AWQ)
     const int strip_rows = (LAYOUT == 2) ? (p.K * 3) >> 5 : (p.K >> 3);      // word rows of one strip
     const int voff_w = (LAYOUT == 2 ? 3 * (t >> 7) : brow) * wrow_bytes +
                        (sm ? (nB >> 4) * strip_rows * 64 + ncs * 4 : (ROWS ? nB * 4 : (nB >> 3) * 4));
-    const int srow_bytes = sm ? 32 : p.N * 2;                                // bytes per group row of the scale table
+    const int srow_bytes = sm ? 32 : PN * 2;                                // bytes per group row of the scale table
     const int voff_s = sm ? (nB >> 4) * Gn * 32 + ncs * 2 : nB * 2, voff_z = zoff * 4;
     const int krow0 = ROWS ? 8 * brow : brow;                               // this thread's first k inside a k-tile
     auto load_b = [&](int kt, BSet &bs) {
@@ -444,7 +461,7 @@ __global__ __launch_bounds__((MW + 4) * 64) void gemm3_kernel(const GemmParams p
   half_t *ep = smem + wave * (32 * 72);  // 32 rows x 64 cols, row stride 72 halves (144 B)
   float bv[2];
 #pragma unroll
-  for (int b = 0; b < 2; ++b) bv[b] = p.bias ? (float)p.bias[n0 + wn * 64 + b * 32 + fr] : 0.f;
+  for (int b = 0; b < 2; ++b) bv[b] = Pbias ? (float)Pbias[n0 + wn * 64 + b * 32 + fr] : 0.f;
 #pragma unroll
   for (int a = 0; a < AM; ++a) {
 #pragma unroll
@@ -465,7 +482,7 @@ __global__ __launch_bounds__((MW + 4) * 64) void gemm3_kernel(const GemmParams p
       const int c = lane + 64 * h, row = c >> 3, ch = c & 7;
       const uint4_t v = *(const uint4_t *)(ep + row * 72 + ch * 8);
       const int m = m0 + wm * WROWS + a * 32 + row;
-      if (m < p.M) *(uint4_t *)((half_t *)p.y + (size_t)m * p.N + n0 + wn * 64 + ch * 8) = v;
+      if (m < p.M) *(uint4_t *)((half_t *)Py + (size_t)m * PN + n0 + wn * 64 + ch * 8) = v;
     }
   }
 }
@@ -507,7 +524,7 @@ static int launch_gemm3_b(const GemmParams &p, hipStream_t stream) {
   using namespace g3;
   static DeviceLatch attr_done;
   if (int rc = lds_optin(attr_done, (const void *)gemm3_kernel<LAYOUT, MW, PRIO, BF>)) return rc;
-  const int tiles_all = ((p.M + BM - 1) / BM) * (p.N / BN);
+  const int tiles_all = p.n_prob > 1 ? p.total_tiles : ((p.M + BM - 1) / BM) * (p.N / BN);
   const int tiles = p.tail_split > 1 ? p.tail_from + (tiles_all - p.tail_from) * p.tail_split : tiles_all * p.split_k;
   const size_t lds = (size_t)(3 * kATile + 2 * kBTile) * sizeof(half_t);  // 128 KB
   hipLaunchKernelGGL((gemm3_kernel<LAYOUT, MW, PRIO, BF>), dim3(tiles), dim3((MW + 4) * 64), lds, stream, p);
@@ -528,8 +545,9 @@ int gemm3_split_k(int M, int N, int K) {
 // of Llama-2-7B run at 970-1070): the r = tiles mod CUs tiles of that round are shared by TS blocks each -- the largest power of two with
 // r * TS <= CUs, whole k-tile counts and >= 16 k-tiles per block (the fix-up moves 2 x 128 KB per block: below that it eats the gain).
 // Returns TS (1: none) and the number of unsplit tiles in *tail_from.
-int gemm3_tail_split(int M, int N, int K, int *tail_from) {
-  const int tiles = ((M + 255) / 256) * (N / 128), cus = compute_units(), kt = K / 64;
+int gemm3_tail_split(int M, int N, int K, int *tail_from) { return gemm3_tail_split_tiles(((M + 255) / 256) * (N / 128), K, tail_from); }
+int gemm3_tail_split_tiles(int tiles, int K, int *tail_from) {
+  const int cus = compute_units(), kt = K / 64;
   *tail_from = tiles;
   if (!knob("QLLM_GEMM3_TAIL", 1) || tiles <= cus || tiles % cus == 0) return 1;
   const int r = tiles % cus;

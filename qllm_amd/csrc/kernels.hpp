@@ -195,6 +195,17 @@ struct GemmParams {
   // rounds of CUs); every tile from tail_from on is shared by tail_split blocks (slab / counter index = tile - tail_from), so that the
   // last round is as full as the others and 1 / tail_split as long.  split_k must be 1 then.
   int tail_from, tail_split;
+  // gemm3, round 6: layers sharing x in ONE launch (q/k/v, gate/up at prefill sizes).  n_prob > 1: the single-layer pointer fields
+  // above are unused; total_tiles = sum of the layers' 256x128 tiles, layer i's tiles are [tile_begin, tile_begin + tiles_m * N / 128)
+  int n_prob, total_tiles;
+  struct GemmProb {
+    const uint32_t *qweight;
+    const half_t *scales;
+    const void *qzeros;
+    const half_t *bias;
+    void *y;
+    int N, zero_kind, tile_begin, pad_;
+  } prob[4];
   int native_bf16;  // gemm3 (round 6): x is bf16 and stays bf16 -- bf16 W, bf16 MFMA, bf16 y (LAYOUT 0; gemm3_bf16_native())
   int prio;         // gemm4: s_setprio values of its wave roles (matrix | dequant << 4 | loader << 8)
   uint64_t *dbg;    // lab builds (-DQLLM_LAB): gemm4 timeline, 16 x u64 per block (tools/lab/g4lab timeline); NULL otherwise
@@ -204,7 +215,10 @@ int launch_gemm(const GemmParams &p, int layout, hipStream_t stream);
 // ---- gemm2.hip (256x256 tile; fp16 activations, trivial groups, N % 256 == 0) -------------------------------------
 bool gemm2_ok(const GemmParams &p, int layout);
 int gemm2_split_k(int M, int N, int K);
+constexpr int kGemm3MaxProb = 4;
+using GemmProb = GemmParams::GemmProb;
 int gemm3_tail_split(int M, int N, int K, int *tail_from);
+int gemm3_tail_split_tiles(int tiles, int K, int *tail_from);
 bool gemm3_bf16_native(int layout);  // gemm3.hip: K-split factor of the ragged last round of tiles (1: none)
 int gemm2_tile_n(int M, int N, int split_k);
 size_t gemm2_slab_bytes(int M, int N, int S);

@@ -36,6 +36,7 @@ class SiblingGroup:
         self._parked: dict = {}
         self._misses = 0     # consecutive grouped launches whose parked outputs nobody collected (see forward_for)
         self._refused_from = GROUP_MAX_M + 1  # smallest row count the grouped entry point refused for this group (see forward_for)
+        self._prefill_refused_upto = GROUP_MAX_M  # largest prefill-sized row count (> GROUP_MAX_M) the grouped entry point refused
         self.grouped_launches = 0  # diagnostics / tests
 
     def describe(self, m: int = 1) -> str:
@@ -75,7 +76,13 @@ class SiblingGroup:
             return None
         x2d = x.reshape(-1, x.shape[-1])
         m = x2d.shape[0]
-        if m > GROUP_MAX_M or m >= self._refused_from or m == 0 or not x2d.is_contiguous() or not self.compatible():
+        # Round 6: prefill-sized calls too -- ONE launch of the 256x128 kernel carries the tiles of all siblings (csrc/gemm3.hip, grouped
+        # form: from 384 rows, at least one tile per CU).  A refusal is remembered as "nothing up to this many rows" (the condition is
+        # monotone in the row count), separately from the decode / mid-batch range.
+        prefill = m > GROUP_MAX_M
+        if prefill and (m <= self._prefill_refused_upto or os.environ.get("QLLM_FUSE_PREFILL", "1") == "0"):
+            return None
+        if (not prefill and m >= self._refused_from) or m == 0 or not x2d.is_contiguous() or not self.compatible():
             return None
         try:
             outs = ops.linear_forward_grouped([l.decode_descriptor(None, add_zero_bias) for l in self.layers], x2d)
@@ -83,6 +90,9 @@ class SiblingGroup:
             # no grouped kernel for this many rows (wide groups above 32 rows: the layers run one by one, panel.hip): do not ask
             # again from here up -- but keep grouping the smaller batches.  (Round 4: this used to switch the group off for good,
             # so one 40-token prefill cost every later decode step its grouped launches.)  Refused at one row: nothing to keep.
+            if prefill:
+                self._prefill_refused_upto = max(self._prefill_refused_upto, m)
+                return None
             self._refused_from = m
             if m == 1:
                 self.enabled = False

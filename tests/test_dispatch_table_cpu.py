@@ -367,3 +367,28 @@ def test_ragged_last_round_of_tiles_is_split_over_k(lib):
     # the workspace a caller is told to bring covers the tail's partial tiles (64 tiles x 4 blocks x 128 KB) + the counters
     arr = (_lib.QllmWeight * 1)(W(5120, 5120))
     assert lib.qllm_workspace_bytes_act(arr, 2048, _lib.DT_F16) >= 16384 + 64 * 4 * 256 * 128 * 4
+
+
+def test_prefill_sized_groups_share_one_launch_of_the_256x128_kernel(lib):
+    """Round 6: q/k/v and gate/up at prefill sizes as ONE grid of the wave-specialised kernel (gemm3.hip, grouped form): the rounds of CUs
+    are counted over the group -- Llama-2-7B's gate/up are 1376 tiles (5.4 rounds, the last one K-split) instead of 2 x 688 (2 x 3)."""
+    from qllm_amd import ops
+    g3 = "gemm3 tile=256x128 matrix-waves=8 staging-waves=4"
+    sm = " layout=strip-major"
+    attn, up = W(4096, 4096, layout=NATIVE), W(4096, 11008, layout=NATIVE)
+    assert plan(lib, [up] * 2, 2048) == g3 + " layers=2 tail_split=2" + sm          # 1376 = 5 x 256 + 96 x 2
+    assert plan(lib, [attn] * 3, 2048) == g3 + " layers=3" + sm                      # 768 tiles: three whole rounds
+    assert plan(lib, [attn, W(4096, 1024, layout=NATIVE), W(4096, 1024, layout=NATIVE)], 2048) == g3 + " layers=3 tail_split=2" + sm  # GQA: 384 tiles
+    assert plan(lib, [W(4096, 4096)] * 3, 2048) == g3 + " layers=3"                   # the reference's row-stream buffers in place too
+    assert plan(lib, [up] * 2, 2048, have_ws=0) == g3 + " layers=2" + sm             # no workspace: no K split, still one launch
+    assert plan(lib, [up] * 2, 384) == g3 + " layers=2 tail_split=2" + sm            # 344 tiles = 256 + 88 x 2
+    for m in (129, 383):
+        assert plan(lib, [up] * 2, m).startswith("unsupported")                       # below 384 rows: layer by layer (gemm2 / panel)
+    assert plan(lib, [W(4096, 1024, layout=NATIVE)] * 2, 512).startswith("unsupported")   # 32 tiles: fewer than CUs -> single launches split K
+    assert plan(lib, [W(4096, 4096, layout=AWQ)] * 3, 2048).startswith("unsupported")     # AWQ words in place: no grouped form
+    assert plan(lib, [W(4096, 4096, 128, 3, NATIVE)] * 3, 2048).startswith("unsupported")
+    try:
+        ops.set_knob("QLLM_GEMM3_GROUP", 0)
+        assert plan(lib, [up] * 2, 2048).startswith("unsupported")
+    finally:
+        ops.reset_knobs()

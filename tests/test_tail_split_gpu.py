@@ -68,3 +68,46 @@ def test_prefill_kernel_dequantises_bit_exactly(layout, g, zk):
         finally:
             os.environ.pop("QLLM_NATIVE_LAYOUT", None)
         assert np.array_equal(got.view(np.uint16), want.view(np.uint16)), (layout, native)
+
+
+@pytest.mark.parametrize("layout,shapes,g,zk,dtype", [
+    ("GEMM", [(4096, 4096), (4096, 1024), (4096, 1024)], 128, "asym", torch.float16),      # GQA q/k/v: 384 tiles, tail split
+    ("HQQ", [(4096, 5632), (4096, 5632)], 64, "f16", torch.float16),                        # gate/up, fp16 zero points
+    ("GPTQ", [(2048, 2048), (2048, 2048), (2048, 2048)], 128, "asym", torch.bfloat16),      # bf16: the native form, grouped
+])
+def test_prefill_sized_sibling_group_is_one_launch_and_matches_single_launches(layout, shapes, g, zk, dtype):
+    """Round 6: a sibling group at M = 2048 -- ONE launch of the 256x128 kernel (gemm3.hip, grouped form) for q/k/v / gate/up.  Tiles
+    of the whole rounds are computed exactly as in the single launches (bit-equal); tiles of a K-split last round differ by the fp32
+    summation order only; every output within 1e-2 of the oracle; bias per layer."""
+    from qllm_amd import ops
+    from qllm_amd.modeling.q_layers import fuse_siblings
+    M = 2048
+    ds = [synth(layout, 4, g, K, N, zk, False, i == 1, seed=31 * i + N) for i, (K, N) in enumerate(shapes)]
+    singles = [to_layer(d, DEV) for d in ds]
+    grouped = [to_layer(d, DEV) for d in ds]
+    grp = fuse_siblings(grouped)
+    x = torch.from_numpy(randx(M, shapes[0][0], seed=11)).to(DEV).to(dtype)
+    assert f"layers={len(shapes)}" in grp.describe(M) and grp.describe(M).startswith("gemm3")
+    before = grp.grouped_launches
+    outs = [l(x) for l in grouped]
+    assert grp.grouped_launches == before + 1
+    tol = 1e-2 if dtype == torch.bfloat16 else 1e-3
+    for o, s_, d in zip(outs, singles, ds):
+        y1 = s_(x)
+        assert o.shape == (M, d["N"]) and o.dtype == dtype and o.is_contiguous()
+        assert O.rel_err(o.float().cpu().numpy(), y1.float().cpu().numpy()) <= tol
+        want = Ref(d).y16(x.to(torch.float16).cpu().numpy())
+        assert O.rel_err(o.float().cpu().numpy(), want) <= TOL
+    if "tail_split" not in grp.describe(M) and not any("tail_split" in ops.plan_describe([s_.decode_descriptor()], M) for s_ in singles):
+        assert all(torch.equal(o, s_(x)) for o, s_ in zip(outs, singles))      # whole rounds only, here and there: the very same tiles
+    # a second call with a new tensor, and determinism
+    x2 = x.clone()
+    assert all(torch.equal(a, b) for a, b in zip([l(x2) for l in grouped], outs))
+    # below 384 rows the group is not served in one launch: every layer runs its own, results unchanged, and the refusal does not
+    # switch the decode-sized grouping off
+    xs = x[:200].contiguous()
+    y_small = grouped[0](xs)
+    assert O.rel_err(y_small.float().cpu().numpy(), singles[0](xs).float().cpu().numpy()) <= tol
+    launches = grp.grouped_launches
+    grouped[0](x[:1].contiguous())
+    assert grp.grouped_launches == launches + 1

@@ -3,5 +3,5 @@
 # the prefill legs: fp16 / act-order / bf16 native / bf16 through the conversion pre-pass, three rounds
 R=$GRAFT_REPO_ROOT
 cd $R; mkdir -p gpurun_out; export TMPDIR=/tmp
-timeout 1500 python -m pytest tests/test_tail_split_gpu.py tests/test_gpu_parity.py -m gpu -q -x --timeout 900 -k "prefill or tail" > gpurun_out/r06n_pytest.log 2>&1; echo "pytest rc=$?"; tail -8 gpurun_out/r06n_pytest.log
-for i in 1 2 3; do timeout 300 python tools/prefill_legs.py 20 2>&1 | grep -v amdgpu.ids; done | tee gpurun_out/r06n_prefill_legs.log
+timeout 1500 python -m pytest tests/test_tail_split_gpu.py tests/test_decode_step_gpu.py tests/test_mixed_bits_gpu.py tests/test_eval_gpu.py -m gpu -q -x --timeout 900 > gpurun_out/r06o_pytest.log 2>&1; echo "pytest rc=$?"; tail -8 gpurun_out/r06o_pytest.log
+for i in 1 2 3; do timeout 300 python tools/prefill_legs.py 20 2>&1 | grep -v amdgpu.ids; done | tee gpurun_out/r06o_prefill_legs.log
