@@ -667,12 +667,13 @@ def main():
                                              "frac_of_mfma_peak": round(tf / MFMA_PEAK_TFLOPS, 4)}
             del ps
         # the other half of BASELINE's metric at top level: the prefill kernel against the dense MFMA peak (fp16 AWQ leg through the
-        # modules = 7 launches of qllm::gemm3_kernel per layer), with the matrix pipe's occupancy from a live counter pass
+        # modules = 4 launches of qllm::gemm3_kernel per layer since round 6: q/k/v and gate/up are one grouped grid each), with the matrix
+        # pipe's occupancy from a live counter pass
         busy, busy_src = (None, "skipped (--no-pmc)") if args.no_pmc else pmc_prefill_mfma_busy()
         pf = extra["prefill_m2048_awq"]
         result["roofline_prefill"] = {
             "bound": "mfma", "kernel": "qllm::gemm3_kernel (256x128x64 tiles, 8 matrix + 4 dequant waves; csrc/gemm3.hip)",
-            "workload": "llama2-7b-awq-w4-g128-prefill-m2048 (7 linears x 4 layers through the q_layer modules, hipGraph replay)",
+            "workload": "llama2-7b-awq-w4-g128-prefill-m2048 (7 linears x 4 layers through the q_layer modules: 4 launches per layer, q/k/v and gate/up grouped; hipGraph replay)",
             "achieved": pf["TFLOPs"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": pf["frac_of_mfma_peak"],
             "gptq_actorder_frac": extra["prefill_m2048_gptq_actorder"]["frac_of_mfma_peak"],
             "awq_bf16_frac": extra["prefill_m2048_awq_bf16"]["frac_of_mfma_peak"],
