@@ -47,7 +47,14 @@ class SiblingGroup:
         for l in self.layers:
             if type(l) is not type(a) or l.infeatures != a.infeatures or l.bits != a.bits or l.groupsize != a.groupsize:
                 return False
-            if getattr(l, "act_order", None):  # every sibling would need its own permutation of x
+        # act-order (GPTQ): the siblings' native copies hold their rows sorted by group and are fed x[:, perm] -- q/k/v (gate/up) of a real
+        # checkpoint carry the SAME permutation (it comes from the shared input's Hessian, qllm/quantization/gptq/gptq.py:168; equal
+        # permutations are interned to one tensor), so the group is served with the one gathered x its callers share.  Different
+        # permutations, or a layer without a row-sorted native copy: every layer on its own.
+        ao = [bool(getattr(l, "act_order", None)) for l in self.layers]
+        if any(ao):
+            perm = getattr(a, "_perm", None)
+            if not all(ao) or perm is None or any(getattr(l, "_perm", None) is not perm for l in self.layers):
                 return False
         return True
 
@@ -76,6 +83,9 @@ class SiblingGroup:
             return None
         x2d = x.reshape(-1, x.shape[-1])
         m = x2d.shape[0]
+        for l in self.layers:   # (act-order siblings: their row-sorted native copies, and with them the permutations, are built lazily)
+            if getattr(l, "act_order", None) and getattr(l, "_perm", None) is None:
+                l.native_descriptor(add_zero_bias)
         # Round 6: prefill-sized calls too -- ONE launch of the 256x128 kernel carries the tiles of all siblings (csrc/gemm3.hip, grouped
         # form: from 384 rows, at least one tile per CU).  A refusal is remembered as "nothing up to this many rows" (the condition is
         # monotone in the row count), separately from the decode / mid-batch range.
@@ -85,7 +95,16 @@ class SiblingGroup:
         if (not prefill and m >= self._refused_from) or m == 0 or not x2d.is_contiguous() or not self.compatible():
             return None
         try:
-            outs = ops.linear_forward_grouped([l.decode_descriptor(None, add_zero_bias) for l in self.layers], x2d)
+            descs = []
+            for l in self.layers:
+                if getattr(l, "act_order", None):   # only the row-sorted native copy matches the gathered x this call was given
+                    d = l.native_descriptor(add_zero_bias)
+                    if d is None:
+                        return None
+                else:
+                    d = l.decode_descriptor(None, add_zero_bias)
+                descs.append(d)
+            outs = ops.linear_forward_grouped(descs, x2d)
         except ops.QllmUnsupported:
             # no grouped kernel for this many rows (wide groups above 32 rows: the layers run one by one, panel.hip): do not ask
             # again from here up -- but keep grouping the smaller batches.  (Round 4: this used to switch the group off for good,

@@ -152,6 +152,12 @@ class QuantLinearGPTQ(nn.Module, CompressWeight, HipForwardMixin):
                 from ... import ops
                 x2d = _gathered(x, self._perm)
                 try:
+                    if self._siblings is not None:
+                        # round 6: act-order siblings share their permutation, hence the gathered x: ONE grouped launch for them too
+                        # (the group is keyed on the gathered tensor, the same object for every sibling: _gathered above)
+                        y = self._siblings.forward_for(self, x2d, azb)
+                        if y is not None:
+                            return y.reshape(x.shape[:-1] + (self.outfeatures,))
                     return ops.linear_forward_shared(w, x2d).reshape(x.shape[:-1] + (self.outfeatures,))
                 except ops.QllmUnsupported:
                     self._needs_reference = True   # a shape the native kernels do not serve: the in-place gather kernel below

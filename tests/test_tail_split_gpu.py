@@ -111,3 +111,43 @@ def test_prefill_sized_sibling_group_is_one_launch_and_matches_single_launches(l
     launches = grp.grouped_launches
     grouped[0](x[:1].contiguous())
     assert grp.grouped_launches == launches + 1
+
+
+def test_act_order_siblings_run_as_one_group():
+    """Round 6: q/k/v of a GPTQ act-order checkpoint share their permutation (gptq.py:168: it comes from the shared input's Hessian), so
+    their row-sorted native copies take the SAME gathered x: one gather + ONE grouped launch at decode, mid-batch and prefill sizes --
+    results equal to the layers on their own, and the oracle's with the reference's in-place g_idx gather."""
+    from qllm_amd import ops
+    from qllm_amd.modeling.q_layers import fuse_siblings
+    from gpu_util import oracle_y
+    K, g = 4096, 128
+    base = synth("GPTQ", 4, g, K, 4096, "asym", True, False, seed=41)
+    ds = [base] + [dict(synth("GPTQ", 4, g, K, n, "asym", False, i == 0, seed=42 + i), g_idx=base["g_idx"].copy()) for i, n in enumerate((1024, 1024))]
+    singles = [to_layer(d, DEV) for d in ds]
+    grouped = [to_layer(d, DEV) for d in ds]
+    grp = fuse_siblings(grouped)
+    calls, real = [], ops.gather_columns
+    ops.gather_columns = lambda x, perm: (calls.append(1), real(x, perm))[1]
+    try:
+        for m in (1, 16, 64, 2048):
+            x = torch.from_numpy(randx(m, K, seed=m)).to(DEV)
+            [l(x) for l in grouped]                          # (first pass builds the row-sorted copies and interns the permutation)
+            x = x.clone()
+            calls.clear()
+            before = grp.grouped_launches
+            ys = [l(x) for l in grouped]
+            assert len(calls) == 1 and grp.grouped_launches == before + 1, (m, calls, grp.grouped_launches - before)
+            for d, y, s_ in zip(ds, ys, singles):
+                assert O.rel_err(y.cpu().numpy(), oracle_y(d, x.cpu().numpy())) <= TOL, m
+                assert O.rel_err(y.cpu().numpy(), s_(x).cpu().numpy()) <= 1e-3, m
+    finally:
+        ops.gather_columns = real
+    # a sibling with ANOTHER permutation: the group stands down, every layer on its own (still right)
+    other = to_layer(synth("GPTQ", 4, g, K, 1024, "asym", True, False, seed=77), DEV)
+    mixed = [to_layer(ds[0], DEV), other]
+    g2 = fuse_siblings(mixed)
+    x = torch.from_numpy(randx(4, K, seed=5)).to(DEV)
+    for _ in range(2):
+        ys = [l(x) for l in mixed]
+    assert g2.grouped_launches == 0
+    assert O.rel_err(ys[0].cpu().numpy(), oracle_y(ds[0], x.cpu().numpy())) <= TOL
