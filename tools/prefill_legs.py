@@ -13,8 +13,11 @@ from qllm_amd.modeling.q_layers import QuantLinearGPTQ, WQLinear_GEMM  # noqa: E
 
 dev = torch.device("cuda:0")
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+only = sys.argv[2].split(",") if len(sys.argv) > 2 else None   # e.g. "awq": one leg (the rocprofv3 per-launch table of the module step)
 for tag, cls, act, xdt in (("awq", WQLinear_GEMM, False, torch.float16), ("gptq_actorder", QuantLinearGPTQ, True, torch.float16),
                            ("awq_bf16", WQLinear_GEMM, False, torch.bfloat16), ("awq_bf16_shim", WQLinear_GEMM, False, torch.bfloat16)):
+    if only and tag not in only:
+        continue
     from qllm_amd import ops
     ps = bench.Stack(cls, 4, dev, seed=99, act_order=act)
     xp = torch.randn(2048, bench.HIDDEN, device=dev, dtype=xdt)

@@ -18,6 +18,8 @@ timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $P/hqq_trace
 timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $P/hqq_fetch -o f -- python $R/tools/hqq_leg.py 3 8 > /dev/null 2> $P/rocprof_hqq_fetch.err
 timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $P/hqq_write -o w -- python $R/tools/hqq_leg.py 3 8 > /dev/null 2> $P/rocprof_hqq_write.err
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $P/prefill -o p -- python $R/tools/kbench.py --m 2048 --iters 40 --layouts GPTQ GEMM > $P/prefill_kbench.log 2> $P/rocprof_prefill.err
+# (round 6) the prefill step as the modules run it: 4 launches per decoder layer (q/k/v and gate/up grouped), AWQ fp16 leg only
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $P/prefill_step -o s -- python $R/tools/prefill_legs.py 10 awq > $P/prefill_step.log 2> $P/rocprof_prefill_step.err
 cd $R
 bash tools/pmc_pass.sh ${tag}_sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -- python tools/one_shape.py > /dev/null
 timeout 100 python tools/one_shape.py --ref --iters 40 > gpurun_out/${tag}_hipblaslt_ref.log 2>&1; tail -2 gpurun_out/${tag}_hipblaslt_ref.log

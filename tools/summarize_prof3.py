@@ -217,6 +217,32 @@ if pf:
             v.sort()
             P.append(f"| `{k[0]}` | {k[1]} | {k[2]} | {len(v)} | {v[0] / 1e3:.1f} | {v[len(v) // 2] / 1e3:.1f} |")
         P.append("")
+    # (round 6) the module step, per launch: dispatches of gemm3 in issue order cycle through q/k/v (grouped), o, gate/up (grouped), down
+    ps = glob.glob(f"{src}/prefill_step/*kernel_trace.csv")
+    if ps:
+        M = 2048
+        roles = [("q/k/v (one grouped launch)", 3 * 2.0 * M * H * H), ("o_proj", 2.0 * M * H * H), ("gate/up (one grouped launch)", 2 * 2.0 * M * H * I),
+                 ("down_proj", 2.0 * M * I * H)]
+        tr3 = [r for r in csv.DictReader(open(ps[0])) if "qllm::gemm3_kernel" in r["Kernel_Name"]]
+        tr3.sort(key=lambda r: int(r["Start_Timestamp"]))
+        if len(tr3) % 4 == 0 and tr3:
+            per3 = collections.defaultdict(list)
+            g3 = {}
+            for i, r in enumerate(tr3):
+                per3[i % 4].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+                g3[i % 4] = int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"])
+            P += ["The prefill step as the modules run it (`rocprofv3 --kernel-trace --stats -- python tools/prefill_legs.py 10 awq`: 4 decoder layers,",
+                  "M = 2048, AWQ w4 g128 native layout, fp16; 4 launches of `gemm3_kernel` per layer since round 6), per launch:", "",
+                  "| launch | blocks | dispatches | min us | median us | TFLOP/s (median) | of 2.5 PF |", "|---|---|---|---|---|---|---|"]
+            tot = 0.0
+            for role in range(4):
+                v = sorted(per3[role])
+                med = v[len(v) // 2] / 1e3
+                tot += med
+                P.append(f"| {roles[role][0]} | {g3[role]} | {len(v)} | {v[0] / 1e3:.1f} | {med:.1f} | {roles[role][1] / med / 1e6:.0f} | {roles[role][1] / med / 1e6 / 2500:.3f} |")
+            fl = sum(r[1] for r in roles)
+            P += ["", f"Sum of the four medians: {tot:.1f} us per decoder layer = {fl / tot / 1e6:.0f} TFLOP/s = {fl / tot / 1e6 / 2500:.3f} of 2.5 PF (un-profiled line of the same script: "
+                  + "; ".join(l.strip() for l in open(f"{src}/prefill_step.log") if l.startswith("awq")) + ").", ""]
     for nm in ("sq1",):
         fn = f"gpurun_out/pmc_{tag}_{nm}.txt"
         if os.path.exists(fn):
