@@ -102,7 +102,7 @@ def test_wave_specialised_prefill_kernel_budget():
     """gemm3: 4 matrix + 4 dequant waves = 2 waves per SIMD (<= 256 registers); 8 + 4 waves = 3 per SIMD (<= 168)."""
     res = _resources("gemm3.hip")
     names = [n for n in res if "gemm3_kernel" in n]
-    assert len(names) == 7  # {GPTQ, AWQ} x {4 matrix waves, 4 without the priority bump, 8 matrix waves} + 3-bit rows x 8
+    assert len(names) == 8  # {GPTQ, AWQ} x {4 matrix waves, 4 without the priority bump, 8 matrix waves} + 3-bit rows x 8 + native bf16 (round 6)
     for n in names:
         vgpr, spill = res[n]
         cap = 256 if "ELi4ELb" in n else 168

@@ -47,7 +47,24 @@ def test_a_refusal_is_remembered_per_row_count_and_keeps_the_group(monkeypatch):
     assert g.forward_for(layers[0], x64).shape == (64, 8) and calls[-1] == 64           # below the refusals: grouped as before
     x1b = torch.zeros(1, 64)
     assert g.forward_for(layers[0], x1b) is not None and g.grouped_launches == 3
-    assert g.forward_for(layers[0], torch.zeros(fused.GROUP_MAX_M + 1, 64)) is None and calls[-1] == 1   # above the limit: never asked
+    # prefill-sized calls (round 6: one grouped grid of the 256x128 kernel): asked; a refusal is remembered as "nothing up to this many
+    # rows" without touching the decode-sized grouping; QLLM_FUSE_PREFILL=0 never asks
+    big = fused.GROUP_MAX_M + 1
+    assert g.forward_for(layers[0], torch.zeros(big + 100, 64)) is None and calls[-1] == big + 100
+    n = len(calls)
+    assert g.forward_for(layers[0], torch.zeros(big, 64)) is None and len(calls) == n            # fewer rows than a refused count: not asked
+    assert g.forward_for(layers[0], torch.zeros(big + 200, 64)) is None and calls[-1] == big + 200   # more rows: asked again
+    assert g.forward_for(layers[0], torch.zeros(1, 64)) is not None                               # decode-sized grouping untouched
+    monkeypatch.setenv("QLLM_FUSE_PREFILL", "0")
+    n = len(calls)
+    assert g.forward_for(layers[0], torch.zeros(4096, 64)) is None and len(calls) == n
+
+
+def test_prefill_sized_calls_are_grouped_when_the_library_serves_them(monkeypatch):
+    g, layers, calls = _group(monkeypatch, refuse_from=10 ** 9)
+    x = torch.zeros(2048, 64)
+    assert g.forward_for(layers[0], x).shape == (2048, 8) and calls == [2048]
+    assert g.forward_for(layers[1], x).shape == (2048, 4) and g.forward_for(layers[2], x).shape == (2048, 4) and calls == [2048]
 
 
 def test_a_refusal_at_one_row_switches_the_group_off(monkeypatch):
