@@ -71,10 +71,9 @@ def main():
                 try:
                     step()   # (builds the native copies / decides the plan)
                     descs = [m.decode_descriptor() for m in mods0]
-                    grouped = len(descs) > 1 and mods0[0]._siblings is not None and M <= 128
-                    plan = ops.plan_describe(descs if grouped else descs[:1], M)
-                    if len(descs) > 1 and not grouped:
-                        plan = f"{len(descs)} launches: " + plan
+                    plan = ops.plan_describe(descs, M) if len(descs) > 1 and mods0[0]._siblings is not None else "unsupported"
+                    if plan.startswith("unsupported"):   # no grouped launch for this many rows: the layers run one by one
+                        plan = (f"{len(descs)} launches: " if len(descs) > 1 else "") + ops.plan_describe(descs[:1], M)
                     gph, _ = bench.capture(step)
                     ms = bench.time_events(gph.replay, a.replays, warm=5) / ncopy
                     del gph
