@@ -21,6 +21,12 @@ bool strip1_shape(int K, int blocks, int cus, int *nw, int *maxs) {
   else if (T <= 256) { if (knob("QLLM_S1_T256_NW16", 0)) { w = 16; m = 16; } else { w = 8; m = 32; } }
   else if (T <= 384) { w = 16; m = 24; }
   else if (T <= 512) { w = 16; m = 32; }
+  // round 6 (profiles/r06_shape_table.md: Qwen2-7B's down_proj, K = 18944, sat on the general strip kernel at 0.33 of 8 TB/s): rounds of
+  // 40 .. 64 k-steps, three / four accumulator sets -- K up to 32768 (Llama-2-70B's unsharded down_proj is K = 28672)
+  else if (T <= 640) { w = 16; m = 40; }
+  else if (T <= 768) { w = 16; m = 48; }
+  else if (T <= 896) { w = 16; m = 56; }
+  else if (T <= 1024) { w = 16; m = 64; }
   else return false;
   // No dead waves where an odd wave count is built: K = 11008 is 344 k-steps = 14 1/3 rounds of 24 -- the sixteenth wave of a 16 x 24
   // block owns nothing (it re-reads its neighbour's words and multiplies zeros); K = 3584 (a Llama-2-70B TP = 8 down_proj shard) is
@@ -35,7 +41,11 @@ bool strip1_shape(int K, int blocks, int cus, int *nw, int *maxs) {
 template <int NW, int MAXS, bool EXACT, bool DBG>
 static int launch_t(const Strip1Params &p, dim3 grid, hipStream_t stream) {
   constexpr int lds_bytes = strip1_lds_bytes<NW, MAXS>();
-  static_assert(lds_bytes <= 64 * 1024, "no dynamic-LDS opt-in needed");
+  static_assert(lds_bytes <= 160 * 1024, "LDS of one CU");
+  if constexpr (lds_bytes > 64 * 1024) {  // (rounds of 56 / 64 k-steps x 16 waves: 4 KB of staged activations per wave)
+    static DeviceLatch attr_done;
+    if (int rc = lds_optin(attr_done, (const void *)strip1_kernel<NW, MAXS, EXACT, 2, 4, DBG>)) return rc;
+  }
   hipLaunchKernelGGL((strip1_kernel<NW, MAXS, EXACT, 2, 4, DBG>), grid, dim3(NW * 64), lds_bytes, stream, p);
   QLLM_HIP_CHECK(hipGetLastError());
   return QLLM_OK;
@@ -88,6 +98,10 @@ int launch_strip1(const Strip1Params &p, int nw, int maxs, int n_prob, int max_s
   if (nw == 16 && maxs == 24) return launch_e<16, 24>(p, grid, stream);
   if (nw == 15 && maxs == 24) return launch_e<15, 24>(p, grid, stream);
   if (nw == 16 && maxs == 32) return launch_e<16, 32>(p, grid, stream);
+  if (nw == 16 && maxs == 40) return launch_e<16, 40>(p, grid, stream);
+  if (nw == 16 && maxs == 48) return launch_e<16, 48>(p, grid, stream);
+  if (nw == 16 && maxs == 56) return launch_e<16, 56>(p, grid, stream);
+  if (nw == 16 && maxs == 64) return launch_e<16, 64>(p, grid, stream);
   return set_error(QLLM_ERR_UNSUPPORTED, "internal: no batch-1 instantiation for nw=%d round=%d", nw, maxs);
 }
 

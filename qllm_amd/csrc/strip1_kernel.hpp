@@ -62,9 +62,9 @@ constexpr int strip1_lds_bytes() {
 template <int NW, int MAXS, bool EXACT, int NCH = 2, int LVL = 4, bool DBG = false, bool AR = false>
 // (second launch bound = minimum waves per SIMD: 64 registers up to rounds of 24 k-steps -- a CU full of waves -- 128 above)
 __global__ __launch_bounds__(NW * 64, (MAXS <= 24) ? 8 : 4) void strip1_kernel(const Strip1Params p) {
-  static_assert(MAXS % 4 == 0 && MAXS >= 8 && MAXS <= 32, "rounds are whole 128-wide groups, at most 8 of them");
+  static_assert(MAXS % 4 == 0 && MAXS >= 8 && MAXS <= 64, "rounds are whole 128-wide groups, at most 16 of them (round 6: 40 .. 64 k-steps for K up to 32768)");
   constexpr int NG = MAXS / 4;            // groups per wave
-  constexpr int NPASS = (NG + 3) / 4;     // accumulator sets: groups 0-3, groups 4-7
+  constexpr int NPASS = (NG + 3) / 4;     // accumulator sets: groups 0-3, groups 4-7, groups 8-11, groups 12-15
   constexpr int XL = (MAXS * 4 + 63) / 64;  // 16-byte activation chunks per lane
   constexpr int RS = strip1_rs(NW);       // floats per column of the reduction buffer (16-byte aligned rows, 2-way banks at most)
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -239,7 +239,8 @@ __global__ __launch_bounds__(NW * 64, (MAXS <= 24) ? 8 : 4) void strip1_kernel(c
       else term[ps] = a;
     }
     val = term[0];
-    if constexpr (NPASS > 1) val += term[1];
+#pragma unroll
+    for (int ps = 1; ps < NPASS; ++ps) val += term[ps];
     if constexpr (LVL < 4) val = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, val) ^ fold);
   } else {
     val = __builtin_bit_cast(float, fold);

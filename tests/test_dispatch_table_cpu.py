@@ -143,7 +143,11 @@ def test_native_layout_decode_routes(lib):
     # ... other group sizes, 3 bits and K beyond 512 k-steps stay on the general strip kernel
     assert plan(lib, [W(4096, 4096, 64, layout=NATIVE)], 1) == "strip nw=8 cpl=1 spw=16 form=lds-slab row_tiles=1" + sm
     assert plan(lib, [W(4096, 4096, 128, 3, NATIVE)], 1).startswith("strip nw=16")
-    assert plan(lib, [W(28672, 8192, layout=NATIVE)], 1).startswith("strip nw=16")
+    assert plan(lib, [W(28672, 8192, layout=NATIVE)], 1) == "strip1 nw=16 round=56 exact grid=strips x 1" + sm     # (round 6; the general kernel until then)
+    assert plan(lib, [W(36864, 8192, layout=NATIVE)], 1).startswith("strip nw=16")                                # K > 32768: the general strip kernel
+    assert plan(lib, [W(18944, 3584, layout=NATIVE)], 1) == "strip1 nw=16 round=40 grid=strips x 1" + sm       # round 6: K up to 24576 (Qwen2-7B down_proj)
+    assert plan(lib, [W(24576, 4096, layout=NATIVE)], 1) == "strip1 nw=16 round=48 exact grid=strips x 1" + sm
+    assert plan(lib, [W(32768, 4096, layout=NATIVE)], 1) == "strip1 nw=16 round=64 exact grid=strips x 1" + sm
     # M = 2..32: strip_dma.hpp (activations through LDS by DMA); one strip per 16-wave block while the strips fit one round of CUs
     for m in (2, 4, 5, 16):
         assert plan(lib, [attn], m) == "strip nw=16 cpl=1 spw=8 form=dma-A row_tiles=1" + sm
@@ -209,7 +213,8 @@ def test_native_layout_decode_routes(lib):
     assert plan(lib, [W(8192, 1024, layout=NATIVE)], 1).startswith("strip1 nw=8 round=32 exact")
     assert plan(lib, [W(1024, 8192, 64, layout=NATIVE)], 1).startswith("strip nw=4 cpl=1 spw=8 form=lds-slab")   # (64-wide groups: the general kernel)
     assert plan(lib, [W(8192, 1024, layout=NATIVE)], 3).startswith("strip nw=16 cpl=1 spw=16 form=dma-A")
-    assert plan(lib, [W(28672, 1024, layout=NATIVE)], 1).startswith("strip nw=16 cpl=1 spw=56 form=lds-slab")  # three rounds of 24
+    assert plan(lib, [W(28672, 1024, layout=NATIVE)], 1).startswith("strip1 nw=16 round=56 exact")                # (round 6: one round of 56)
+    assert plan(lib, [W(36864, 1024, layout=NATIVE)], 1).startswith("strip nw=16 cpl=1 spw=72 form=lds-slab")     # beyond 32768: three rounds of 24
     # g64 / 3 bits / fp16 zero points: slab form for short chunks at batch 1, register-A beyond (no spilling instantiation is built)
     h4, h3 = W(4096, 4096, 64, 4, NATIVE_F16Z), W(4096, 4096, 64, 3, NATIVE_F16Z)
     assert plan(lib, [h4], 1).startswith("strip nw=8 cpl=1 spw=16 form=lds-slab")

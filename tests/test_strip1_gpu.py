@@ -16,7 +16,10 @@ FORMS = [(256, "nw=4 round=8 grid"), (1024, "nw=4 round=8 exact"), (1152, "nw=4 
          (3584, "nw=7 round=16 exact"), (3840, "nw=8 round=16 grid"), (4096, "nw=8 round=16 exact"), (5120, "nw=8 round=24 grid"), (6144, "nw=8 round=24 exact"),
          (8192, "nw=8 round=32 exact"), (6656, "nw=8 round=32 grid"), (11008, "nw=15 round=24 grid"), (11776, "nw=16 round=24 grid"),
          (12288, "nw=16 round=24 exact"),
-         (14336, "nw=16 round=32 grid"), (16384, "nw=16 round=32 exact")]
+         (14336, "nw=16 round=32 grid"), (16384, "nw=16 round=32 exact"),
+         # round 6: rounds of 40 .. 64 k-steps, three / four accumulator sets (Qwen2-7B's down_proj is K = 18944, Llama-2-70B's 28672)
+         (18944, "nw=16 round=40 grid"), (20480, "nw=16 round=40 exact"), (22016, "nw=16 round=48 grid"), (24576, "nw=16 round=48 exact"),
+         (26624, "nw=16 round=56 grid"), (28672, "nw=16 round=56 exact"), (32768, "nw=16 round=64 exact")]
 
 
 def _native(layer, d, zk, compat=0):
