@@ -282,7 +282,14 @@ def hqq_leg(dev, n_layers=LAYERS):
             ms = time_events(gh.replay, 20) / n_layers
             del gh
             res["grouped" if fz else "ungrouped"] = ms
+        # (round 6) the same stack at batch 1: 64-wide groups ride the batch-1 kernel since round 6 (4 bits; 3-bit layers: the general strips)
+        hs.set_fused(True)
+        x1 = torch.randn(1, HIDDEN, device=dev, dtype=torch.float16)
+        g1, _ = capture(lambda: hs(x1))
+        res["batch1"] = time_events(g1.replay, 20) / n_layers
+        del g1
         extra[tag] = {"ms_per_layer": round(res["grouped"], 4), "GBps": round(nbytes / res["grouped"] / 1e6, 1),
+                      "ms_per_layer_batch1": round(res["batch1"], 4),
                       "frac_of_hbm_peak": round(nbytes / res["grouped"] / 1e6 / HBM_PEAK_GBPS, 4), "layers": n_layers,
                       "sibling_groups": hs.groups, "ms_per_layer_7_launches": round(res["ungrouped"], 4)}
         del hs

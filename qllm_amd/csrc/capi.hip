@@ -37,7 +37,7 @@ struct Settable {
   int value, set;
 };
 static Settable kSettable[] = {
-    {"QLLM_STRIP1", 0, 1, 0, 0},               // 0: batch-1 calls on the general strip kernel (the round-4 path)
+    {"QLLM_STRIP1", 0, 2, 0, 0},               // 0: batch-1 calls on the general strip kernel (the round-4 path); 2: only 128-wide groups on the batch-1 kernel
     {"QLLM_PANEL", 0, 1, 0, 0},                // 0: no panel kernel (strips to 32 rows, the 256-row tiles above)
     {"QLLM_PANEL_MIN_M", 17, 129, 0, 0},       // single layers: rows from which the panel kernel serves (no form below 17 rows)
     {"QLLM_PANEL_GROUP_MIN_M", 17, 129, 0, 0}, // sibling groups: rows from which ONE panel launch serves the group
@@ -315,7 +315,9 @@ static bool strip_plan(const qllm_weight_t *w, int n, int M, StripPlan *plan) {
         plan->sm = 1;
         // batch 1, 4 bits, 128-wide groups: the specialised kernel (round 5; profiles/r05_decode_bisect.md)
         int nw1 = 0, maxs1 = 0;
-        if (M == 1 && bits == 4 && w[0].group_size == 128 && knob("QLLM_STRIP1", 1) && strip1_shape(w[0].K, strips, compute_units(), &nw1, &maxs1)) {
+        // (round 6: 64-wide groups too -- HQQ's default; QLLM_STRIP1 = 2 keeps them on the general kernel)
+        const int s1 = knob("QLLM_STRIP1", 1);
+        if (M == 1 && bits == 4 && (w[0].group_size == 128 || (w[0].group_size == 64 && s1 != 2 && w[0].K <= 24576)) && s1 && strip1_shape(w[0].K, strips, compute_units(), &nw1, &maxs1)) {
           plan->one_nw = nw1;
           plan->one_maxs = maxs1;
         }
@@ -371,7 +373,8 @@ static int run_strip1(const StripPlan &pl, const qllm_weight_t *w, void *const *
   memset(&p, 0, sizeof(p));
   p.x = x;
   p.T = w[0].K / 32;
-  p.n_groups = w[0].K / 128;
+  p.n_groups = w[0].K / w[0].group_size;
+  p.group64 = w[0].group_size == 64;
   p.add_zero_bias = w[0].add_zero_bias;
   p.act_bf16 = (act_dtype == QLLM_BF16);
   p.dbg = (g_timeline && g_timeline_next < g_timeline_slots) ? g_timeline + 24 * (g_timeline_next++) : nullptr;
@@ -897,8 +900,8 @@ static void describe(const Decision &d, const qllm_weight_t *w, int n, int M, si
     case ROUTE_STRIP: {
       const StripPlan &pl = d.strip;
       if (pl.one_nw)
-        snprintf(buf, buflen, "strip1 nw=%d round=%d%s grid=strips x %d layout=strip-major", pl.one_nw, pl.one_maxs,
-                 pl.one_nw * pl.one_maxs == w[0].K / 32 ? " exact" : "", n);
+        snprintf(buf, buflen, "strip1 nw=%d round=%d%s%s grid=strips x %d layout=strip-major", pl.one_nw, pl.one_maxs,
+                 pl.one_nw * pl.one_maxs == w[0].K / 32 ? " exact" : "", w[0].group_size == 64 ? " g64" : "", n);
       else
         snprintf(buf, buflen, "strip nw=%d cpl=%d spw=%d form=%s row_tiles=%d%s", pl.nw, pl.cpl, pl.spw,
                  pl.ra == 2 ? "dma-A" : (pl.ra ? "register-A" : "lds-slab"), M > 32 ? 4 : (M > 16 ? 2 : 1), pl.sm ? " layout=strip-major" : "");
@@ -1138,7 +1141,7 @@ int qllm_linear_forward_allreduce(const qllm_weight_t *w, const void *x, void *y
   if (world < 1 || world > kCommMaxWorld || rank < 0 || rank >= world) return set_error(QLLM_ERR_INVALID, "world must be 1..%d and 0 <= rank < world (rank=%d world=%d)", kCommMaxWorld, rank, world);
   StripPlan pl;
   // the batch-1 kernel's shapes only (callers run the layer and qllm_allreduce_oneshot / RCCL separately for everything else)
-  if (M != 1 || !is_native(*w) || !strip_plan(w, 1, 1, &pl) || !pl.one_nw)
+  if (M != 1 || !is_native(*w) || w->group_size != 128 || !strip_plan(w, 1, 1, &pl) || !pl.one_nw)
     return set_error(QLLM_ERR_UNSUPPORTED, "fused all-reduce: batch-1 calls on native 4-bit layers with 128-wide groups (M=%d bits=%d g=%d layout=%d)", M, w->bits, w->group_size, w->layout);
   if ((size_t)w->N * 2 > slot_bytes || slot_bytes % 16 != 0 || (uintptr_t)y % 16 != 0)
     return set_error(QLLM_ERR_UNSUPPORTED, "fused all-reduce: N * 2 <= slot_bytes, slot_bytes %% 16 == 0, y 16-byte aligned (N=%d slot=%zu)", w->N, slot_bytes);

@@ -59,12 +59,20 @@ constexpr int strip1_lds_bytes() {
 //     the activation type like the unfused path's y, into slot [parity][rank] of EVERY peer's staging buffer (comm.hip's layout and
 //     protocol) and takes a ticket; the rank's last block publishes the world's flags, waits for the peers' and writes the sum of the
 //     slots in rank order -- the o_proj / down_proj launch and its all-reduce are ONE launch (160 kernel boundaries per Llama-2-70B token).
-template <int NW, int MAXS, bool EXACT, int NCH = 2, int LVL = 4, bool DBG = false, bool AR = false>
+// G64 (round 6): 64-wide groups (HQQ's default; the batch-1 kernel took 128-wide groups only and a g64 layer fell back to the general strip
+//     kernel: 35.5 us per Llama-2-7B decoder layer against 26.3).  A group is then TWO k-steps, a pass of 16 k-steps holds EIGHT groups:
+//     A rows 2 j, 2 j + 1 carry x on the k-steps of group j, so lane (g, i) finds group 2 g of the pass in accumulator registers 0 / 1
+//     and group 2 g + 1 in registers 2 / 3 -- two scales, two zero points, two corrections per lane and pass; the staging pass sums x
+//     over the 8 lanes of a group and fetches the neighbouring group's sums with one more DPP move.
+template <int NW, int MAXS, bool EXACT, int NCH = 2, int LVL = 4, bool DBG = false, bool AR = false, bool G64 = false>
 // (second launch bound = minimum waves per SIMD: 64 registers up to rounds of 24 k-steps -- a CU full of waves -- 128 above)
-__global__ __launch_bounds__(NW * 64, (MAXS <= 24) ? 8 : 4) void strip1_kernel(const Strip1Params p) {
+__global__ __launch_bounds__(NW * 64, (MAXS <= 24 && !G64) ? 8 : 4) void strip1_kernel(const Strip1Params p) {
   static_assert(MAXS % 4 == 0 && MAXS >= 8 && MAXS <= 64, "rounds are whole 128-wide groups, at most 16 of them (round 6: 40 .. 64 k-steps for K up to 32768)");
-  constexpr int NG = MAXS / 4;            // groups per wave
-  constexpr int NPASS = (NG + 3) / 4;     // accumulator sets: groups 0-3, groups 4-7, groups 8-11, groups 12-15
+  static_assert(!(G64 && AR), "the fused all-reduce form is built for 128-wide groups");
+  constexpr int KPG = G64 ? 2 : 4;        // k-steps per group
+  constexpr int NG = MAXS / KPG;          // groups per wave
+  constexpr int NPASS = (MAXS + 15) / 16; // accumulator sets: one per 16 k-steps (four 128-wide groups / eight 64-wide ones)
+  constexpr int GPL = G64 ? 2 : 1;        // groups per lane and pass
   constexpr int XL = (MAXS * 4 + 63) / 64;  // 16-byte activation chunks per lane
   constexpr int RS = strip1_rs(NW);       // floats per column of the reduction buffer (16-byte aligned rows, 2-way banks at most)
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -103,20 +111,23 @@ __global__ __launch_bounds__(NW * 64, (MAXS <= 24) ? 8 : 4) void strip1_kernel(c
     const int t = tb + (c >> 2);
     xkeep[u] = EXACT ? (c < MAXS * 4) : (c < MAXS * 4 && t >= t0 && t < T);
   }
-  const int G0 = tb >> 2;
+  const int G0 = tb / KPG;
   const size_t grow = (size_t)b * p.n_groups + G0;         // first group row of the wave in the strip's scale / zero tables
   const int zk = pr.zero_kind;
   const uint32_t *zbase = (zk == ZK_SYM) ? (const uint32_t *)pr.scales : (const uint32_t *)pr.qzeros;
   const int zmul = (zk == ZK_PACKED) ? 2 : 8;              // dwords per group row
   const int zoff = (zk == ZK_PACKED) ? (i >> 3) : (i >> 1);
-  half_t sc[NPASS];
-  uint32_t zraw[NPASS];
+  half_t sc[NPASS][GPL];
+  uint32_t zraw[NPASS][GPL];
 #pragma unroll
-  for (int ps = 0; ps < NPASS; ++ps) {
-    const int gj = min(4 * ps + g, NG - 1);                // (lanes past the last group re-read it; their sums of x are zero)
-    sc[ps] = pr.scales[(grow + gj) * 16 + i];
-    zraw[ps] = zbase[(grow + gj) * zmul + zoff];
-  }
+  for (int ps = 0; ps < NPASS; ++ps)
+#pragma unroll
+    for (int h = 0; h < GPL; ++h) {
+      // the lane's group(s) of the pass: 4 ps + g (128-wide), 8 ps + 2 g + h (64-wide)
+      const int gj = min((G64 ? 8 * ps + 2 * g + h : 4 * ps + g), NG - 1);  // (lanes past the last group re-read it; their sums of x are zero)
+      sc[ps][h] = pr.scales[(grow + gj) * 16 + i];
+      zraw[ps][h] = zbase[(grow + gj) * zmul + zoff];
+    }
   const uint32_t *wl = pr.qweight + ((size_t)b * T + tb) * 64 + lane;
   uint32_t w[MAXS];
 #pragma unroll
@@ -132,7 +143,7 @@ __global__ __launch_bounds__(NW * 64, (MAXS <= 24) ? 8 : 4) void strip1_kernel(c
   uint32_t fold = 0;  // (LVL < 4: keeps the loaded values alive)
 
   // ---- activations -> LDS (needs only the OLDEST loads; the weights stay in flight) ---------------------------------------------
-  float sx[XL], sxp[XL];
+  float sx[XL], sxp[XL], sx2[XL], sxp2[XL];  // (sx2 / sxp2: the lane's second group of the pass, 64-wide groups only)
   if constexpr (LVL >= 2) {
 #pragma unroll
     for (int u = 0; u < XL; ++u) asm volatile("" : "+v"(xa[u]));  // (pins the staging below the weight loads: strip_kernel.hpp)
@@ -159,34 +170,48 @@ __global__ __launch_bounds__(NW * 64, (MAXS <= 24) ? 8 : 4) void strip1_kernel(c
       a = dpp_add1<0xB1>(a); c = dpp_add1<0xB1>(c);
       a = dpp_add1<0x4E>(a); c = dpp_add1<0x4E>(c);
       a = dpp_add1<0x141>(a); c = dpp_add1<0x141>(c);
-      a = dpp_add1<0x140>(a); c = dpp_add1<0x140>(c);
-      sx[u] = a; sxp[u] = c;   // lane (g, i): sums of group 4 u + g of the wave
+      if constexpr (G64) {
+        // 64-wide groups: the 8-lane halves of the row are two groups (2 g, 2 g + 1 of the pass); every lane needs both
+        const float ao = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x140, 0xF, 0xF, true));
+        const float co = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c), 0x140, 0xF, 0xF, true));
+        const bool lo = (lane & 8) == 0;
+        sx[u] = lo ? a : ao; sxp[u] = lo ? c : co;      // group 8 u + 2 g
+        sx2[u] = lo ? ao : a; sxp2[u] = lo ? co : c;    // group 8 u + 2 g + 1
+      } else {
+        a = dpp_add1<0x140>(a); c = dpp_add1<0x140>(c);
+        sx[u] = a; sxp[u] = c;   // lane (g, i): sums of group 4 u + g of the wave
+      }
       *(half8_t *)(wbase + 16 * (lane + 64 * u)) = half8_t{p0.x, p0.y, q1.x, q1.y, p2.x, p2.y, q3.x, q3.y};
     }
   } else {
 #pragma unroll
-    for (int u = 0; u < XL; ++u) { fold ^= xa[u].x ^ xa[u].y ^ xa[u].z ^ xa[u].w; sx[u] = 0.f; sxp[u] = 0.f; }
+    for (int u = 0; u < XL; ++u) { fold ^= xa[u].x ^ xa[u].y ^ xa[u].z ^ xa[u].w; sx[u] = sxp[u] = sx2[u] = sxp2[u] = 0.f; }
   }
   if constexpr (DBG) {
     if (dbg_slot && lane == 0) dbg_slot[2] = __builtin_amdgcn_s_memrealtime();
   }
 
   // ---- per lane: scale and correction of ITS group (pass ps: group 4 ps + g), while the weights are in flight ------------------
-  float sf[NPASS], cf[NPASS];
+  float sf[NPASS][GPL], cf[NPASS][GPL];
   if constexpr (LVL >= 4) {
     const uint32_t zsel_p = (zk == ZK_PACKED) ? 0xffffffffu : 0u, zsel_h = (zk == ZK_F16) ? 0xffffffffu : 0u;
     const uint32_t zsel_s = (zk == ZK_SYM) ? __builtin_bit_cast(uint32_t, 8.0f) : 0u;
 #pragma unroll
-    for (int ps = 0; ps < NPASS; ++ps) {
-      const float zp = (float)(((zraw[ps] >> (4 * (i & 7))) + (uint32_t)p.add_zero_bias) & 15u);
-      const float zh = (float)__builtin_bit_cast(half_t, (uint16_t)((i & 1) ? (zraw[ps] >> 16) : (zraw[ps] & 0xffffu)));
-      const float zf = __builtin_bit_cast(float, (__builtin_bit_cast(uint32_t, zp) & zsel_p) | (__builtin_bit_cast(uint32_t, zh) & zsel_h) | zsel_s);
-      sf[ps] = (float)sc[ps];
-      cf[ps] = sf[ps] * __builtin_fmaf(zf, sx[ps], 1024.f * sxp[ps]);
-    }
+    for (int ps = 0; ps < NPASS; ++ps)
+#pragma unroll
+      for (int h = 0; h < GPL; ++h) {
+        const uint32_t zr = zraw[ps][h];
+        const float zp = (float)(((zr >> (4 * (i & 7))) + (uint32_t)p.add_zero_bias) & 15u);
+        const float zh = (float)__builtin_bit_cast(half_t, (uint16_t)((i & 1) ? (zr >> 16) : (zr & 0xffffu)));
+        const float zf = __builtin_bit_cast(float, (__builtin_bit_cast(uint32_t, zp) & zsel_p) | (__builtin_bit_cast(uint32_t, zh) & zsel_h) | zsel_s);
+        sf[ps][h] = (float)sc[ps][h];
+        cf[ps][h] = sf[ps][h] * __builtin_fmaf(zf, h ? sx2[ps] : sx[ps], 1024.f * (h ? sxp2[ps] : sxp[ps]));
+      }
   } else if constexpr (LVL >= 1) {
 #pragma unroll
-    for (int ps = 0; ps < NPASS; ++ps) fold ^= zraw[ps] ^ (uint32_t)__builtin_bit_cast(uint16_t, sc[ps]);
+    for (int ps = 0; ps < NPASS; ++ps)
+#pragma unroll
+      for (int h = 0; h < GPL; ++h) fold ^= zraw[ps][h] ^ (uint32_t)__builtin_bit_cast(uint16_t, sc[ps][h]);
   }
 
   // ---- A fragment addresses: lane (g, i) is row i of the A operand; rows 4 j .. 4 j + 3 belong to group j of the pass -----------
@@ -195,14 +220,15 @@ __global__ __launch_bounds__(NW * 64, (MAXS <= 24) ? 8 : 4) void strip1_kernel(c
   uint32_t a_addr[NG];
   const uint32_t xs_lane = (uint32_t)(wbase - (char *)lds) + 16 * g, z_lane = (uint32_t)(zeros - (char *)lds) + 16 * g;
 #pragma unroll
-  for (int j = 0; j < NG; ++j) a_addr[j] = ((i >> 2) == (j & 3)) ? xs_lane : z_lane - 256 * j;
+  for (int j = 0; j < NG; ++j)   // (the zero block is read at + 64 s for the k-steps s of group j: bias its address by the group's first offset)
+    a_addr[j] = (G64 ? ((i >> 1) == (j & 7)) : ((i >> 2) == (j & 3))) ? xs_lane : z_lane - 64 * KPG * j;
 
   float4_t acc[NPASS][NCH];
   const uint32_t mask_lo = nib_mask_vgpr();  // 0x000f000f
   const uint32_t mask_hi = mask_lo << 4;     // 0x00f000f0
 #pragma unroll
   for (int s = 0; s < MAXS; ++s) {
-    const int j = s >> 2, ps = j >> 2, ch = s % NCH;
+    const int j = s / KPG, ps = s >> 4, ch = s % NCH;
     if constexpr (LVL >= 2) {
       const half8_t av = *(const half8_t *)((const char *)lds + a_addr[j] + 64 * s);
       if constexpr (LVL >= 3) {
@@ -231,12 +257,14 @@ __global__ __launch_bounds__(NW * 64, (MAXS <= 24) ? 8 : 4) void strip1_kernel(c
     float term[NPASS];
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
-      float a = acc[ps][0][0];
+      float a = acc[ps][0][0], a2 = acc[ps][0][2];   // (rows 4 g, 4 g + 2 of the lane's column: its first / second group of the pass)
 #pragma unroll
       for (int ch = 1; ch < NCH; ++ch)
-        if (16 * ps + ch < MAXS) a += acc[ps][ch][0];
-      if constexpr (LVL >= 4) term[ps] = __builtin_fmaf(sf[ps], a, -cf[ps]);
-      else term[ps] = a;
+        if (16 * ps + ch < MAXS) { a += acc[ps][ch][0]; a2 += acc[ps][ch][2]; }
+      if constexpr (LVL >= 4) {
+        term[ps] = __builtin_fmaf(sf[ps][0], a, -cf[ps][0]);
+        if constexpr (G64) term[ps] += __builtin_fmaf(sf[ps][1], a2, -cf[ps][1]);
+      } else term[ps] = a;
     }
     val = term[0];
 #pragma unroll

@@ -141,7 +141,8 @@ def test_native_layout_decode_routes(lib):
     assert plan(lib, [W(1024, 8192, layout=NATIVE)], 1) == "strip1 nw=4 round=8 exact grid=strips x 1" + sm
     assert plan(lib, [W(3584, 8192, layout=NATIVE)], 1) == "strip1 nw=7 round=16 exact grid=strips x 1" + sm
     # ... other group sizes, 3 bits and K beyond 512 k-steps stay on the general strip kernel
-    assert plan(lib, [W(4096, 4096, 64, layout=NATIVE)], 1) == "strip nw=8 cpl=1 spw=16 form=lds-slab row_tiles=1" + sm
+    assert plan(lib, [W(4096, 4096, 64, layout=NATIVE)], 1) == "strip1 nw=4 round=32 exact g64 grid=strips x 1" + sm      # (round 6: 64-wide groups on the batch-1 kernel)
+    assert plan(lib, [W(4096, 4096, 32, layout=NATIVE)], 1).startswith("strip nw=")                                       # 32-wide groups: the general kernel
     assert plan(lib, [W(4096, 4096, 128, 3, NATIVE)], 1).startswith("strip nw=16")
     assert plan(lib, [W(28672, 8192, layout=NATIVE)], 1) == "strip1 nw=16 round=56 exact grid=strips x 1" + sm     # (round 6; the general kernel until then)
     assert plan(lib, [W(36864, 8192, layout=NATIVE)], 1).startswith("strip nw=16")                                # K > 32768: the general strip kernel
@@ -211,16 +212,17 @@ def test_native_layout_decode_routes(lib):
     # shard shapes of Llama-2-70B (TP = 8): short K -> 4-wave blocks, K = 8192 -> 8 waves x one round of 32
     assert plan(lib, [W(1024, 8192, layout=NATIVE)], 1).startswith("strip1 nw=4 round=8 exact")
     assert plan(lib, [W(8192, 1024, layout=NATIVE)], 1).startswith("strip1 nw=8 round=32 exact")
-    assert plan(lib, [W(1024, 8192, 64, layout=NATIVE)], 1).startswith("strip nw=4 cpl=1 spw=8 form=lds-slab")   # (64-wide groups: the general kernel)
+    assert plan(lib, [W(1024, 8192, 64, layout=NATIVE)], 1).startswith("strip1 nw=4 round=8 exact g64")           # (64-wide groups too since round 6)
     assert plan(lib, [W(8192, 1024, layout=NATIVE)], 3).startswith("strip nw=16 cpl=1 spw=16 form=dma-A")
     assert plan(lib, [W(28672, 1024, layout=NATIVE)], 1).startswith("strip1 nw=16 round=56 exact")                # (round 6: one round of 56)
     assert plan(lib, [W(36864, 1024, layout=NATIVE)], 1).startswith("strip nw=16 cpl=1 spw=72 form=lds-slab")     # beyond 32768: three rounds of 24
     # g64 / 3 bits / fp16 zero points: slab form for short chunks at batch 1, register-A beyond (no spilling instantiation is built)
     h4, h3 = W(4096, 4096, 64, 4, NATIVE_F16Z), W(4096, 4096, 64, 3, NATIVE_F16Z)
-    assert plan(lib, [h4], 1).startswith("strip nw=8 cpl=1 spw=16 form=lds-slab")
+    assert plan(lib, [h4], 1) == "strip1 nw=4 round=32 exact g64 grid=strips x 1" + sm   # (round 6: HQQ's 64-wide groups on the batch-1 kernel)
     assert plan(lib, [h4], 2).startswith("strip nw=16 cpl=1 spw=8 form=dma-A")          # 64-wide groups, 3 bits: strip_dma from two rows
     assert plan(lib, [h3], 4).startswith("strip nw=16 cpl=1 spw=8 form=dma-A")
-    assert plan(lib, [W(11008, 4096, 64, 4, NATIVE_F16Z)], 1).startswith("strip nw=16 cpl=1 spw=22 form=register-A")
+    assert plan(lib, [W(11008, 4096, 64, 4, NATIVE_F16Z)], 1) == "strip1 nw=15 round=24 g64 grid=strips x 1" + sm   # (was the register-A form: 12.3 us)
+    assert plan(lib, [W(28672, 4096, 64, 4, NATIVE_F16Z)], 1).startswith("strip nw=16")                             # 64-wide groups: K <= 24576
     assert plan(lib, [h3], 1).startswith("strip nw=16 cpl=1 spw=8 form=lds-slab")
     assert plan(lib, [h3], 16).startswith("strip nw=16 cpl=1 spw=8 form=dma-A")
     # 3 bits from 17 rows: the panel kernel (exact q - z from the slot-scaled patterns), up to 64 rows; the 256-row tiles above

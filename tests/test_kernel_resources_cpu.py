@@ -89,13 +89,14 @@ def test_native_layout_decode_kernels_keep_their_occupancy():
 
 def test_batch1_kernel_keeps_a_cu_full_of_waves():
     """csrc/strip1_kernel.hpp (round 5, the headline kernel): rounds of up to 24 k-steps at <= 64 registers (8 waves per SIMD: its
-    launch bound), rounds of 32 at <= 128; the fused all-reduce forms within the same budgets; no instantiation spills."""
+    launch bound), rounds of 32 .. 64 and the 64-wide-group forms at <= 128; the fused all-reduce forms within the same budgets; no instantiation spills."""
     res = {n: v for n, v in _resources("strip1.hip").items() if "strip1_kernel" in n}
     assert len(res) >= 16
     for n, (vgpr, spill) in res.items():
         m = re.search(r"strip1_kernelILi(\d+)ELi(\d+)E", n)
         nw, maxs = int(m.group(1)), int(m.group(2))
-        assert spill == 0 and vgpr <= (64 if maxs <= 24 else 128), (n, nw, maxs, vgpr, spill)
+        g64 = n.endswith("ELb1EEEvNS_12Strip1ParamsE")   # (round 6: the 64-wide-group forms carry twice the group addresses / scales: <= 128)
+        assert spill == 0 and vgpr <= (64 if maxs <= 24 and not g64 else 128), (n, nw, maxs, vgpr, spill)
 
 
 def test_wave_specialised_prefill_kernel_budget():

@@ -107,3 +107,56 @@ def test_properties_at_full_size():
         row = ops.linear_forward(w, e).float().cpu().numpy()[0]
         want = Ref(d).w[k].astype(np.float32) + d["bias"].astype(np.float32)
         assert np.abs(row - want).max() <= 2e-3 * np.abs(want).max()
+
+
+G64_FORMS = [(256, "nw=4 round=8 g64"), (1024, "nw=4 round=8 exact g64"), (2048, "nw=4 round=16 exact g64"), (3584, "nw=7 round=16 exact g64"),
+             (4096, "nw=8 round=16 exact g64"), (5120, "nw=8 round=24 g64"), (8192, "nw=8 round=32 exact g64"), (11008, "nw=15 round=24 g64"),
+             (14336, "nw=16 round=32 g64"), (18944, "nw=16 round=40 g64"), (24576, "nw=16 round=48 exact g64")]
+
+
+@pytest.mark.parametrize("K,form", G64_FORMS)
+def test_every_form_with_64_wide_groups(K, form):
+    """Round 6: 64-wide groups on the batch-1 kernel (G64: two A rows per group, two groups per lane and pass) -- HQQ fp16 zero points,
+    GPTQ packed zero points with bias, symmetric; fp16 and bf16; against the oracle and float64 of the reference's W."""
+    from qllm_amd import ops
+    N = 1024 if K > 8192 else 8192
+    for layout, zk, bias in (("HQQ", "asym", False), ("GPTQ", "asym", True), ("GPTQ", "sym", False)):
+        d = synth(layout, 4, 64, K, N, zk, False, bias, seed=K + len(layout) + 64)
+        d["scales"] = (d["scales"].astype(np.float32) * (4096 / K) ** 0.5 * 0.5).astype(np.float16)
+        layer = to_layer(d, DEV)
+        w, keep = _native(layer, d, zk)
+        assert ops.plan_describe([w], 1).startswith("strip1 " + form), ops.plan_describe([w], 1)
+        ref = Ref(d)
+        for seed in (1, 2):
+            x = randx(1, K, seed=seed)
+            y = ops.linear_forward(w, torch.from_numpy(x).to(DEV)).cpu().numpy()
+            assert O.rel_err(y, ref.y16(x)) <= 1e-2, (layout, zk)
+            assert O.rel_err(y.astype(np.float64), ref.y64(x)) <= 2e-3, (layout, zk)
+        xb = torch.from_numpy(randx(1, K, seed=9)).to(DEV).to(torch.bfloat16)
+        yb = ops.linear_forward(w, xb)
+        assert yb.dtype == torch.bfloat16
+        assert O.rel_err(yb.float().cpu().numpy(), ref.y64(xb.float().cpu().numpy().astype(np.float16))) <= 2e-2, (layout, zk)
+        # the general strip kernel on the same descriptor (QLLM_STRIP1 = 2: 128-wide groups only): same contract, close results
+        try:
+            ops.set_knob("QLLM_STRIP1", 2)
+            assert ops.plan_describe([w], 1).startswith("strip nw=")
+            x = torch.from_numpy(randx(1, K, seed=1)).to(DEV)
+            y_gen = ops.linear_forward(w, x)
+        finally:
+            ops.reset_knobs()
+        assert O.rel_err(ops.linear_forward(w, x).cpu().numpy(), y_gen.cpu().numpy()) <= 1e-3
+
+
+def test_grouped_launch_with_64_wide_groups():
+    """q/k/v of an HQQ g64 layer stack at batch 1: one grouped launch of the G64 form, unequal widths."""
+    from qllm_amd import ops
+    K = 4096
+    ds = [synth("HQQ", 4, 64, K, n, "asym", False, i == 2, seed=70 + i) for i, n in enumerate((4096, 1024, 1024))]
+    layers = [to_layer(d, DEV) for d in ds]
+    descs = [l.native_descriptor(0) for l in layers]
+    assert ops.plan_describe(descs, 1) == "strip1 nw=8 round=16 exact g64 grid=strips x 3 layout=strip-major"
+    x = randx(1, K, seed=3)
+    outs = ops.linear_forward_grouped(descs, torch.from_numpy(x).to(DEV))
+    for o, d in zip(outs, ds):
+        assert O.rel_err(o.cpu().numpy(), Ref(d).y16(x)) <= 1e-2
+        assert O.rel_err(o.cpu().numpy().astype(np.float64), Ref(d).y64(x)) <= 2e-3
