@@ -37,6 +37,7 @@ struct Settable {
   int value, set;
 };
 static Settable kSettable[] = {
+    {"QLLM_STRIP1_MAX_M", 1, 4, 0, 0},         // 1: batches 2..4 on strip_dma instead of the batch-1 kernel's four-row forms
     {"QLLM_STRIP1", 0, 2, 0, 0},               // 0: batch-1 calls on the general strip kernel (the round-4 path); 2: only 128-wide groups on the batch-1 kernel
     {"QLLM_PANEL", 0, 1, 0, 0},                // 0: no panel kernel (strips to 32 rows, the 256-row tiles above)
     {"QLLM_PANEL_MIN_M", 17, 129, 0, 0},       // single layers: rows from which the panel kernel serves (no form below 17 rows)
@@ -237,6 +238,17 @@ static bool strip_plan(const qllm_weight_t *w, int n, int M, StripPlan *plan) {
     // strip-major: 16-column strips only (every wave-load is 256 contiguous bytes whatever the width; narrow strips balance best)
     const int strips = cols / 16;
     if (strips < 1) return false;
+    // Round 6: batches 2..4 on the batch-1 kernel's four-row forms (128-wide groups, K <= 16384): the A rows that carry four copies of x
+    // at batch 1 carry four batch rows -- the weight stream and the MFMAs of a batch-1 launch.  QLLM_STRIP1_MAX_M = 1 keeps them on strip_dma.
+    if (M >= 2 && M <= 4 && M <= knob("QLLM_STRIP1_MAX_M", 4) && bits == 4 && w[0].group_size == 128 && w[0].K <= 16384 && knob("QLLM_STRIP1", 1)) {
+      int nw1 = 0, maxs1 = 0;
+      if (strip1_shape(w[0].K, strips, compute_units(), &nw1, &maxs1) && maxs1 <= 32) {
+        plan->cpl = 1; plan->nw = nw1; plan->spw = maxs1; plan->ra = 0; plan->sm = 1;
+        plan->one_nw = nw1;
+        plan->one_maxs = maxs1;
+        return true;
+      }
+    }
     const int slab_nw = ra_base ? 0 : strip_sm_nw(w[0].K, M, w[0].group_size, bits);  // 0: no slab form for this shape
     // register-A form at M = 5..16, 4 bits, every layer a multiple of 64 wide and enough of them: blocks of four adjacent strips
     // (a register-A block re-reads all of x from L2; 64 columns share it instead of 16)
@@ -368,13 +380,14 @@ static bool strip_plan(const qllm_weight_t *w, int n, int M, StripPlan *plan) {
 // layouts that may share a grouped launch: reference row-stream (GPTQ / HQQ), AWQ, native
 static int layout_family(const qllm_weight_t &w) { return is_native(w) ? 2 : (w.layout == QLLM_LAYOUT_AWQ_GEMM ? 1 : 0); }
 
-static int run_strip1(const StripPlan &pl, const qllm_weight_t *w, void *const *y, int n, const void *x, int act_dtype, hipStream_t stream) {
+static int run_strip1(const StripPlan &pl, const qllm_weight_t *w, void *const *y, int n, const void *x, int M, int act_dtype, hipStream_t stream) {
   Strip1Params p;
   memset(&p, 0, sizeof(p));
   p.x = x;
   p.T = w[0].K / 32;
   p.n_groups = w[0].K / w[0].group_size;
   p.group64 = w[0].group_size == 64;
+  p.M = M;
   p.add_zero_bias = w[0].add_zero_bias;
   p.act_bf16 = (act_dtype == QLLM_BF16);
   p.dbg = (g_timeline && g_timeline_next < g_timeline_slots) ? g_timeline + 24 * (g_timeline_next++) : nullptr;
@@ -394,7 +407,7 @@ static int run_strip1(const StripPlan &pl, const qllm_weight_t *w, void *const *
 }
 
 static int run_strip(const StripPlan &pl, const qllm_weight_t *w, void *const *y, int n, const void *x, int M, int act_dtype, hipStream_t stream) {
-  if (pl.one_nw) return run_strip1(pl, w, y, n, x, act_dtype, stream);
+  if (pl.one_nw) return run_strip1(pl, w, y, n, x, M, act_dtype, stream);
   StripParams p;
   memset(&p, 0, sizeof(p));
   p.x = x;
@@ -900,8 +913,8 @@ static void describe(const Decision &d, const qllm_weight_t *w, int n, int M, si
     case ROUTE_STRIP: {
       const StripPlan &pl = d.strip;
       if (pl.one_nw)
-        snprintf(buf, buflen, "strip1 nw=%d round=%d%s%s grid=strips x %d layout=strip-major", pl.one_nw, pl.one_maxs,
-                 pl.one_nw * pl.one_maxs == w[0].K / 32 ? " exact" : "", w[0].group_size == 64 ? " g64" : "", n);
+        snprintf(buf, buflen, "strip1 nw=%d round=%d%s%s%s grid=strips x %d layout=strip-major", pl.one_nw, pl.one_maxs,
+                 pl.one_nw * pl.one_maxs == w[0].K / 32 ? " exact" : "", w[0].group_size == 64 ? " g64" : "", M > 1 ? " rows=4" : "", n);
       else
         snprintf(buf, buflen, "strip nw=%d cpl=%d spw=%d form=%s row_tiles=%d%s", pl.nw, pl.cpl, pl.spw,
                  pl.ra == 2 ? "dma-A" : (pl.ra ? "register-A" : "lds-slab"), M > 32 ? 4 : (M > 16 ? 2 : 1), pl.sm ? " layout=strip-major" : "");
@@ -1150,6 +1163,7 @@ int qllm_linear_forward_allreduce(const qllm_weight_t *w, const void *x, void *y
   p.x = x;
   p.T = w->K / 32;
   p.n_groups = w->K / 128;
+  p.M = 1;
   p.add_zero_bias = w->add_zero_bias;
   p.act_bf16 = (act_dtype == QLLM_BF16);
   p.prob[0] = Strip1Problem{(const uint32_t *)w->qweight, (const half_t *)w->scales, w->qzeros, (const half_t *)w->bias, y, w->N / 16, zero_kind_of(*w)};

@@ -114,6 +114,7 @@ struct Strip1Params {
   int T;          // K / 32
   int n_groups;   // K / group size (128, or 64: group64)
   int group64;    // 1: 64-wide groups (the G64 instantiations, round 6)
+  int M;          // batch rows: 1, or 2..4 on the four-row instantiations (MR = 4, round 6; 128-wide groups)
   int add_zero_bias;
   int act_bf16;
   uint64_t *dbg;  // diagnostics (qllm_debug_timeline): 24 timestamps for this launch (3 blocks x 8), or NULL

@@ -47,11 +47,11 @@ __device__ __forceinline__ float dpp_add1(float v) {
 // waves would otherwise put all 16 columns on the same banks)
 constexpr int strip1_rs(int nw) { return nw * 4 + 4 + (((nw * 4 + 4) % 32 == 0) ? 4 : 0); }
 
-template <int NW, int MAXS>
+template <int NW, int MAXS, int MR = 1>
 constexpr int strip1_lds_bytes() {
   constexpr int XL = (MAXS * 4 + 63) / 64;
   static_assert(NW * 4 <= 64, "at most 16 waves");
-  return 16 * strip1_rs(NW) * 4 + NW * (XL * 1024 + 256);
+  return 16 * MR * strip1_rs(NW) * 4 + NW * (MR * XL * 1024 + 256);
 }
 
 // NW waves x MAXS k-steps cover T (host: NW * MAXS >= T >= MAXS; EXACT: NW * MAXS == T, no masking of a shifted window)
@@ -64,11 +64,16 @@ constexpr int strip1_lds_bytes() {
 //     A rows 2 j, 2 j + 1 carry x on the k-steps of group j, so lane (g, i) finds group 2 g of the pass in accumulator registers 0 / 1
 //     and group 2 g + 1 in registers 2 / 3 -- two scales, two zero points, two corrections per lane and pass; the staging pass sums x
 //     over the 8 lanes of a group and fetches the neighbouring group's sums with one more DPP move.
-template <int NW, int MAXS, bool EXACT, int NCH = 2, int LVL = 4, bool DBG = false, bool AR = false, bool G64 = false>
+// MR = 4 (round 6): batches 2..4 at the price of batch 1.  With 128-wide groups the A operand's rows 4 j .. 4 j + 3 all belong to group j of
+//     the pass -- at batch 1 they carry four copies of x.  Here row 4 j + m carries batch row m (rows past M: zeros), so accumulator
+//     register m of lane (g, i) is batch row m of column i for group g: the same weight stream, the same MFMAs, four times the staging
+//     and four corrections per lane.  (Until then batches 2..4 took strip_dma.hpp: ~1.5 x a batch-1 launch.)
+template <int NW, int MAXS, bool EXACT, int NCH = 2, int LVL = 4, bool DBG = false, bool AR = false, bool G64 = false, int MR = 1>
 // (second launch bound = minimum waves per SIMD: 64 registers up to rounds of 24 k-steps -- a CU full of waves -- 128 above)
-__global__ __launch_bounds__(NW * 64, (MAXS <= 24 && !G64) ? 8 : 4) void strip1_kernel(const Strip1Params p) {
+__global__ __launch_bounds__(NW * 64, (MAXS <= 24 && !G64 && MR == 1) ? 8 : 4) void strip1_kernel(const Strip1Params p) {
   static_assert(MAXS % 4 == 0 && MAXS >= 8 && MAXS <= 64, "rounds are whole 128-wide groups, at most 16 of them (round 6: 40 .. 64 k-steps for K up to 32768)");
   static_assert(!(G64 && AR), "the fused all-reduce form is built for 128-wide groups");
+  static_assert(MR == 1 || (MR == 4 && !G64 && !AR && !DBG && LVL == 4), "four batch rows: 128-wide groups, the plain form");
   constexpr int KPG = G64 ? 2 : 4;        // k-steps per group
   constexpr int NG = MAXS / KPG;          // groups per wave
   constexpr int NPASS = (MAXS + 15) / 16; // accumulator sets: one per 16 k-steps (four 128-wide groups / eight 64-wide ones)
@@ -101,13 +106,17 @@ __global__ __launch_bounds__(NW * 64, (MAXS <= 24 && !G64) ? 8 : 4) void strip1_
   const int t0 = wave * MAXS;                              // the wave owns k-steps [t0, min(t0 + MAXS, T))
   const int tb = EXACT ? t0 : min(t0, T - MAXS);           // its window [tb, tb + MAXS): shifted back into the strip at the end of K
   // ---- every load of the wave, back to back: x chunk(s), one scale + one zero word per pass, MAXS weight words -----------------
-  uint4_t xa[XL];
+  uint4_t xa[MR][XL];
   bool xkeep[XL];
 #pragma unroll
   for (int u = 0; u < XL; ++u) {
     const int c = lane + 64 * u;                           // 16-byte chunk of the window: k-step tb + c / 4
     const int cc = min(c, MAXS * 4 - 1);
-    xa[u] = *(const uint4_t *)((const uint16_t *)p.x + 32 * tb + 8 * cc);
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {                         // (MR = 4: batch row m of x, row stride K = 32 T halves; rows past M stay zero)
+      xa[m][u] = uint4_t{0, 0, 0, 0};
+      if (MR == 1 || m < p.M) xa[m][u] = *(const uint4_t *)((const uint16_t *)p.x + (size_t)m * 32 * T + 32 * tb + 8 * cc);
+    }
     const int t = tb + (c >> 2);
     xkeep[u] = EXACT ? (c < MAXS * 4) : (c < MAXS * 4 && t >= t0 && t < T);
   }
@@ -138,20 +147,24 @@ __global__ __launch_bounds__(NW * 64, (MAXS <= 24 && !G64) ? 8 : 4) void strip1_
   }
 
   // wave-private LDS: staged activations (XL KB: chunk c at 16 c) and 256 zero bytes
-  char *wbase = (char *)lds + 16 * RS * 4 + wave * (XL * 1024 + 256);
-  char *zeros = wbase + XL * 1024;
+  char *wbase = (char *)lds + 16 * MR * RS * 4 + wave * (MR * XL * 1024 + 256);   // (MR = 4: batch row m's chunks at + m XL KB)
+  char *zeros = wbase + MR * XL * 1024;
   uint32_t fold = 0;  // (LVL < 4: keeps the loaded values alive)
 
   // ---- activations -> LDS (needs only the OLDEST loads; the weights stay in flight) ---------------------------------------------
-  float sx[XL], sxp[XL], sx2[XL], sxp2[XL];  // (sx2 / sxp2: the lane's second group of the pass, 64-wide groups only)
+  float sx[MR][XL], sxp[MR][XL], sx2[XL], sxp2[XL];  // (sx2 / sxp2: the lane's second group of the pass, 64-wide groups only)
   if constexpr (LVL >= 2) {
 #pragma unroll
-    for (int u = 0; u < XL; ++u) asm volatile("" : "+v"(xa[u]));  // (pins the staging below the weight loads: strip_kernel.hpp)
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+      for (int u = 0; u < XL; ++u) asm volatile("" : "+v"(xa[m][u]));  // (pins the staging below the weight loads: strip_kernel.hpp)
     *(uint32_t *)(zeros + 4 * lane) = 0u;
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
 #pragma unroll
     for (int u = 0; u < XL; ++u) {
       const half8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-      half8_t xv = p.act_bf16 ? bf16x8_to_h8(xa[u]) : __builtin_bit_cast(half8_t, xa[u]);
+      half8_t xv = p.act_bf16 ? bf16x8_to_h8(xa[m][u]) : __builtin_bit_cast(half8_t, xa[m][u]);
       xv = xkeep[u] ? xv : zero8;
       const half8_t pv = a_perm_04152637(xv);
       const half2_t p0 = {pv[0], pv[1]}, p1 = {pv[2], pv[3]}, p2 = {pv[4], pv[5]}, p3 = {pv[6], pv[7]};
@@ -175,24 +188,25 @@ __global__ __launch_bounds__(NW * 64, (MAXS <= 24 && !G64) ? 8 : 4) void strip1_
         const float ao = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x140, 0xF, 0xF, true));
         const float co = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c), 0x140, 0xF, 0xF, true));
         const bool lo = (lane & 8) == 0;
-        sx[u] = lo ? a : ao; sxp[u] = lo ? c : co;      // group 8 u + 2 g
+        sx[m][u] = lo ? a : ao; sxp[m][u] = lo ? c : co;      // group 8 u + 2 g
         sx2[u] = lo ? ao : a; sxp2[u] = lo ? co : c;    // group 8 u + 2 g + 1
       } else {
         a = dpp_add1<0x140>(a); c = dpp_add1<0x140>(c);
-        sx[u] = a; sxp[u] = c;   // lane (g, i): sums of group 4 u + g of the wave
+        sx[m][u] = a; sxp[m][u] = c;   // lane (g, i): sums of group 4 u + g of the wave (batch row m)
       }
-      *(half8_t *)(wbase + 16 * (lane + 64 * u)) = half8_t{p0.x, p0.y, q1.x, q1.y, p2.x, p2.y, q3.x, q3.y};
+      *(half8_t *)(wbase + m * (XL * 1024) + 16 * (lane + 64 * u)) = half8_t{p0.x, p0.y, q1.x, q1.y, p2.x, p2.y, q3.x, q3.y};
     }
   } else {
 #pragma unroll
-    for (int u = 0; u < XL; ++u) { fold ^= xa[u].x ^ xa[u].y ^ xa[u].z ^ xa[u].w; sx[u] = sxp[u] = sx2[u] = sxp2[u] = 0.f; }
+    for (int u = 0; u < XL; ++u) { fold ^= xa[0][u].x ^ xa[0][u].y ^ xa[0][u].z ^ xa[0][u].w; sx[0][u] = sxp[0][u] = sx2[u] = sxp2[u] = 0.f; }
   }
   if constexpr (DBG) {
     if (dbg_slot && lane == 0) dbg_slot[2] = __builtin_amdgcn_s_memrealtime();
   }
 
   // ---- per lane: scale and correction of ITS group (pass ps: group 4 ps + g), while the weights are in flight ------------------
-  float sf[NPASS][GPL], cf[NPASS][GPL];
+  constexpr int NCF = (MR > 1) ? MR : GPL;   // corrections per lane and pass: its group(s), or its four batch rows
+  float sf[NPASS][GPL], cf[NPASS][NCF];
   if constexpr (LVL >= 4) {
     const uint32_t zsel_p = (zk == ZK_PACKED) ? 0xffffffffu : 0u, zsel_h = (zk == ZK_F16) ? 0xffffffffu : 0u;
     const uint32_t zsel_s = (zk == ZK_SYM) ? __builtin_bit_cast(uint32_t, 8.0f) : 0u;
@@ -205,7 +219,12 @@ __global__ __launch_bounds__(NW * 64, (MAXS <= 24 && !G64) ? 8 : 4) void strip1_
         const float zh = (float)__builtin_bit_cast(half_t, (uint16_t)((i & 1) ? (zr >> 16) : (zr & 0xffffu)));
         const float zf = __builtin_bit_cast(float, (__builtin_bit_cast(uint32_t, zp) & zsel_p) | (__builtin_bit_cast(uint32_t, zh) & zsel_h) | zsel_s);
         sf[ps][h] = (float)sc[ps][h];
-        cf[ps][h] = sf[ps][h] * __builtin_fmaf(zf, h ? sx2[ps] : sx[ps], 1024.f * (h ? sxp2[ps] : sxp[ps]));
+        if constexpr (MR > 1) {
+#pragma unroll
+          for (int m = 0; m < MR; ++m) cf[ps][m] = sf[ps][0] * __builtin_fmaf(zf, sx[m][ps], 1024.f * sxp[m][ps]);
+        } else {
+          cf[ps][h] = sf[ps][h] * __builtin_fmaf(zf, h ? sx2[ps] : sx[0][ps], 1024.f * (h ? sxp2[ps] : sxp[0][ps]));
+        }
       }
   } else if constexpr (LVL >= 1) {
 #pragma unroll
@@ -221,7 +240,7 @@ __global__ __launch_bounds__(NW * 64, (MAXS <= 24 && !G64) ? 8 : 4) void strip1_
   const uint32_t xs_lane = (uint32_t)(wbase - (char *)lds) + 16 * g, z_lane = (uint32_t)(zeros - (char *)lds) + 16 * g;
 #pragma unroll
   for (int j = 0; j < NG; ++j)   // (the zero block is read at + 64 s for the k-steps s of group j: bias its address by the group's first offset)
-    a_addr[j] = (G64 ? ((i >> 1) == (j & 7)) : ((i >> 2) == (j & 3))) ? xs_lane : z_lane - 64 * KPG * j;
+    a_addr[j] = (G64 ? ((i >> 1) == (j & 7)) : ((i >> 2) == (j & 3))) ? xs_lane + (MR > 1 ? (i & 3) * (XL * 1024) : 0) : z_lane - 64 * KPG * j;
 
   float4_t acc[NPASS][NCH];
   const uint32_t mask_lo = nib_mask_vgpr();  // 0x000f000f
@@ -252,34 +271,44 @@ __global__ __launch_bounds__(NW * 64, (MAXS <= 24 && !G64) ? 8 : 4) void strip1_
   }
 
   // ---- the lane's value: its group's partial of column i; then one pass over [column][wave][g] -------------------------------------
-  float val;
+  float val[MR];
   if constexpr (LVL >= 3) {
-    float term[NPASS];
+#pragma unroll
+    for (int m = 0; m < MR; ++m) val[m] = 0.f;
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
-      float a = acc[ps][0][0], a2 = acc[ps][0][2];   // (rows 4 g, 4 g + 2 of the lane's column: its first / second group of the pass)
+      if constexpr (MR > 1) {
 #pragma unroll
-      for (int ch = 1; ch < NCH; ++ch)
-        if (16 * ps + ch < MAXS) { a += acc[ps][ch][0]; a2 += acc[ps][ch][2]; }
-      if constexpr (LVL >= 4) {
-        term[ps] = __builtin_fmaf(sf[ps][0], a, -cf[ps][0]);
-        if constexpr (G64) term[ps] += __builtin_fmaf(sf[ps][1], a2, -cf[ps][1]);
-      } else term[ps] = a;
+        for (int m = 0; m < MR; ++m) {   // (register m of the lane's accumulators: batch row m of its group)
+          float a = acc[ps][0][m];
+#pragma unroll
+          for (int ch = 1; ch < NCH; ++ch)
+            if (16 * ps + ch < MAXS) a += acc[ps][ch][m];
+          val[m] += __builtin_fmaf(sf[ps][0], a, -cf[ps][m]);
+        }
+      } else {
+        float a = acc[ps][0][0], a2 = acc[ps][0][2];   // (rows 4 g, 4 g + 2 of the lane's column: its first / second group of the pass)
+#pragma unroll
+        for (int ch = 1; ch < NCH; ++ch)
+          if (16 * ps + ch < MAXS) { a += acc[ps][ch][0]; a2 += acc[ps][ch][2]; }
+        if constexpr (LVL >= 4) {
+          val[0] += __builtin_fmaf(sf[ps][0], a, -cf[ps][0]);
+          if constexpr (G64) val[0] += __builtin_fmaf(sf[ps][1], a2, -cf[ps][1]);
+        } else val[0] += a;
+      }
     }
-    val = term[0];
-#pragma unroll
-    for (int ps = 1; ps < NPASS; ++ps) val += term[ps];
-    if constexpr (LVL < 4) val = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, val) ^ fold);
+    if constexpr (LVL < 4) val[0] = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, val[0]) ^ fold);
   } else {
-    val = __builtin_bit_cast(float, fold);
+    val[0] = __builtin_bit_cast(float, fold);
   }
-  lds[i * RS + wave * 4 + g] = val;
+#pragma unroll
+  for (int m = 0; m < MR; ++m) lds[(m * 16 + i) * RS + wave * 4 + g] = val[m];
   __syncthreads();
   if constexpr (DBG) {
     if (dbg_slot && lane == 0) dbg_slot[4] = __builtin_amdgcn_s_memrealtime();
   }
-  float vfin = 0.f;  // (lanes 0..15 of wave 0: the block's 16 outputs)
-  if (threadIdx.x < 16) {
+  float vfin = 0.f;  // (lanes 0..15 of wave 0: the block's 16 outputs; MR = 4: threads 16 m .. 16 m + 15 hold batch row m)
+  if (threadIdx.x < 16 * MR) {
     const float4_t *row = (const float4_t *)(lds + threadIdx.x * RS);
     float4_t t[NW];
 #pragma unroll
@@ -297,12 +326,15 @@ __global__ __launch_bounds__(NW * 64, (MAXS <= 24 && !G64) ? 8 : 4) void strip1_
       for (int q = 0; q < NW; ++q) { const uint4_t r = __builtin_bit_cast(uint4_t, t[q]); f ^= r.x ^ r.y ^ r.z ^ r.w; }
       v = (float)(f & 1023u);
     }
-    const int n = b * 16 + threadIdx.x;
+    const int n = b * 16 + (threadIdx.x & 15), mrow = threadIdx.x >> 4;
     if (pr.bias) v += (float)pr.bias[n];
     vfin = v;
     if constexpr (!AR) {
-      if (p.act_bf16) ((uint16_t *)pr.y)[n] = f32_to_bf16(v);
-      else ((half_t *)pr.y)[n] = (half_t)v;
+      if (MR == 1 || mrow < p.M) {
+        const size_t at = (size_t)mrow * pr.n_strips * 16 + n;   // (y is [M][N], N = 16 n_strips)
+        if (p.act_bf16) ((uint16_t *)pr.y)[at] = f32_to_bf16(v);
+        else ((half_t *)pr.y)[at] = (half_t)v;
+      }
     }
   }
   if constexpr (AR) {

@@ -150,7 +150,21 @@ def test_native_layout_decode_routes(lib):
     assert plan(lib, [W(24576, 4096, layout=NATIVE)], 1) == "strip1 nw=16 round=48 exact grid=strips x 1" + sm
     assert plan(lib, [W(32768, 4096, layout=NATIVE)], 1) == "strip1 nw=16 round=64 exact grid=strips x 1" + sm
     # M = 2..32: strip_dma.hpp (activations through LDS by DMA); one strip per 16-wave block while the strips fit one round of CUs
-    for m in (2, 4, 5, 16):
+    # (round 6: batches 2..4 on 128-wide groups ride the batch-1 kernel's four-row forms -- 32.0 / 33.6 / 35.0 us per 7B layer against
+    #  37.6 / 38.0 / 38.5 on strip_dma; QLLM_STRIP1_MAX_M = 1 restores strip_dma)
+    for m in (2, 3, 4):
+        assert plan(lib, [attn], m) == "strip1 nw=4 round=32 exact rows=4 grid=strips x 1" + sm
+        assert plan(lib, [attn] * 3, m) == "strip1 nw=8 round=16 exact rows=4 grid=strips x 3" + sm
+        assert plan(lib, [down], m) == "strip1 nw=15 round=24 rows=4 grid=strips x 1" + sm
+        assert plan(lib, [W(4096, 4096, 64, layout=NATIVE)], m).startswith("strip nw=16 cpl=1 spw=8 form=dma-A")     # 64-wide groups: strip_dma
+        assert plan(lib, [W(18944, 3584, layout=NATIVE)], m).startswith("strip nw=16 cpl=1 spw=40 form=dma-A")       # K > 16384: strip_dma
+    from qllm_amd import ops as _ops
+    try:
+        _ops.set_knob("QLLM_STRIP1_MAX_M", 1)
+        assert plan(lib, [attn], 2) == "strip nw=16 cpl=1 spw=8 form=dma-A row_tiles=1" + sm
+    finally:
+        _ops.reset_knobs()
+    for m in (5, 16):
         assert plan(lib, [attn], m) == "strip nw=16 cpl=1 spw=8 form=dma-A row_tiles=1" + sm
         # K >= 2 N: round 4 sent 9..16 rows to the panel kernel; with the strips' scale / zero tables in LDS (round 5) the one-strip
         # blocks win again (M = 16: 15.0 -> 13.5-14.4 us at g64, 13.5 -> 13.1 at g128; profiles/r05_batch16.md)
@@ -213,7 +227,8 @@ def test_native_layout_decode_routes(lib):
     assert plan(lib, [W(1024, 8192, layout=NATIVE)], 1).startswith("strip1 nw=4 round=8 exact")
     assert plan(lib, [W(8192, 1024, layout=NATIVE)], 1).startswith("strip1 nw=8 round=32 exact")
     assert plan(lib, [W(1024, 8192, 64, layout=NATIVE)], 1).startswith("strip1 nw=4 round=8 exact g64")           # (64-wide groups too since round 6)
-    assert plan(lib, [W(8192, 1024, layout=NATIVE)], 3).startswith("strip nw=16 cpl=1 spw=16 form=dma-A")
+    assert plan(lib, [W(8192, 1024, layout=NATIVE)], 3).startswith("strip1 nw=8 round=32 exact rows=4")
+    assert plan(lib, [W(8192, 1024, layout=NATIVE)], 5).startswith("strip nw=16 cpl=1 spw=16 form=dma-A")
     assert plan(lib, [W(28672, 1024, layout=NATIVE)], 1).startswith("strip1 nw=16 round=56 exact")                # (round 6: one round of 56)
     assert plan(lib, [W(36864, 1024, layout=NATIVE)], 1).startswith("strip nw=16 cpl=1 spw=72 form=lds-slab")     # beyond 32768: three rounds of 24
     # g64 / 3 bits / fp16 zero points: slab form for short chunks at batch 1, register-A beyond (no spilling instantiation is built)
@@ -316,7 +331,7 @@ def test_release_library_has_no_reachable_one_row_tile_panel(lib, monkeypatch):
     for K, N, g, bits, lay in ((11008, 4096, 128, 4, NATIVE), (11008, 4096, 64, 4, NATIVE_F16Z), (11008, 4096, 64, 3, NATIVE_F16Z),
                                (28672, 8192, 128, 4, NATIVE), (4096, 4096, 32, 4, NATIVE), (8192, 1024, 128, 4, NATIVE)):
         for m in range(2, 17):
-            assert plan(lib, [W(K, N, g, bits, lay)], m).startswith("strip "), (K, N, g, bits, m)
+            assert plan(lib, [W(K, N, g, bits, lay)], m).startswith(("strip ", "strip1 ")), (K, N, g, bits, m)   # (strip1: batches 2..4, round 6)
         assert plan(lib, [W(K, N, g, bits, lay)], 33).startswith("panel "), (K, N, g, bits)
 
 

@@ -160,3 +160,44 @@ def test_grouped_launch_with_64_wide_groups():
     for o, d in zip(outs, ds):
         assert O.rel_err(o.cpu().numpy(), Ref(d).y16(x)) <= 1e-2
         assert O.rel_err(o.cpu().numpy().astype(np.float64), Ref(d).y64(x)) <= 2e-3
+
+
+@pytest.mark.parametrize("K,N", [(4096, 4096), (11008, 4096), (4096, 11008), (8192, 1024), (3584, 8192), (16384, 1024), (1152, 2048)])
+def test_batches_2_to_4_on_the_four_row_forms(K, N):
+    """Round 6: with 128-wide groups the four A rows of a group carry four BATCH rows (rows past M: zeros): batches 2..4 through the
+    batch-1 kernel's weight stream.  Against the oracle, float64 of the reference's W, strip_dma on the same descriptor, and row by row
+    against the batch-1 launch (same arithmetic per row: bit-equal)."""
+    from qllm_amd import ops
+    for layout, zk, bias in (("GPTQ", "asym", True), ("HQQ", "asym", False)):
+        d = synth(layout, 4, 128, K, N, zk, False, bias, seed=K + N + len(layout))
+        d["scales"] = (d["scales"].astype(np.float32) * (4096 / K) ** 0.5 * 0.5).astype(np.float16)
+        layer = to_layer(d, DEV)
+        w = layer.native_descriptor(0)
+        ref = Ref(d)
+        for m in (2, 3, 4):
+            assert " rows=4 " in ops.plan_describe([w], m), ops.plan_describe([w], m)
+            x = randx(m, K, seed=m)
+            xt = torch.from_numpy(x).to(DEV)
+            y = ops.linear_forward(w, xt)
+            assert y.shape == (m, N)
+            assert O.rel_err(y.cpu().numpy(), ref.y16(x)) <= 1e-2, (layout, m)
+            assert O.rel_err(y.cpu().numpy().astype(np.float64), ref.y64(x)) <= 2e-3, (layout, m)
+            for r in range(m):
+                assert torch.equal(y[r:r + 1], ops.linear_forward(w, xt[r:r + 1].contiguous())), (layout, m, r)
+            try:
+                ops.set_knob("QLLM_STRIP1_MAX_M", 1)
+                assert ops.plan_describe([w], m).startswith("strip nw=")
+                y_dma = ops.linear_forward(w, xt)
+            finally:
+                ops.reset_knobs()
+            assert O.rel_err(y.cpu().numpy(), y_dma.cpu().numpy()) <= 1e-3
+            yb = ops.linear_forward(w, xt.to(torch.bfloat16))
+            assert yb.dtype == torch.bfloat16 and O.rel_err(yb.float().cpu().numpy(), ref.y64(x)) <= 2e-2
+    # grouped launch of unequal widths at batch 3
+    ds = [synth("GPTQ", 4, 128, 4096, n, "asym", False, i == 0, seed=90 + i) for i, n in enumerate((4096, 1024, 1024))]
+    glayers = [to_layer(d_, DEV) for d_ in ds]          # (kept alive: the descriptors point into their native copies)
+    descs = [l.native_descriptor(0) for l in glayers]
+    assert ops.plan_describe(descs, 3) == "strip1 nw=8 round=16 exact rows=4 grid=strips x 3 layout=strip-major"
+    x = randx(3, 4096, seed=8)
+    for o, d_ in zip(ops.linear_forward_grouped(descs, torch.from_numpy(x).to(DEV)), ds):
+        assert O.rel_err(o.cpu().numpy(), Ref(d_).y16(x)) <= 1e-2
