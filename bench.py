@@ -627,6 +627,19 @@ def main():
         except Exception as e:  # noqa: BLE001  (a side leg must not take the headline down with it)
             extra["batch64_stack"] = {"error": f"{type(e).__name__}: {e}"}
             torch.cuda.synchronize()
+        # batches 2 and 4 (round 6: the batch-1 kernel's four-row forms -- the group's four A rows carry four batch rows)
+        for mb in (2, 4):
+            try:
+                hb = torch.randn(mb, HIDDEN, device=dev, dtype=torch.float16) * 0.1
+                gg, _ = capture(decode_step_fn(stack, hb))
+                ms = time_events(gg.replay, 20)
+                del gg
+                extra[f"decode_stack_batch{mb}"] = {"ms_per_step": round(ms, 4), "tokens_per_s": round(mb * 1e3 / ms, 1), "us_per_layer": round(ms * 1e3 / n_layers, 2),
+                                                    "GBps": round(bytes_per_token(n_layers, mb) / ms / 1e6, 1),
+                                                    "frac_of_hbm_peak": round(bytes_per_token(n_layers, mb) / ms / 1e6 / HBM_PEAK_GBPS, 4)}
+            except Exception as e:  # noqa: BLE001
+                extra[f"decode_stack_batch{mb}"] = {"error": f"{type(e).__name__}: {e}"}
+                torch.cuda.synchronize()
         # the other launch forms of the same step (all through the modules): 7 launches per layer; the reference buffers in place
         for tag, fz, native in (("ungrouped", False, True), ("fused_reference_layout_in_place", True, False)):
             stack.set_fused(fz)
