@@ -236,14 +236,15 @@ def test_three_bit_act_order_runs_on_the_native_path(g, K, N, zk):
     from qllm_amd import ops
     d = synth("GPTQ", 3, g, K, N, zk, True, False, seed=K + N + g)
     layer = to_layer(d, DEV)
-    w = oracle_w(d)
+    ref = Ref(d)   # (the oracle's W with its own g_idx gather, converted once; y16 = its fp32-accumulated matmul beyond 8 rows: a 300-row
+    #                  fp16 matmul on the CPU took two minutes of the suite)
     for m in (1, 16, 300):
         x = randx(m, K, seed=m)
         y = layer(torch.from_numpy(x).to(DEV)).cpu().numpy()
         nd = layer.native_descriptor(0)
         assert layer.act_order is True and nd is not None and layer._perm is not None and nd.bits == 3
         assert ("strip" in ops.plan_describe([nd], m)) if m <= 32 else ("gemm3" in ops.plan_describe([nd], m))
-        assert O.rel_err(y, oracle_y(d, x, w)) <= TOL, (g, K, N, m)
+        assert O.rel_err(y, ref.y16(x)) <= TOL, (g, K, N, m)
 
 
 def test_act_order_nonuniform_groups_use_inplace_gather():
@@ -643,6 +644,7 @@ def test_act_order_siblings_share_one_gather():
     base = synth("GPTQ", 4, g, K, 4096, "asym", True, False, seed=41)
     ds = [base] + [dict(synth("GPTQ", 4, g, K, n, "asym", False, False, seed=42 + i), g_idx=base["g_idx"].copy()) for i, n in enumerate((1024, 1024))]
     layers = [to_layer(d, DEV) for d in ds]
+    refs = [Ref(d) for d in ds]                            # (the oracle's W converted once per layer)
     calls = []
     real = ops.gather_columns
     ops.gather_columns = lambda x, perm: (calls.append(1), real(x, perm))[1]
@@ -652,19 +654,19 @@ def test_act_order_siblings_share_one_gather():
             calls.clear()
             ys = [l(x) for l in layers]
             assert len(calls) == 1, calls
-            for d, y in zip(ds, ys):
-                assert O.rel_err(y.cpu().numpy(), oracle_y(d, x.cpu().numpy())) <= TOL
+            for r, y in zip(refs, ys):
+                assert O.rel_err(y.cpu().numpy(), r.y16(x.cpu().numpy())) <= TOL
             x.mul_(0.5)                                    # same tensor object, new version: never a stale gather
             calls.clear()
             y0 = layers[0](x)
             assert len(calls) == 1
-            assert O.rel_err(y0.cpu().numpy(), oracle_y(ds[0], x.cpu().numpy())) <= TOL
+            assert O.rel_err(y0.cpu().numpy(), refs[0].y16(x.cpu().numpy())) <= TOL
         other_d = synth("GPTQ", 4, g, K, 1024, "asym", True, False, seed=77)   # its own order: its own gather
         other = to_layer(other_d, DEV)
         calls.clear()
         y_o = other(x)
         assert len(calls) == 1
-        assert O.rel_err(y_o.cpu().numpy(), oracle_y(other_d, x.cpu().numpy())) <= TOL
+        assert O.rel_err(y_o.cpu().numpy(), Ref(other_d).y16(x.cpu().numpy())) <= TOL
     finally:
         ops.gather_columns = real
 
