@@ -130,7 +130,7 @@ def test_act_order_siblings_run_as_one_group():
     calls, real = [], ops.gather_columns
     ops.gather_columns = lambda x, perm: (calls.append(1), real(x, perm))[1]
     try:
-        for m in (1, 16, 64, 1024):
+        for m in (1, 16, 64, 2048):
             x = torch.from_numpy(randx(m, K, seed=m)).to(DEV)
             [l(x) for l in grouped]                          # (first pass builds the row-sorted copies and interns the permutation)
             x = x.clone()
