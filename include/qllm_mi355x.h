@@ -158,7 +158,11 @@ int qllm_linear_forward(const qllm_weight_t *w, const void *x, void *y, int32_t 
  * `w` and `y` are HOST arrays of length n_weights (<= 8); all w[i] must agree on K, bits, layout family and
  * group_size.  Decode and mid-batch sizes: M <= 32 (<= 64 for narrow groups) on the strip kernels; native 4-bit layers (N % 64 == 0,
  * K % 64 == 0, group size 32 to 64 rows / 64 / 128) up to M = 128 in one launch of the panel kernel, split-K partials in the
- * workspace (qllm_workspace_bytes of the widest layer x n_weights covers it); QLLM_ERR_UNSUPPORTED otherwise: call layer by layer. */
+ * workspace (qllm_workspace_bytes of the widest layer x n_weights covers it).  Prefill sizes (ABI 6, round 6): from 384 rows, 2..4 four-bit
+ * layers of one storage kind (row-stream or strip-major; not AWQ words in place), N % 128 == 0, K % 64 == 0, at least one 256x128 tile
+ * per CU over the group, run as ONE grid of the prefill kernel (bf16 natively).  When the group's tiles do not fill whole rounds of CUs the
+ * last round is split over K: that needs kCounter (16 KB) + tail_tiles x split x 128 KB of workspace -- at most 16 KB + 32 MB; with less
+ * the launch simply does not split.  QLLM_ERR_UNSUPPORTED otherwise: call layer by layer. */
 int qllm_linear_forward_grouped(const qllm_weight_t *w, void *const *y, int32_t n_weights, const void *x,
                                 int32_t M, int32_t act_dtype, void *workspace, size_t workspace_bytes,
                                 void *stream);
