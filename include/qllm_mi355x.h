@@ -119,7 +119,7 @@ int qllm_is_lab_build(void);
 /* Planner thresholds (ABI 6).  The kernel-selection tree was measured on Llama-2-7B / 70B shapes (profiles/r06_shape_table.md has other
  * families); a deployment may move these thresholds without rebuilding.  Process-global, not synchronised with forward calls running on
  * other threads: set them before serving.  Settable names (values outside the range every built kernel covers are refused):
- *   QLLM_STRIP1 0|1|2, QLLM_STRIP1_MAX_M 1..4, QLLM_PANEL 0|1, QLLM_PANEL_MIN_M 17..129, QLLM_PANEL_GROUP_MIN_M 17..129, QLLM_GEMM2 0|1, QLLM_GEMM3 0|1,
+ *   QLLM_STRIP1 0|1|2, QLLM_STRIP1_MAX_M 1..4, QLLM_STRIP1_3BIT 0|1, QLLM_PANEL 0|1, QLLM_PANEL_MIN_M 17..129, QLLM_PANEL_GROUP_MIN_M 17..129, QLLM_GEMM2 0|1, QLLM_GEMM3 0|1,
  *   QLLM_GEMM2_MIN_M >= 33, QLLM_GEMM3_MIN_M >= 0 (0: the measured 384 / 768 line), QLLM_GEMM2_SPLITK 0|1, QLLM_GEMM3_TAIL 0|1, QLLM_GEMM3_BF16 0|1, QLLM_GEMM3_GROUP 0|1,
  *   QLLM_SKINNY_MAX_M 0..64, QLLM_STRIP_MIN >= 0, QLLM_BITGEMV 0|1.
  * qllm_plan_describe() reflects them (it asks the same decision functions the forward calls execute).  QLLM_ERR_INVALID for any other name. */

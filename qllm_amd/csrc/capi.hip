@@ -37,6 +37,7 @@ struct Settable {
   int value, set;
 };
 static Settable kSettable[] = {
+    {"QLLM_STRIP1_3BIT", 0, 1, 0, 0},          // 0: 3-bit layers at batch 1 on the general strip kernel
     {"QLLM_STRIP1_MAX_M", 1, 4, 0, 0},         // 1: batches 2..4 on strip_dma instead of the batch-1 kernel's four-row forms
     {"QLLM_STRIP1", 0, 2, 0, 0},               // 0: batch-1 calls on the general strip kernel (the round-4 path); 2: only 128-wide groups on the batch-1 kernel
     {"QLLM_PANEL", 0, 1, 0, 0},                // 0: no panel kernel (strips to 32 rows, the 256-row tiles above)
@@ -329,7 +330,10 @@ static bool strip_plan(const qllm_weight_t *w, int n, int M, StripPlan *plan) {
         int nw1 = 0, maxs1 = 0;
         // (round 6: 64-wide groups too -- HQQ's default; QLLM_STRIP1 = 2 keeps them on the general kernel)
         const int s1 = knob("QLLM_STRIP1", 1);
-        if (M == 1 && bits == 4 && (w[0].group_size == 128 || (w[0].group_size == 64 && s1 != 2 && w[0].K <= 24576)) && s1 && strip1_shape(w[0].K, strips, compute_units(), &nw1, &maxs1)) {
+        // (round 6: 3-bit layers too -- batch 1, K <= 16384; QLLM_STRIP1_3BIT = 0 keeps them on the general kernel)
+        const bool w4 = bits == 4 && (w[0].group_size == 128 || (w[0].group_size == 64 && s1 != 2 && w[0].K <= 24576));
+        const bool w3 = bits == 3 && (w[0].group_size == 128 || w[0].group_size == 64) && w[0].K <= 16384 && knob("QLLM_STRIP1_3BIT", 1);
+        if (M == 1 && (w4 || w3) && s1 && strip1_shape(w[0].K, strips, compute_units(), &nw1, &maxs1)) {
           plan->one_nw = nw1;
           plan->one_maxs = maxs1;
         }
@@ -388,6 +392,7 @@ static int run_strip1(const StripPlan &pl, const qllm_weight_t *w, void *const *
   p.n_groups = w[0].K / w[0].group_size;
   p.group64 = w[0].group_size == 64;
   p.M = M;
+  p.bits3 = w[0].bits == 3;
   p.add_zero_bias = w[0].add_zero_bias;
   p.act_bf16 = (act_dtype == QLLM_BF16);
   p.dbg = (g_timeline && g_timeline_next < g_timeline_slots) ? g_timeline + 24 * (g_timeline_next++) : nullptr;
@@ -914,7 +919,8 @@ static void describe(const Decision &d, const qllm_weight_t *w, int n, int M, si
       const StripPlan &pl = d.strip;
       if (pl.one_nw)
         snprintf(buf, buflen, "strip1 nw=%d round=%d%s%s%s grid=strips x %d layout=strip-major", pl.one_nw, pl.one_maxs,
-                 pl.one_nw * pl.one_maxs == w[0].K / 32 ? " exact" : "", w[0].group_size == 64 ? " g64" : "", M > 1 ? " rows=4" : "", n);
+                 pl.one_nw * pl.one_maxs == w[0].K / 32 ? " exact" : "", w[0].group_size == 64 ? (w[0].bits == 3 ? " g64 bits=3" : " g64") : (w[0].bits == 3 ? " bits=3" : ""),
+                 M > 1 ? " rows=4" : "", n);
       else
         snprintf(buf, buflen, "strip nw=%d cpl=%d spw=%d form=%s row_tiles=%d%s", pl.nw, pl.cpl, pl.spw,
                  pl.ra == 2 ? "dma-A" : (pl.ra ? "register-A" : "lds-slab"), M > 32 ? 4 : (M > 16 ? 2 : 1), pl.sm ? " layout=strip-major" : "");

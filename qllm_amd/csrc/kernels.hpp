@@ -101,7 +101,7 @@ int launch_strip_dma_g128(const StripParams &p, int grid, hipStream_t stream);  
 
 // ---- strip1.hip (batch 1, native layout, 4 bits, 128-wide groups: strip1_kernel.hpp) -------------------------------------------
 struct Strip1Problem {  // 48 bytes
-  const uint32_t *qweight;  // native: [N/16][K/8][16] words
+  const uint32_t *qweight;  // native: [N/16][K/8][16] words (3 bits: [N/16][3 K/32][16])
   const half_t *scales;     // native: [N/16][K/g][16]  (g = 128 or 64)
   const void *qzeros;       // native: [N/16][K/128][2] words (packed), [N/16][K/128][16] halves (fp16), NULL (symmetric)
   const half_t *bias;
@@ -115,6 +115,7 @@ struct Strip1Params {
   int n_groups;   // K / group size (128, or 64: group64)
   int group64;    // 1: 64-wide groups (the G64 instantiations, round 6)
   int M;          // batch rows: 1, or 2..4 on the four-row instantiations (MR = 4, round 6; 128-wide groups)
+  int bits3;      // 1: 3-bit layers (the B3 instantiations, round 6; batch 1, K <= 16384)
   int add_zero_bias;
   int act_bf16;
   uint64_t *dbg;  // diagnostics (qllm_debug_timeline): 24 timestamps for this launch (3 blocks x 8), or NULL

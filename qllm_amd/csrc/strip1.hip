@@ -38,21 +38,30 @@ bool strip1_shape(int K, int blocks, int cus, int *nw, int *maxs) {
   return true;
 }
 
-template <int NW, int MAXS, bool EXACT, bool DBG, bool G64 = false, int MR = 1>
+template <int NW, int MAXS, bool EXACT, bool DBG, bool G64 = false, int MR = 1, bool B3 = false>
 static int launch_t(const Strip1Params &p, dim3 grid, hipStream_t stream) {
   constexpr int lds_bytes = strip1_lds_bytes<NW, MAXS, MR>();
   static_assert(lds_bytes <= 160 * 1024, "LDS of one CU");
   if constexpr (lds_bytes > 64 * 1024) {  // (rounds of 56 / 64 k-steps x 16 waves, or four batch rows: the staged activations)
     static DeviceLatch attr_done;
-    if (int rc = lds_optin(attr_done, (const void *)strip1_kernel<NW, MAXS, EXACT, 2, 4, DBG, false, G64, MR>)) return rc;
+    if (int rc = lds_optin(attr_done, (const void *)strip1_kernel<NW, MAXS, EXACT, 2, 4, DBG, false, G64, MR, B3>)) return rc;
   }
-  hipLaunchKernelGGL((strip1_kernel<NW, MAXS, EXACT, 2, 4, DBG, false, G64, MR>), grid, dim3(NW * 64), lds_bytes, stream, p);
+  hipLaunchKernelGGL((strip1_kernel<NW, MAXS, EXACT, 2, 4, DBG, false, G64, MR, B3>), grid, dim3(NW * 64), lds_bytes, stream, p);
   QLLM_HIP_CHECK(hipGetLastError());
   return QLLM_OK;
 }
 
 template <int NW, int MAXS>
 static int launch_e(const Strip1Params &p, dim3 grid, hipStream_t stream) {
+  if (p.bits3) {  // 3-bit layers (round 6): batch 1, 64- and 128-wide groups, rounds of up to 32 k-steps (two word loads per k-step)
+    if constexpr (MAXS <= 32) {
+      if (p.group64)
+        return (NW * MAXS == p.T) ? launch_t<NW, MAXS, true, false, true, 1, true>(p, grid, stream) : launch_t<NW, MAXS, false, false, true, 1, true>(p, grid, stream);
+      return (NW * MAXS == p.T) ? launch_t<NW, MAXS, true, false, false, 1, true>(p, grid, stream) : launch_t<NW, MAXS, false, false, false, 1, true>(p, grid, stream);
+    } else {
+      return set_error(QLLM_ERR_UNSUPPORTED, "internal: 3-bit layers on the batch-1 kernel stop at K = 16384");
+    }
+  }
   if (p.M > 1) {  // batches 2..4 (round 6): the four-row forms, 128-wide groups, rounds of up to 32 k-steps (LDS: four staged rows per wave)
     if constexpr (MAXS <= 32)
       return (NW * MAXS == p.T) ? launch_t<NW, MAXS, true, false, false, 4>(p, grid, stream) : launch_t<NW, MAXS, false, false, false, 4>(p, grid, stream);
@@ -95,7 +104,7 @@ int launch_strip1_allreduce(const Strip1Params &p, int nw, int maxs, int n_strip
 
 int launch_strip1(const Strip1Params &p, int nw, int maxs, int n_prob, int max_strips, hipStream_t stream) {
   const dim3 grid(max_strips, n_prob);
-  if (p.dbg && !p.group64 && p.M == 1) {  // diagnostics instantiations (timeline stamps): the two Llama-2-7B forms
+  if (p.dbg && !p.group64 && p.M == 1 && !p.bits3) {  // diagnostics instantiations (timeline stamps): the two Llama-2-7B forms
     if (nw == 8 && maxs == 16 && p.T == 128) return launch_t<8, 16, true, true>(p, grid, stream);
     if (nw == 15 && maxs == 24 && p.T < 360) return launch_t<15, 24, false, true>(p, grid, stream);
   }

@@ -68,12 +68,18 @@ constexpr int strip1_lds_bytes() {
 //     the pass -- at batch 1 they carry four copies of x.  Here row 4 j + m carries batch row m (rows past M: zeros), so accumulator
 //     register m of lane (g, i) is batch row m of column i for group g: the same weight stream, the same MFMAs, four times the staging
 //     and four corrections per lane.  (Until then batches 2..4 took strip_dma.hpp: ~1.5 x a batch-1 launch.)
-template <int NW, int MAXS, bool EXACT, int NCH = 2, int LVL = 4, bool DBG = false, bool AR = false, bool G64 = false, int MR = 1>
+// B3 (round 6): 3-bit layers (configs[3] mixes 3- and 4-bit HQQ layers; at batch 1 the 3-bit ones ran on the general strip kernel: 43 us per
+//     Llama-2-7B decoder layer against 28.6 for the 4-bit ones).  The recipe of strip_kernel.hpp inside this kernel's skeleton: a k-step is
+//     three word rows of the strip; lane (g, i) needs bits [24 g, 24 g + 24) of column i's 96: two word loads (rows {0,0,1,2}[g] and
+//     {0,1,2,2}[g]) + one v_alignbit; fragment slots (k0,k5 | k1,k6 | k2,k7 | k3,k4) taken where the fields sit, their weights
+//     (2,1 | 16,8 | 128,64 | 1,1) divided out of the staged activations (exact: powers of two).
+template <int NW, int MAXS, bool EXACT, int NCH = 2, int LVL = 4, bool DBG = false, bool AR = false, bool G64 = false, int MR = 1, bool B3 = false>
 // (second launch bound = minimum waves per SIMD: 64 registers up to rounds of 24 k-steps -- a CU full of waves -- 128 above)
-__global__ __launch_bounds__(NW * 64, (MAXS <= 24 && !G64 && MR == 1) ? 8 : 4) void strip1_kernel(const Strip1Params p) {
+__global__ __launch_bounds__(NW * 64, (MAXS <= 24 && !G64 && MR == 1 && !B3) ? 8 : 4) void strip1_kernel(const Strip1Params p) {
   static_assert(MAXS % 4 == 0 && MAXS >= 8 && MAXS <= 64, "rounds are whole 128-wide groups, at most 16 of them (round 6: 40 .. 64 k-steps for K up to 32768)");
   static_assert(!(G64 && AR), "the fused all-reduce form is built for 128-wide groups");
   static_assert(MR == 1 || (MR == 4 && !G64 && !AR && !DBG && LVL == 4), "four batch rows: 128-wide groups, the plain form");
+  static_assert(!B3 || (MR == 1 && !AR && !DBG && LVL == 4), "3 bits: the plain batch-1 form");
   constexpr int KPG = G64 ? 2 : 4;        // k-steps per group
   constexpr int NG = MAXS / KPG;          // groups per wave
   constexpr int NPASS = (MAXS + 15) / 16; // accumulator sets: one per 16 k-steps (four 128-wide groups / eight 64-wide ones)
@@ -127,7 +133,7 @@ __global__ __launch_bounds__(NW * 64, (MAXS <= 24 && !G64 && MR == 1) ? 8 : 4) v
   const int zmul = (zk == ZK_PACKED) ? 2 : 8;              // dwords per group row
   const int zoff = (zk == ZK_PACKED) ? (i >> 3) : (i >> 1);
   half_t sc[NPASS][GPL];
-  uint32_t zraw[NPASS][GPL];
+  uint32_t zraw[NPASS][GPL], zraw2[B3 ? NPASS : 1][GPL];  // (zraw2: packed 3-bit zero points are bit 3 i of the group row's 64-bit pair)
 #pragma unroll
   for (int ps = 0; ps < NPASS; ++ps)
 #pragma unroll
@@ -135,12 +141,29 @@ __global__ __launch_bounds__(NW * 64, (MAXS <= 24 && !G64 && MR == 1) ? 8 : 4) v
       // the lane's group(s) of the pass: 4 ps + g (128-wide), 8 ps + 2 g + h (64-wide)
       const int gj = min((G64 ? 8 * ps + 2 * g + h : 4 * ps + g), NG - 1);  // (lanes past the last group re-read it; their sums of x are zero)
       sc[ps][h] = pr.scales[(grow + gj) * 16 + i];
-      zraw[ps][h] = zbase[(grow + gj) * zmul + zoff];
+      if constexpr (B3) {
+        // packed: both words of the pair; fp16: the dword holding the half; symmetric: any valid dword
+        zraw[ps][h] = zbase[(grow + gj) * zmul + ((zk == ZK_PACKED) ? 0 : zoff)];
+        zraw2[ps][h] = zbase[(grow + gj) * zmul + ((zk == ZK_PACKED) ? 1 : zoff)];
+      } else {
+        zraw[ps][h] = zbase[(grow + gj) * zmul + zoff];
+      }
     }
-  const uint32_t *wl = pr.qweight + ((size_t)b * T + tb) * 64 + lane;
-  uint32_t w[MAXS];
+  uint32_t w[MAXS], wh[B3 ? MAXS : 1];
+  if constexpr (B3) {
+    // the strip is [3 T word rows][16]: k-step t = rows 3 t .. 3 t + 2; the lane's 24-bit field straddles rows {0,0,1,2}[g] / {0,1,2,2}[g]
+    const uint32_t *wl3 = pr.qweight + ((size_t)b * T + tb) * 48 + i;
+    const int lo_off = (g == 0 ? 0 : g - 1) * 16, hi_off = (g == 3 ? 2 : g) * 16;
 #pragma unroll
-  for (int s = 0; s < MAXS; ++s) w[s] = __builtin_nontemporal_load(wl + s * 64);
+    for (int s = 0; s < MAXS; ++s) {
+      w[s] = __builtin_nontemporal_load(wl3 + s * 48 + lo_off);
+      wh[s] = __builtin_nontemporal_load(wl3 + s * 48 + hi_off);
+    }
+  } else {
+    const uint32_t *wl = pr.qweight + ((size_t)b * T + tb) * 64 + lane;
+#pragma unroll
+    for (int s = 0; s < MAXS; ++s) w[s] = __builtin_nontemporal_load(wl + s * 64);
+  }
   __builtin_amdgcn_sched_barrier(0);
   if constexpr (DBG) {
     if (dbg_slot && lane == 0) dbg_slot[1] = __builtin_amdgcn_s_memrealtime();
@@ -166,18 +189,23 @@ __global__ __launch_bounds__(NW * 64, (MAXS <= 24 && !G64 && MR == 1) ? 8 : 4) v
       const half8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
       half8_t xv = p.act_bf16 ? bf16x8_to_h8(xa[m][u]) : __builtin_bit_cast(half8_t, xa[m][u]);
       xv = xkeep[u] ? xv : zero8;
-      const half8_t pv = a_perm_04152637(xv);
+      // fragment slot order and per-slot divisors (the B-fragment construction below):
+      //   4 bits: (k0,k4 | k1,k5 | k2,k6 | k3,k7), divisors (1,1 | 16,16 | 1,1 | 16,16);  3 bits: (k0,k5 | k1,k6 | k2,k7 | k3,k4), (2,1 | 16,8 | 128,64 | 1,1)
+      const half8_t pv = B3 ? __builtin_shufflevector(xv, xv, 0, 5, 1, 6, 2, 7, 3, 4) : a_perm_04152637(xv);
       const half2_t p0 = {pv[0], pv[1]}, p1 = {pv[2], pv[3]}, p2 = {pv[4], pv[5]}, p3 = {pv[6], pv[7]};
-      const half2_t sixteenth = {(half_t)0.0625f, (half_t)0.0625f};
-      const half2_t q1 = p1 * sixteenth, q3 = p3 * sixteenth;
+      const half2_t d0 = B3 ? half2_t{(half_t)0.5f, (half_t)1.f} : half2_t{(half_t)1.f, (half_t)1.f};
+      const half2_t d1 = B3 ? half2_t{(half_t)0.0625f, (half_t)0.125f} : half2_t{(half_t)0.0625f, (half_t)0.0625f};
+      const half2_t d2 = B3 ? half2_t{(half_t)0.0078125f, (half_t)0.015625f} : half2_t{(half_t)1.f, (half_t)1.f};
+      const half2_t d3 = B3 ? half2_t{(half_t)1.f, (half_t)1.f} : half2_t{(half_t)0.0625f, (half_t)0.0625f};
+      const half2_t q0 = B3 ? p0 * d0 : p0, q1 = p1 * d1, q2 = B3 ? p2 * d2 : p2, q3 = B3 ? p3 : p3 * d3;
       const half2_t one = {(half_t)1.f, (half_t)1.f};
       float a = __builtin_amdgcn_fdot2(p0, one, 0.f, false);
       a = __builtin_amdgcn_fdot2(p1, one, a, false);
       a = __builtin_amdgcn_fdot2(p2, one, a, false);
       a = __builtin_amdgcn_fdot2(p3, one, a, false);
-      float c = __builtin_amdgcn_fdot2(p0, one, 0.f, false);
+      float c = __builtin_amdgcn_fdot2(q0, one, 0.f, false);
       c = __builtin_amdgcn_fdot2(q1, one, c, false);
-      c = __builtin_amdgcn_fdot2(p2, one, c, false);
+      c = __builtin_amdgcn_fdot2(q2, one, c, false);
       c = __builtin_amdgcn_fdot2(q3, one, c, false);
       // all-reduce over the 16 lanes of the row (= the 128 k of one group): xor 1, xor 2, half-row mirror, row mirror
       a = dpp_add1<0xB1>(a); c = dpp_add1<0xB1>(c);
@@ -194,7 +222,7 @@ __global__ __launch_bounds__(NW * 64, (MAXS <= 24 && !G64 && MR == 1) ? 8 : 4) v
         a = dpp_add1<0x140>(a); c = dpp_add1<0x140>(c);
         sx[m][u] = a; sxp[m][u] = c;   // lane (g, i): sums of group 4 u + g of the wave (batch row m)
       }
-      *(half8_t *)(wbase + m * (XL * 1024) + 16 * (lane + 64 * u)) = half8_t{p0.x, p0.y, q1.x, q1.y, p2.x, p2.y, q3.x, q3.y};
+      *(half8_t *)(wbase + m * (XL * 1024) + 16 * (lane + 64 * u)) = half8_t{q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, q3.x, q3.y};
     }
   } else {
 #pragma unroll
@@ -209,13 +237,15 @@ __global__ __launch_bounds__(NW * 64, (MAXS <= 24 && !G64 && MR == 1) ? 8 : 4) v
   float sf[NPASS][GPL], cf[NPASS][NCF];
   if constexpr (LVL >= 4) {
     const uint32_t zsel_p = (zk == ZK_PACKED) ? 0xffffffffu : 0u, zsel_h = (zk == ZK_F16) ? 0xffffffffu : 0u;
-    const uint32_t zsel_s = (zk == ZK_SYM) ? __builtin_bit_cast(uint32_t, 8.0f) : 0u;
+    const uint32_t zsel_s = (zk == ZK_SYM) ? __builtin_bit_cast(uint32_t, B3 ? 4.0f : 8.0f) : 0u;
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps)
 #pragma unroll
       for (int h = 0; h < GPL; ++h) {
         const uint32_t zr = zraw[ps][h];
-        const float zp = (float)(((zr >> (4 * (i & 7))) + (uint32_t)p.add_zero_bias) & 15u);
+        float zp;
+        if constexpr (B3) zp = (float)(((uint32_t)(((((uint64_t)zraw2[ps][h]) << 32) | zr) >> (3 * i)) + (uint32_t)p.add_zero_bias) & 7u);
+        else zp = (float)(((zr >> (4 * (i & 7))) + (uint32_t)p.add_zero_bias) & 15u);
         const float zh = (float)__builtin_bit_cast(half_t, (uint16_t)((i & 1) ? (zr >> 16) : (zr & 0xffffu)));
         const float zf = __builtin_bit_cast(float, (__builtin_bit_cast(uint32_t, zp) & zsel_p) | (__builtin_bit_cast(uint32_t, zh) & zsel_h) | zsel_s);
         sf[ps][h] = (float)sc[ps][h];
@@ -245,15 +275,32 @@ __global__ __launch_bounds__(NW * 64, (MAXS <= 24 && !G64 && MR == 1) ? 8 : 4) v
   float4_t acc[NPASS][NCH];
   const uint32_t mask_lo = nib_mask_vgpr();  // 0x000f000f
   const uint32_t mask_hi = mask_lo << 4;     // 0x00f000f0
+  // 3-bit field masks, derived from the opaque VGPR so hipcc can fuse each (x & m) | magic into one v_and_or_b32
+  const uint32_t m3a = ((mask_lo & 0x7u) << 1) | (mask_lo & 0x00070000u);  // 0x0007000E
+  const uint32_t m3b = m3a << 3, m3c = m3a << 6;                           // 0x00380070, 0x01C00380
+  const uint32_t m3d = mask_lo & 0x00000007u, m3e = mask_lo & 0x00070000u;
+  const uint32_t shift3 = (uint32_t)((32 - 8 * g) & 31);                   // funnel shift {0, 24, 16, 8}[g]
 #pragma unroll
   for (int s = 0; s < MAXS; ++s) {
     const int j = s / KPG, ps = s >> 4, ch = s % NCH;
     if constexpr (LVL >= 2) {
       const half8_t av = *(const half8_t *)((const char *)lds + a_addr[j] + 64 * s);
       if constexpr (LVL >= 3) {
-        const uint32_t wv = w[s], w8 = wv >> 8;
-        const half2_t b0 = as_h2((wv & mask_lo) | kMagic), b1 = as_h2((wv & mask_hi) | kMagic);
-        const half2_t b2 = as_h2((w8 & mask_lo) | kMagic), b3 = as_h2((w8 & mask_hi) | kMagic);
+        half2_t b0, b1, b2, b3;
+        if constexpr (B3) {
+          // f: the lane's 8 three-bit values at bits 0, 3, .., 21.  f1 = f << 1 puts q5, q6, q7 at bits 16, 19, 22 (upper half, offsets
+          // 0, 3, 6) and q0, q1, q2 at bits 1, 4, 7 (lower half): three v_and_or give (2 q0, q5), (16 q1, 8 q6), (128 q2, 64 q7) on top of
+          // 1024; q3, q4 (bits 9, 12) are moved to bit 0 / bit 16 separately
+          const uint32_t f = __builtin_amdgcn_alignbit(wh[s], w[s], shift3), f1 = f << 1;
+          b0 = as_h2((f1 & m3a) | kMagic);
+          b1 = as_h2((f1 & m3b) | kMagic);
+          b2 = as_h2((f1 & m3c) | kMagic);
+          b3 = as_h2(((f << 4) & m3e) | (((f >> 9) & m3d) | kMagic));
+        } else {
+          const uint32_t wv = w[s], w8 = wv >> 8;
+          b0 = as_h2((wv & mask_lo) | kMagic); b1 = as_h2((wv & mask_hi) | kMagic);
+          b2 = as_h2((w8 & mask_lo) | kMagic); b3 = as_h2((w8 & mask_hi) | kMagic);
+        }
         const half8_t bf = {b0.x, b0.y, b1.x, b1.y, b2.x, b2.y, b3.x, b3.y};
         const bool first = (s - 16 * ps) < NCH;  // the chain's first k-step of this pass
         const float4_t cin = first ? float4_t{0.f, 0.f, 0.f, 0.f} : acc[ps][ch];

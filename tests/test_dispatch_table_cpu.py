@@ -143,7 +143,8 @@ def test_native_layout_decode_routes(lib):
     # ... other group sizes, 3 bits and K beyond 512 k-steps stay on the general strip kernel
     assert plan(lib, [W(4096, 4096, 64, layout=NATIVE)], 1) == "strip1 nw=4 round=32 exact g64 grid=strips x 1" + sm      # (round 6: 64-wide groups on the batch-1 kernel)
     assert plan(lib, [W(4096, 4096, 32, layout=NATIVE)], 1).startswith("strip nw=")                                       # 32-wide groups: the general kernel
-    assert plan(lib, [W(4096, 4096, 128, 3, NATIVE)], 1).startswith("strip nw=16")
+    assert plan(lib, [W(4096, 4096, 128, 3, NATIVE)], 1) == "strip1 nw=4 round=32 exact bits=3 grid=strips x 1" + sm          # (round 6: 3-bit layers too)
+    assert plan(lib, [W(28672, 4096, 128, 3, NATIVE)], 1).startswith("strip nw=16")                                           # 3 bits: K <= 16384
     assert plan(lib, [W(28672, 8192, layout=NATIVE)], 1) == "strip1 nw=16 round=56 exact grid=strips x 1" + sm     # (round 6; the general kernel until then)
     assert plan(lib, [W(36864, 8192, layout=NATIVE)], 1).startswith("strip nw=16")                                # K > 32768: the general strip kernel
     assert plan(lib, [W(18944, 3584, layout=NATIVE)], 1) == "strip1 nw=16 round=40 grid=strips x 1" + sm       # round 6: K up to 24576 (Qwen2-7B down_proj)
@@ -238,7 +239,7 @@ def test_native_layout_decode_routes(lib):
     assert plan(lib, [h3], 4).startswith("strip nw=16 cpl=1 spw=8 form=dma-A")
     assert plan(lib, [W(11008, 4096, 64, 4, NATIVE_F16Z)], 1) == "strip1 nw=15 round=24 g64 grid=strips x 1" + sm   # (was the register-A form: 12.3 us)
     assert plan(lib, [W(28672, 4096, 64, 4, NATIVE_F16Z)], 1).startswith("strip nw=16")                             # 64-wide groups: K <= 24576
-    assert plan(lib, [h3], 1).startswith("strip nw=16 cpl=1 spw=8 form=lds-slab")
+    assert plan(lib, [h3], 1) == "strip1 nw=4 round=32 exact g64 bits=3 grid=strips x 1" + sm   # (round 6; the lds-slab form until then: 43 -> 34 us per 7B layer)
     assert plan(lib, [h3], 16).startswith("strip nw=16 cpl=1 spw=8 form=dma-A")
     # 3 bits from 17 rows: the panel kernel (exact q - z from the slot-scaled patterns), up to 64 rows; the 256-row tiles above
     assert plan(lib, [h3], 32) == "strip nw=8 cpl=1 spw=16 form=dma-A row_tiles=2" + sm      # (up to 4096 x 4096 and 32 rows: strips)

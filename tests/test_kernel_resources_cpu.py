@@ -95,8 +95,9 @@ def test_batch1_kernel_keeps_a_cu_full_of_waves():
     for n, (vgpr, spill) in res.items():
         m = re.search(r"strip1_kernelILi(\d+)ELi(\d+)E", n)
         nw, maxs = int(m.group(1)), int(m.group(2))
-        # (round 6: the 64-wide-group forms carry twice the group addresses / scales, the four-row forms four sets of sums: <= 128)
-        wide = "ELb1ELi1EEEvNS_12Strip1ParamsE" in n or "ELi4EEEvNS_12Strip1ParamsE" in n
+        # (round 6: the 64-wide-group forms carry twice the group addresses / scales, the four-row forms four sets of sums, the 3-bit forms two words per k-step: <= 128)
+        tail = re.search(r"ELb([01])ELi(\d)ELb([01])EEEvNS_12Strip1ParamsE$", n)   # <..., G64, MR, B3>
+        wide = tail is not None and (tail.group(1) == "1" or tail.group(2) != "1" or tail.group(3) == "1")
         assert spill == 0 and vgpr <= (64 if maxs <= 24 and not wide else 128), (n, nw, maxs, vgpr, spill)
 
 

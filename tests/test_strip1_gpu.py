@@ -201,3 +201,48 @@ def test_batches_2_to_4_on_the_four_row_forms(K, N):
     x = randx(3, 4096, seed=8)
     for o, d_ in zip(ops.linear_forward_grouped(descs, torch.from_numpy(x).to(DEV)), ds):
         assert O.rel_err(o.cpu().numpy(), Ref(d_).y16(x)) <= 1e-2
+
+
+B3_FORMS = [(1024, "nw=4 round=8 exact"), (2048, "nw=4 round=16 exact"), (3584, "nw=7 round=16 exact"), (4096, "nw=8 round=16 exact"),
+            (5120, "nw=8 round=24"), (8192, "nw=8 round=32 exact"), (11008, "nw=15 round=24"), (14336, "nw=16 round=32"), (16384, "nw=16 round=32 exact")]
+
+
+@pytest.mark.parametrize("K,form", B3_FORMS)
+def test_every_form_with_3_bit_weights(K, form):
+    """Round 6: 3-bit layers on the batch-1 kernel (B3 forms: two word loads + a funnel shift per k-step, slot-weighted patterns) -- HQQ g64
+    with fp16 zero points, GPTQ g128 packed and symmetric zero points, bias, bf16; against the oracle, float64 of the reference's W, and the
+    general strip kernel on the same descriptor."""
+    from qllm_amd import ops
+    N = 1024 if K > 8192 else 8192
+    for layout, g, zk, bias in (("HQQ", 64, "asym", False), ("GPTQ", 128, "asym", True), ("GPTQ", 128, "sym", False), ("HQQ", 128, "asym", True)):
+        d = synth(layout, 3, g, K, N, zk, False, bias, seed=K + g + len(layout))
+        d["scales"] = (d["scales"].astype(np.float32) * (4096 / K) ** 0.5).astype(np.float16)
+        layer = to_layer(d, DEV)
+        w, keep = _native(layer, d, zk)
+        plan = ops.plan_describe([w], 1)
+        assert plan.startswith("strip1 " + form) and " bits=3 " in plan and ((" g64 " in plan) == (g == 64)), plan
+        ref = Ref(d)
+        for seed in (1, 2):
+            x = randx(1, K, seed=seed)
+            y = ops.linear_forward(w, torch.from_numpy(x).to(DEV)).cpu().numpy()
+            assert O.rel_err(y, ref.y16(x)) <= 1e-2, (layout, g, zk)
+            assert O.rel_err(y.astype(np.float64), ref.y64(x)) <= 2e-3, (layout, g, zk)
+        xb = torch.from_numpy(randx(1, K, seed=9)).to(DEV).to(torch.bfloat16)
+        yb = ops.linear_forward(w, xb)
+        assert yb.dtype == torch.bfloat16 and O.rel_err(yb.float().cpu().numpy(), ref.y64(xb.float().cpu().numpy().astype(np.float16))) <= 2e-2
+        try:
+            ops.set_knob("QLLM_STRIP1_3BIT", 0)
+            assert ops.plan_describe([w], 1).startswith("strip nw=")
+            x = torch.from_numpy(randx(1, K, seed=1)).to(DEV)
+            y_gen = ops.linear_forward(w, x)
+        finally:
+            ops.reset_knobs()
+        assert O.rel_err(ops.linear_forward(w, x).cpu().numpy(), y_gen.cpu().numpy()) <= 1e-3
+    # grouped q/k/v of unequal widths, HQQ g64 3 bits
+    ds = [synth("HQQ", 3, 64, 4096, n, "asym", False, i == 1, seed=170 + i) for i, n in enumerate((4096, 1024, 1024))]
+    glayers = [to_layer(d_, DEV) for d_ in ds]
+    descs = [l.native_descriptor(0) for l in glayers]
+    assert ops.plan_describe(descs, 1) == "strip1 nw=8 round=16 exact g64 bits=3 grid=strips x 3 layout=strip-major"
+    x = randx(1, 4096, seed=4)
+    for o, d_ in zip(ops.linear_forward_grouped(descs, torch.from_numpy(x).to(DEV)), ds):
+        assert O.rel_err(o.cpu().numpy(), Ref(d_).y16(x)) <= 1e-2
